@@ -1,0 +1,96 @@
+/*
+ * mc_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the reference's Monte Carlo path (marcomatteo/MonteCarloCUDA,
+ * {double,single}_precision/MonteCarloHost.c and the device formulas of MonteCarloKernel.cu).
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library;
+ * the product (montecarlocuda_amd/csrc) never links, imports or calls it.
+ *
+ * Parity status: PINNED.  The "host" family below is bit-checked against the unmodified
+ * reference MonteCarloHost.c compiled in the dev container (oracle/_ref, recipe in
+ * oracle/Makefile) and against the golden vectors committed under tests/golden/ that were
+ * generated from it (tests/golden/gen_golden.py).
+ *
+ * Two families, both for f32 and f64 (suffix _f32 / _f64):
+ *
+ *  orc_host_*  : the reference CPU algorithm on the reference CPU random stream
+ *                (glibc rand() + cosine-branch Box-Muller, srand(seed)).  Bit-for-bit equal
+ *                to the compiled reference under a pinned time() seed -- "hop A".
+ *
+ *  orc_dev_*   : the reference DEVICE formulas (MonteCarloKernel.cu:67-129,222-262) evaluated
+ *                on the product's counter-based Philox4x32-10 stream, path by path, in the
+ *                stated precision with libm.  This is what the HIP kernels are compared
+ *                against on identical counters -- "hop B".
+ */
+#ifndef MC_ORACLE_H_
+#define MC_ORACLE_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* All fields are doubles so one struct serves both precisions (an f32 value is exact in f64). */
+typedef struct {
+    double expected;    /* price (discounted mean) or CVA          */
+    double confidence;  /* 95 % half width, 1.96 s / sqrt(n)        */
+    double sum;         /* sum of per-path values                   */
+    double sum2;        /* sum of squared per-path values           */
+    long long n;        /* paths simulated                          */
+} orc_result;
+
+/* Stream domains: counter word 3 of the Philox block (keeps product streams disjoint). */
+#define ORC_DOMAIN_VANILLA 1u
+#define ORC_DOMAIN_BASKET  2u
+#define ORC_DOMAIN_CVA     3u
+
+/* Philox4x32-10 (Salmon et al., SC'11; same generator rocRAND/cuRAND ship). */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* Closing formulas shared by every estimator: reference MonteCarloHost.c:220-228 /
+ * MonteCarloKernel.cu:420-423 (discount = exp(-rT) for prices, 1 for CVA :466). fp64. */
+void orc_closing(double sum, double sum2, long long n, double discount,
+                 double *expected, double *confidence);
+
+#define ORC_DECL(X, REAL)                                                                        \
+    /* deterministic pieces */                                                                   \
+    REAL orc_cnd_##X(REAL d);                                                                    \
+    REAL orc_bs_call_##X(REAL s, REAL k, REAL r, REAL v, REAL t);                                \
+    void orc_chol_##X(int n, const REAL *c, REAL *a);                                            \
+    /* reference CPU stream */                                                                   \
+    void orc_host_uniforms_##X(unsigned seed, int count, REAL *out);                             \
+    void orc_host_gaussians_##X(unsigned seed, int count, REAL *out);                            \
+    void orc_host_vanilla_##X(REAL s, REAL k, REAL r, REAL v, REAL t, int paths, unsigned seed,  \
+                              orc_result *out);                                                  \
+    void orc_host_basket_##X(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,  \
+                             const REAL *w, REAL k, REAL t, REAL r, int paths, unsigned seed,    \
+                             int vol_in_diffusion, orc_result *out);                             \
+    void orc_host_cva_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint, REAL lgd,         \
+                          int n_grid, int paths, unsigned seed, orc_result *out);                \
+    /* product stream (Philox), device formulas */                                               \
+    void orc_dev_normals_##X(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block,      \
+                             REAL *z);                                                           \
+    void orc_dev_vanilla_##X(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,              \
+                             uint64_t first_path, uint64_t n_paths, REAL *payoffs,               \
+                             orc_result *out);                                                   \
+    void orc_dev_basket_##X(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,   \
+                            const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,                \
+                            uint64_t first_path, uint64_t n_paths, REAL *payoffs,                \
+                            orc_result *out);                                                    \
+    void orc_dev_cva_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint, REAL lgd,          \
+                         int n_grid, uint64_t seed, uint64_t first_path, uint64_t n_paths,       \
+                         REAL *values, orc_result *out);
+
+ORC_DECL(f32, float)
+ORC_DECL(f64, double)
+
+/* Number of normals one Philox block yields: 4 in f32 (one u32 per uniform), 2 in f64
+ * (two u32 per uniform). */
+#define ORC_NORMALS_PER_BLOCK_F32 4
+#define ORC_NORMALS_PER_BLOCK_F64 2
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_ORACLE_H_ */

@@ -1,0 +1,384 @@
+/*
+ * mc_oracle_impl.h -- TEST INFRASTRUCTURE ONLY; precision-generic body, included twice by
+ * mc_oracle.c with
+ *     REAL   float | double          X      f32 | f64
+ *     SQRT_R sqrtf | sqrt            LOG_R  logf | log          EXP_R expf | exp
+ *
+ * Reference line numbers are for double_precision/ ("dp/"); the single_precision/ twin
+ * ("sp/") is the same text with float/sqrtf/logf/expf (SURVEY.md conventions).  Where the two
+ * differ in more than the type, both are cited.
+ *
+ * NOTE ON LITERALS: the reference mixes double literals (0.5, 1.0, -2.0, 2.0*M_PI, 1.96) into
+ * float expressions in sp/.  C's usual arithmetic conversions make those sub-expressions
+ * double, and the bits depend on it.  The host family below therefore spells every
+ * promotion as an explicit cast, so that one body reproduces dp/ and sp/ bit for bit.
+ */
+
+#define ORC_CAT_(a, b) a##_##b
+#define ORC_CAT(a, b) ORC_CAT_(a, b)
+#define FN(name) ORC_CAT(name, X)
+
+/* ===================================================================================== */
+/*  Deterministic pieces                                                                  */
+/* ===================================================================================== */
+
+/* Hastings / Abramowitz-Stegun 26.2.17 normal CDF.  dp/MonteCarloHost.c:124-136 (identical
+ * constants on the device, dp/MonteCarloKernel.cu:110-123). */
+REAL FN(orc_cnd)(REAL d)
+{
+    const REAL a1 = (REAL)0.31938153, a2 = (REAL)-0.356563782, a3 = (REAL)1.781477937;
+    const REAL a4 = (REAL)-1.821255978, a5 = (REAL)1.330274429;
+    const REAL inv_sqrt_2pi = (REAL)0.39894228040143267793994605993438;
+    /* `1.0 / (1.0 + 0.2316419 * fabs(d))` is a double expression in both precisions */
+    REAL kk = (REAL)(1.0 / (1.0 + 0.2316419 * fabs((double)d)));
+    REAL poly = kk * (a1 + kk * (a2 + kk * (a3 + kk * (a4 + kk * a5))));
+    /* `- 0.5 * d * d` is double; the exponential is taken in REAL */
+    REAL tail = inv_sqrt_2pi * EXP_R((REAL)(-0.5 * (double)d * (double)d)) * poly;
+    if (d > 0)
+        tail = (REAL)(1.0 - (double)tail);
+    return tail;
+}
+
+/* Closed-form Black-Scholes call.  dp/MonteCarloHost.c:139-143. */
+REAL FN(orc_bs_call)(REAL s, REAL k, REAL r, REAL v, REAL t)
+{
+    REAL sqrt_t = SQRT_R(t);
+    double num = (double)LOG_R(s / k) + ((double)r + 0.5 * (double)v * (double)v) * (double)t;
+    REAL d1 = (REAL)(num / (double)(v * sqrt_t));
+    REAL d2 = d1 - v * sqrt_t;
+    return s * FN(orc_cnd)(d1) - k * EXP_R(-r * t) * FN(orc_cnd)(d2);
+}
+
+/* Cholesky, column by column, with the reference's zero-pivot rule (a column whose pivot is
+ * not positive is left zero).  dp/MonteCarloHost.c:90-105.  Row-major n x n, runtime n. */
+void FN(orc_chol)(int n, const REAL *c, REAL *a)
+{
+    REAL *work = (REAL *)malloc(sizeof(REAL) * (size_t)n);
+    for (int col = 0; col < n; col++) {
+        for (int row = 0; row < n; row++) {
+            a[row * n + col] = 0;
+            if (row < col)
+                continue;
+            work[row] = c[row * n + col];
+            for (int q = 0; q < col; q++)
+                work[row] -= a[col * n + q] * a[row * n + q];
+            if (work[col] > 0)
+                a[row * n + col] = work[row] / SQRT_R(work[col]);
+        }
+    }
+    free(work);
+}
+
+/* ===================================================================================== */
+/*  Reference CPU random stream: glibc rand(), cosine-branch Box-Muller                    */
+/* ===================================================================================== */
+
+/* dp/MonteCarloHost.c:111-114 */
+static REAL FN(host_rand_between)(REAL lo, REAL hi)
+{
+    REAL x = (REAL)rand() / (REAL)(RAND_MAX);
+    return hi * x + (REAL)(1.0f - x) * lo; /* 1.0f - x: float in sp, promoted in dp */
+}
+
+/* dp/MonteCarloHost.c:117-121; sp/:118-122 keeps `cos` and `2.0 * M_PI` in double */
+static REAL FN(host_gaussian)(REAL mu, REAL sigma)
+{
+    REAL x = FN(host_rand_between)(0, 1);
+    REAL y = FN(host_rand_between)(0, 1);
+    REAL radius = SQRT_R((REAL)(-2.0 * (double)LOG_R(x)));
+    double c = cos(2.0 * M_PI * (double)y);
+    return (REAL)((double)mu + (double)sigma * ((double)radius * c));
+}
+
+void FN(orc_host_uniforms)(unsigned seed, int count, REAL *out)
+{
+    srand(seed);
+    for (int i = 0; i < count; i++)
+        out[i] = FN(host_rand_between)(0, 1);
+}
+
+void FN(orc_host_gaussians)(unsigned seed, int count, REAL *out)
+{
+    srand(seed);
+    for (int i = 0; i < count; i++)
+        out[i] = FN(host_gaussian)(0, 1);
+}
+
+/* closing, reference arithmetic: dp/MonteCarloHost.c:220-228 (prices, discounted) and
+ * :270-275 (CVA, not discounted).  sp/ does all of it in float with sqrtf/expf. */
+static void FN(host_close)(REAL sum, REAL sum2, int paths, int discounted, REAL r, REAL t,
+                           orc_result *out)
+{
+    REAL mean = sum / (REAL)paths;
+    REAL price = discounted ? EXP_R(-r * t) * mean : mean;
+    REAL dev = SQRT_R(((REAL)paths * sum2 - sum * sum) / ((REAL)paths * (REAL)(paths - 1)));
+    /* `1.96 * dev / sqrt(paths)`: double in dp (sqrt of an int), `1.96 * dev / sqrtf(paths)`
+     * in sp = double * float / float -> double, stored into a REAL field */
+    REAL conf = (REAL)(1.96 * (double)dev / (double)SQRT_R((REAL)paths));
+    out->expected = (double)price;
+    out->confidence = (double)conf;
+    out->sum = (double)sum;
+    out->sum2 = (double)sum2;
+    out->n = paths;
+}
+
+/* Vanilla: dp/MonteCarloHost.c:170-173 (payoff) inside :185-199 (loop). */
+void FN(orc_host_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, int paths, unsigned seed,
+                          orc_result *out)
+{
+    REAL sum = 0, sum2 = 0;
+    srand(seed);
+    for (int i = 0; i < paths; i++) {
+        REAL g = FN(host_gaussian)(0, 1);
+        double drift = ((double)r - 0.5 * (double)v * (double)v) * (double)t;
+        REAL diffusion = g * SQRT_R(t) * v;
+        REAL value = s * EXP_R((REAL)(drift + (double)diffusion)) - k;
+        REAL payoff = value > 0 ? value : 0;
+        sum += payoff;
+        sum2 += payoff * payoff;
+    }
+    FN(host_close)(sum, sum2, paths, 1, r, t, out);
+}
+
+/* Basket: dp/MonteCarloHost.c:150-161 (correlated normals: n draws, FULL n x n product,
+ * + drift), :176-183 (terminal spots) and :200-218 (loop).
+ *   vol_in_diffusion = 1 : si = v[i]*g[i]*sqrt(t)   (sp/MonteCarloHost.c:182, and the device)
+ *   vol_in_diffusion = 0 : si =      g[i]*sqrt(t)   (dp/MonteCarloHost.c:180 -- the reference
+ *                          dp CPU bug; kept ONLY so the unmodified dp object
+ *                          pins stream / mat-vec / accumulation order bit for bit) */
+void FN(orc_host_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                         const REAL *w, REAL k, REAL t, REAL r, int paths, unsigned seed,
+                         int vol_in_diffusion, orc_result *out)
+{
+    REAL sum = 0, sum2 = 0;
+    REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)n * 2);
+    REAL *bt = g + n;
+    srand(seed);
+    for (int i = 0; i < paths; i++) {
+        for (int a = 0; a < n; a++)
+            g[a] = FN(host_gaussian)(0, 1);
+        for (int a = 0; a < n; a++) {
+            REAL acc = 0;
+            for (int b = 0; b < n; b++)
+                acc += p[a * n + b] * g[b];
+            bt[a] = acc;
+        }
+        for (int a = 0; a < n; a++)
+            bt[a] += d[a];
+        REAL basket = 0;
+        for (int a = 0; a < n; a++) {
+            REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
+            REAL si = vol_in_diffusion ? v[a] * bt[a] * SQRT_R(t) : bt[a] * SQRT_R(t);
+            /* the reference first fills s[] then forms the weighted sum; same values */
+            bt[a] = s[a] * EXP_R(mu + si);
+        }
+        for (int a = 0; a < n; a++)
+            basket += bt[a] * w[a];
+        REAL value = basket - k;
+        REAL payoff = value > 0 ? value : 0;
+        sum += payoff;
+        sum2 += payoff * payoff;
+    }
+    free(g);
+    FN(host_close)(sum, sum2, paths, 1, r, t, out);
+}
+
+/* CVA, HOST ordering: dp/MonteCarloHost.c:231-276.  Exposure at step j is priced at the
+ * spot of step j-1 (the new spot is stored after the exposure, :254-261);
+ * time to maturity by repeated subtraction, exposure zero once it goes negative (:255-259). */
+void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd,
+                      int n_grid, int paths, unsigned seed, orc_result *out)
+{
+    REAL sum = 0, sum2 = 0;
+    REAL dt = t0 / n_grid;
+    srand(seed);
+    for (int i = 0; i < paths; i++) {
+        REAL spot = s0, ttm = t0, acc = 0;
+        for (int j = 1; j <= n_grid; j++) {
+            REAL dpd = EXP_R(-(dt * (j - 1)) * defint) - EXP_R(-(dt * j) * defint);
+            /* one GBM step over dt, dp/MonteCarloHost.c:164-167 */
+            REAL g = FN(host_gaussian)(0, 1);
+            REAL x = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)dt +
+                            (double)(g * SQRT_R(dt) * v));
+            REAL next = spot * EXP_R(x);
+            ttm -= dt;
+            REAL ee = (ttm < 0) ? 0 : FN(orc_bs_call)(spot, k, r, v, ttm);
+            acc += dpd * ee;
+            spot = next;
+        }
+        acc *= lgd;
+        sum += acc;
+        sum2 += acc * acc;
+    }
+    FN(host_close)(sum, sum2, paths, 0, r, t0, out);
+}
+
+/* ===================================================================================== */
+/*  Product random stream (Philox4x32-10, counter-based) + reference DEVICE formulas       */
+/* ===================================================================================== */
+
+/* One Philox block -> NPB normals (NPB = 4 in f32, 2 in f64) by two-branch Box-Muller.
+ *   counter = { unit_lo, unit_hi, block, domain },  key = { seed_lo, seed_hi }
+ * f32: u = fma(x, 2^-32, 2^-33) in (0,1];  f64: u = ((x_hi:x_lo >> 12) + 0.5) 2^-52 in (0,1)
+ *   radius = sqrt(-2 ln u_a),  z_even = radius cos(2 pi u_b),  z_odd = radius sin(2 pi u_b)
+ * The f32 radius is written with log2 (the HIP kernel's v_log_f32 is a base-2 log). */
+void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
+{
+    uint32_t ctr[4] = {(uint32_t)unit, (uint32_t)(unit >> 32), block, domain};
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    uint32_t x[4];
+    orc_philox4x32_10(ctr, key, x);
+#if ORC_IS_F32
+    for (int h = 0; h < 2; h++) {
+        float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f);
+        float ub = fmaf((float)x[2 * h + 1], 0x1p-32f, 0x1p-33f);
+        float radius = sqrtf(-1.3862943611198906f * log2f(ua)); /* -2 ln 2 */
+        double ang = 2.0 * M_PI * (double)ub;
+        z[2 * h] = radius * (float)cos(ang);
+        z[2 * h + 1] = radius * (float)sin(ang);
+    }
+#else
+    uint64_t ka = ((uint64_t)x[1] << 20) | (x[0] >> 12);
+    uint64_t kb = ((uint64_t)x[3] << 20) | (x[2] >> 12);
+    double ua = ((double)ka + 0.5) * 0x1p-52;
+    double ub = ((double)kb + 0.5) * 0x1p-52;
+    double radius = sqrt(-2.0 * log(ua));
+    double ang = 2.0 * M_PI * ub;
+    z[0] = radius * cos(ang);
+    z[1] = radius * sin(ang);
+#endif
+}
+
+static void FN(dev_finish)(double sum, double sum2, uint64_t n, double discount, orc_result *out)
+{
+    if (!out)
+        return;
+    out->sum = sum;
+    out->sum2 = sum2;
+    out->n = (long long)n;
+    orc_closing(sum, sum2, (long long)n, discount, &out->expected, &out->confidence);
+}
+
+/* Vanilla, device formula dp/MonteCarloKernel.cu:67-71:
+ *   payoff = max(S exp((r - v^2/2) T + v sqrt(T) z) - K, 0)
+ * Path p draws normal (p mod NPB) of Philox unit (p div NPB), block 0, domain VANILLA.
+ * Per-path values in REAL, (sum, sum2) accumulated in fp64. */
+void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
+                         uint64_t first_path, uint64_t n_paths, REAL *payoffs, orc_result *out)
+{
+    const REAL drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)t);
+    const REAL vol = (REAL)((double)v * sqrt((double)t));
+    double sum = 0, sum2 = 0;
+    REAL z[ORC_NPB];
+    uint64_t have = (uint64_t)-1;
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t p = first_path + i;
+        uint64_t unit = p / ORC_NPB;
+        if (unit != have) {
+            FN(orc_dev_normals)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
+            have = unit;
+        }
+        REAL value = s * EXP_R(drift + vol * z[p % ORC_NPB]) - k;
+        REAL payoff = value > 0 ? value : 0;
+        if (payoffs)
+            payoffs[i] = payoff;
+        sum += (double)payoff;
+        sum2 += (double)payoff * (double)payoff;
+    }
+    FN(dev_finish)(sum, sum2, n_paths, exp(-(double)r * (double)t), out);
+}
+
+/* Basket, device formulas dp/MonteCarloKernel.cu:74-87 (bt = P g + d, P = Cholesky factor
+ * held in the correlation slot) and :89-101 (s_j = S_j exp((r - v_j^2/2) T + v_j bt_j sqrt T),
+ * payoff = max(sum_j w_j s_j - K, 0)).  Path p is Philox unit p; block b holds normals
+ * g[b*NPB .. b*NPB+NPB-1]; domain BASKET.  The product multiplies only the lower triangle
+ * (structural zeros of the factor skipped) -- identical values whenever the upper triangle is
+ * zero, which Chol guarantees (dp/MonteCarloHost.c:95). */
+void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                        const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,
+                        uint64_t first_path, uint64_t n_paths, REAL *payoffs, orc_result *out)
+{
+    int nblk = (n + ORC_NPB - 1) / ORC_NPB;
+    REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)(nblk * ORC_NPB));
+    const REAL sqrt_t = (REAL)sqrt((double)t);
+    double sum = 0, sum2 = 0;
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t path = first_path + i;
+        for (int b = 0; b < nblk; b++)
+            FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
+        REAL basket = 0;
+        for (int a = 0; a < n; a++) {
+            REAL bt = 0;
+            for (int b = 0; b <= a; b++)
+                bt += p[a * n + b] * g[b];
+            bt += d[a];
+            REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
+            REAL sa = s[a] * EXP_R(mu + v[a] * bt * sqrt_t);
+            basket += sa * w[a];
+        }
+        REAL value = basket - k;
+        REAL payoff = value > 0 ? value : 0;
+        if (payoffs)
+            payoffs[i] = payoff;
+        sum += (double)payoff;
+        sum2 += (double)payoff * (double)payoff;
+    }
+    free(g);
+    FN(dev_finish)(sum, sum2, n_paths, exp(-(double)r * (double)t), out);
+}
+
+/* CVA, DEVICE ordering dp/MonteCarloKernel.cu:241-262: at step j the spot is advanced FIRST
+ * and the exposure is the Black-Scholes value at the NEW spot and the new time to maturity
+ * (SURVEY 2.3 #7).  Time to maturity by repeated subtraction in REAL; once negative the
+ * exposure is 0 and no normal is consumed (:249-256).
+ * Product semantics stated in DESIGN.md and mirrored here:
+ *   - default-probability increment dp_j = e^{-lambda t_{j-1}} - e^{-lambda t_j},
+ *     t_j = dt*j, evaluated in fp64 via expm1 and rounded to REAL;
+ *   - residual maturity exactly 0 -> exposure = intrinsic max(s-K,0), the limit of the
+ *     closed form, instead of 0/0;
+ *   - step j uses normal (j-1): Philox unit = path, block = (j-1) div NPB, domain CVA;
+ *   - result is LGD * sum_j dp_j ee_j, NOT discounted (dp/MonteCarloKernel.cu:259,466). */
+void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid,
+                     uint64_t seed, uint64_t first_path, uint64_t n_paths, REAL *values,
+                     orc_result *out)
+{
+    const REAL dt = t0 / n_grid;
+    const REAL step_drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)dt);
+    const REAL step_vol = (REAL)((double)v * sqrt((double)dt));
+    double sum = 0, sum2 = 0;
+    REAL z[ORC_NPB];
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t path = first_path + i;
+        REAL spot = s0, ttm = t0, acc = 0;
+        for (int j = 1; j <= n_grid; j++) {
+            double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
+            /* e^{-l a} - e^{-l b} = -e^{-l a} expm1(-l (b - a)) */
+            REAL dpd = (REAL)(-exp(-(double)defint * t_prev) * expm1(-(double)defint * (t_now - t_prev)));
+            REAL ee = 0;
+            ttm -= dt;
+            if (ttm >= 0) {
+                int idx = j - 1;
+                if (idx % ORC_NPB == 0)
+                    FN(orc_dev_normals)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
+                spot = spot * EXP_R(step_drift + step_vol * z[idx % ORC_NPB]);
+                if (ttm == 0) {
+                    REAL iv = spot - k;
+                    ee = iv > 0 ? iv : 0;
+                } else {
+                    ee = FN(orc_bs_call)(spot, k, r, v, ttm);
+                }
+            }
+            acc += dpd * ee;
+        }
+        acc *= lgd;
+        if (values)
+            values[i] = acc;
+        sum += (double)acc;
+        sum2 += (double)acc * (double)acc;
+    }
+    FN(dev_finish)(sum, sum2, n_paths, 1.0, out);
+}
+
+#undef FN
+#undef ORC_CAT
+#undef ORC_CAT_

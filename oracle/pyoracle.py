@@ -1,0 +1,305 @@
+"""ctypes bindings for the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product package ``montecarlocuda_amd`` never does.
+
+Two libraries are bound here:
+
+* ``oracle/liboracle.so`` -- our CPU restatement (``mc_oracle.c``), see ``mc_oracle.h``.
+* ``oracle/_ref/libref_{f32,f64}_n{3,4,16}.so`` -- the UNMODIFIED reference CPU path
+  (``/root/reference/{single,double}_precision/MonteCarloHost.c``) compiled by
+  ``oracle/Makefile``; present only where that recipe ran (dev container) or where the
+  prebuilt files travelled (GPU box).  Struct layouts mirror reference ``MonteCarlo.h:32-65``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from functools import lru_cache
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liboracle.so")
+REF_DIR = os.path.join(HERE, "_ref")
+
+DOMAIN_VANILLA, DOMAIN_BASKET, DOMAIN_CVA = 1, 2, 3
+NPB = {"f32": 4, "f64": 2}
+CT = {"f32": C.c_float, "f64": C.c_double}
+NP = {"f32": np.float32, "f64": np.float64}
+
+
+class OrcResult(C.Structure):
+    _fields_ = [("expected", C.c_double), ("confidence", C.c_double), ("sum", C.c_double),
+                ("sum2", C.c_double), ("n", C.c_longlong)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def build(force: bool = False) -> None:
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    if force or not os.path.exists(LIB_PATH) or \
+            os.path.getmtime(LIB_PATH) < max(os.path.getmtime(os.path.join(HERE, f))
+                                             for f in ("mc_oracle.c", "mc_oracle_impl.h", "mc_oracle.h")):
+        subprocess.check_call(["make", "-C", HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    if os.path.isdir("/root/reference/double_precision"):
+        subprocess.check_call(["make", "-C", HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+@lru_cache(maxsize=None)
+def lib() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        build()
+    L = C.CDLL(LIB_PATH)
+    u32p = C.POINTER(C.c_uint32)
+    L.orc_philox4x32_10.argtypes = [u32p, u32p, u32p]
+    L.orc_philox4x32_10.restype = None
+    L.orc_closing.argtypes = [C.c_double, C.c_double, C.c_longlong, C.c_double,
+                              C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_closing.restype = None
+    for X in ("f32", "f64"):
+        R = CT[X]
+        RP = C.POINTER(R)
+        res = C.POINTER(OrcResult)
+
+        def f(name):
+            return getattr(L, f"{name}_{X}")
+        f("orc_cnd").argtypes = [R]
+        f("orc_cnd").restype = R
+        f("orc_bs_call").argtypes = [R] * 5
+        f("orc_bs_call").restype = R
+        f("orc_chol").argtypes = [C.c_int, RP, RP]
+        f("orc_chol").restype = None
+        for nm in ("orc_host_uniforms", "orc_host_gaussians"):
+            f(nm).argtypes = [C.c_uint, C.c_int, RP]
+            f(nm).restype = None
+        f("orc_host_vanilla").argtypes = [R] * 5 + [C.c_int, C.c_uint, res]
+        f("orc_host_basket").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R, C.c_int, C.c_uint,
+                                         C.c_int, res]
+        f("orc_host_cva").argtypes = [R] * 7 + [C.c_int, C.c_int, C.c_uint, res]
+        f("orc_dev_normals").argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, RP]
+        f("orc_dev_vanilla").argtypes = [R] * 5 + [C.c_uint64, C.c_uint64, C.c_uint64, RP, res]
+        f("orc_dev_basket").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R, C.c_uint64,
+                                        C.c_uint64, C.c_uint64, RP, res]
+        f("orc_dev_cva").argtypes = [R] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, RP, res]
+        for nm in ("orc_host_vanilla", "orc_host_basket", "orc_host_cva", "orc_dev_normals",
+                   "orc_dev_vanilla", "orc_dev_basket", "orc_dev_cva"):
+            f(nm).restype = None
+    return L
+
+
+def _arr(a, X):
+    a = np.ascontiguousarray(a, dtype=NP[X])
+    return a, a.ctypes.data_as(C.POINTER(CT[X]))
+
+
+# ------------------------------------------------------------------------------------------
+# thin pythonic wrappers
+# ------------------------------------------------------------------------------------------
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, o)
+    return [int(v) for v in o]
+
+
+def closing(s, s2, n, discount=1.0):
+    e, c = C.c_double(), C.c_double()
+    lib().orc_closing(s, s2, n, discount, C.byref(e), C.byref(c))
+    return e.value, c.value
+
+
+def cnd(X, d):
+    return getattr(lib(), f"orc_cnd_{X}")(d)
+
+
+def bs_call(X, s, k, r, v, t):
+    return getattr(lib(), f"orc_bs_call_{X}")(s, k, r, v, t)
+
+
+def chol(X, c):
+    c = np.asarray(c, dtype=NP[X])
+    n = c.shape[0]
+    cc, cp = _arr(c, X)
+    out = np.zeros((n, n), dtype=NP[X])
+    getattr(lib(), f"orc_chol_{X}")(n, cp, out.ctypes.data_as(C.POINTER(CT[X])))
+    return out
+
+
+def host_uniforms(X, seed, count):
+    out = np.zeros(count, dtype=NP[X])
+    getattr(lib(), f"orc_host_uniforms_{X}")(seed, count, out.ctypes.data_as(C.POINTER(CT[X])))
+    return out
+
+
+def host_gaussians(X, seed, count):
+    out = np.zeros(count, dtype=NP[X])
+    getattr(lib(), f"orc_host_gaussians_{X}")(seed, count, out.ctypes.data_as(C.POINTER(CT[X])))
+    return out
+
+
+def host_vanilla(X, opt, paths, seed):
+    r = OrcResult()
+    getattr(lib(), f"orc_host_vanilla_{X}")(opt["s"], opt["k"], opt["r"], opt["v"], opt["t"],
+                                            paths, seed, C.byref(r))
+    return r.as_dict()
+
+
+def host_basket(X, b, paths, seed, vol_in_diffusion=None):
+    """b: dict(s, v, p (factor, n x n), d, w, k, t, r).  vol_in_diffusion defaults to what the
+    reference host of that precision does (f64: 0 = dp bug, f32: 1)."""
+    if vol_in_diffusion is None:
+        vol_in_diffusion = 1 if X == "f32" else 0
+    n = len(b["s"])
+    keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
+    r = OrcResult()
+    getattr(lib(), f"orc_host_basket_{X}")(n, *[p for _, p in keep], b["k"], b["t"], b["r"],
+                                           paths, seed, vol_in_diffusion, C.byref(r))
+    return r.as_dict()
+
+
+def host_cva(X, c, paths, seed):
+    """c: dict(s,k,r,v,t, defint, lgd, n_grid)."""
+    r = OrcResult()
+    getattr(lib(), f"orc_host_cva_{X}")(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"],
+                                        c["lgd"], c["n_grid"], paths, seed, C.byref(r))
+    return r.as_dict()
+
+
+def dev_normals(X, seed, domain, unit, block):
+    out = np.zeros(NPB[X], dtype=NP[X])
+    getattr(lib(), f"orc_dev_normals_{X}")(seed, domain, unit, block,
+                                           out.ctypes.data_as(C.POINTER(CT[X])))
+    return out
+
+
+def dev_vanilla(X, opt, seed, first, n, want_paths=True):
+    out = np.zeros(n if want_paths else 0, dtype=NP[X])
+    ptr = out.ctypes.data_as(C.POINTER(CT[X])) if want_paths else None
+    r = OrcResult()
+    getattr(lib(), f"orc_dev_vanilla_{X}")(opt["s"], opt["k"], opt["r"], opt["v"], opt["t"], seed,
+                                           first, n, ptr, C.byref(r))
+    return out, r.as_dict()
+
+
+def dev_basket(X, b, seed, first, n, want_paths=True):
+    nn = len(b["s"])
+    keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
+    out = np.zeros(n if want_paths else 0, dtype=NP[X])
+    ptr = out.ctypes.data_as(C.POINTER(CT[X])) if want_paths else None
+    r = OrcResult()
+    getattr(lib(), f"orc_dev_basket_{X}")(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], seed,
+                                          first, n, ptr, C.byref(r))
+    return out, r.as_dict()
+
+
+def dev_cva(X, c, seed, first, n, want_paths=True):
+    out = np.zeros(n if want_paths else 0, dtype=NP[X])
+    ptr = out.ctypes.data_as(C.POINTER(CT[X])) if want_paths else None
+    r = OrcResult()
+    getattr(lib(), f"orc_dev_cva_{X}")(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"],
+                                       c["lgd"], c["n_grid"], seed, first, n, ptr, C.byref(r))
+    return out, r.as_dict()
+
+
+# ------------------------------------------------------------------------------------------
+# compiled reference (oracle/_ref)
+# ------------------------------------------------------------------------------------------
+def ref_available(X="f64", n=3) -> bool:
+    return os.path.exists(os.path.join(REF_DIR, f"libref_{X}_n{n}.so"))
+
+
+def ref_types(X, n):
+    """ctypes mirrors of reference MonteCarlo.h:32-65 for precision X and asset count n."""
+    R = CT[X]
+
+    class OptionData(C.Structure):
+        _fields_ = [("s", R), ("k", R), ("r", R), ("v", R), ("t", R)]
+
+    class MultiOptionData(C.Structure):
+        _fields_ = [("s", R * n), ("v", R * n), ("p", (R * n) * n), ("d", R * n), ("w", R * n),
+                    ("k", R), ("t", R), ("r", R)]
+
+    class OptionValue(C.Structure):
+        _fields_ = [("Expected", R), ("Confidence", R)]
+
+    class CVA(C.Structure):
+        _fields_ = [("defInt", R), ("lgd", R), ("ns", C.c_int), ("option", OptionData),
+                    ("n", C.c_int)]
+
+    return OptionData, MultiOptionData, OptionValue, CVA
+
+
+class Ref:
+    """The unmodified reference host object for one (precision, N), with time() pinned."""
+
+    def __init__(self, X="f64", n=3):
+        self.X, self.n = X, n
+        self.L = C.CDLL(os.path.join(REF_DIR, f"libref_{X}_n{n}.so"))
+        self.OptionData, self.MultiOptionData, self.OptionValue, self.CVA = ref_types(X, n)
+        R = CT[X]
+        self.L.mcref_set_seed.argtypes = [C.c_uint]
+        self.L.host_bsCall.argtypes = [self.OptionData]
+        self.L.host_bsCall.restype = R
+        self.L.host_vanillaOpt.argtypes = [self.OptionData, C.c_int]
+        self.L.host_vanillaOpt.restype = self.OptionValue
+        self.L.host_basketOpt.argtypes = [C.POINTER(self.MultiOptionData), C.c_int]
+        self.L.host_basketOpt.restype = self.OptionValue
+        self.L.host_cvaEquityOption.argtypes = [C.POINTER(self.CVA), C.c_int]
+        self.L.host_cvaEquityOption.restype = self.OptionValue
+        self.L.Chol.argtypes = [C.POINTER((R * n) * n), C.POINTER((R * n) * n)]
+        self.L.Chol.restype = None
+        self.L.randMinMax.argtypes = [R, R]
+        self.L.randMinMax.restype = R
+        self.libc = C.CDLL(None)
+
+    def opt(self, o):
+        return self.OptionData(o["s"], o["k"], o["r"], o["v"], o["t"])
+
+    def bs_call(self, o):
+        return float(self.L.host_bsCall(self.opt(o)))
+
+    def vanilla(self, o, paths, seed):
+        self.L.mcref_set_seed(seed)
+        v = self.L.host_vanillaOpt(self.opt(o), paths)
+        return float(v.Expected), float(v.Confidence)
+
+    def multi(self, b):
+        m = self.MultiOptionData()
+        n = self.n
+        for i in range(n):
+            m.s[i], m.v[i], m.d[i], m.w[i] = b["s"][i], b["v"][i], b["d"][i], b["w"][i]
+            for j in range(n):
+                m.p[i][j] = b["p"][i][j]
+        m.k, m.t, m.r = b["k"], b["t"], b["r"]
+        return m
+
+    def basket(self, b, paths, seed):
+        self.L.mcref_set_seed(seed)
+        m = self.multi(b)
+        v = self.L.host_basketOpt(C.byref(m), paths)
+        return float(v.Expected), float(v.Confidence)
+
+    def cva(self, c, paths, seed):
+        self.L.mcref_set_seed(seed)
+        s = self.CVA(c["defint"], c["lgd"], 0, self.opt(c), c["n_grid"])
+        v = self.L.host_cvaEquityOption(C.byref(s), paths)
+        return float(v.Expected), float(v.Confidence)
+
+    def chol(self, c):
+        n = self.n
+        R = CT[self.X]
+        a = ((R * n) * n)()
+        cc = ((R * n) * n)()
+        for i in range(n):
+            for j in range(n):
+                cc[i][j] = c[i][j]
+        self.L.Chol(C.byref(cc), C.byref(a))
+        return np.array([[a[i][j] for j in range(n)] for i in range(n)], dtype=NP[self.X])
+
+    def uniforms(self, seed, count):
+        self.libc.srand(C.c_uint(seed))
+        return np.array([self.L.randMinMax(0, 1) for _ in range(count)], dtype=NP[self.X])

@@ -1,0 +1,33 @@
+"""pytest configuration: markers, paths, and the golden-fixture loader."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def fromhex(h):
+    return float.fromhex(h)
+
+
+@pytest.fixture(scope="session")
+def po():
+    """The CPU oracle bindings (test infrastructure)."""
+    from oracle import pyoracle
+    pyoracle.build()
+    return pyoracle
