@@ -1,0 +1,174 @@
+/*
+ * mc_mi355x.h -- C ABI of libmc_mi355x.so, the MI355X (gfx950) Monte Carlo engine.
+ *
+ * Plain C: pointers, sizes and PODs only.  This is the boundary a maintainer of the reference
+ * (marcomatteo/MonteCarloCUDA) binds to in place of MonteCarloKernel.cu; INTEGRATION.md shows
+ * the binding.  Each entry point cites the reference interface it replaces ("dp/" =
+ * double_precision/, the single_precision/ twin is the same code with float).
+ *
+ * Shape of the API
+ *   - an opaque context per GPU owns every device buffer (the reference re-allocates and
+ *     re-seeds on every call: dp/MonteCarloKernel.cu:296-342,344-363 -- that fixed cost is
+ *     what a persistent context removes);
+ *   - *_launch_* enqueue the simulation of the path range [first_path, first_path+n_paths) on
+ *     a caller-supplied HIP stream and leave {sum, sum2, n} (three doubles) in device memory:
+ *     the 24-byte payload of the multi-GPU all-reduce.  No host synchronisation;
+ *   - *_run_* are the synchronous forms: launch, wait, close the estimator on the host;
+ *   - *_paths_* return per-path values for a (small) path range: used by the parity tests.
+ *
+ * Random numbers: Philox4x32-10, key = 64-bit seed, counter = {unit_lo, unit_hi, block,
+ * domain}.  A path's normals depend only on (seed, global path index), never on the launch
+ * geometry or on how a range is split over GPUs.  Layout per product: DESIGN.md "RNG".
+ *
+ * Precision suffix: _f32 simulates in float (sums are still accumulated in double),
+ * _f64 simulates in double.  Struct layouts equal the reference's of that precision.
+ */
+#ifndef MC_MI355X_H_
+#define MC_MI355X_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status ------------------------------------------------------------------------- */
+enum {
+    MC_OK = 0,
+    MC_ERR_INVALID = 1,   /* bad argument (message in mc_last_error)                    */
+    MC_ERR_HIP = 2,       /* a HIP runtime call failed                                   */
+    MC_ERR_NO_DEVICE = 3, /* no usable gfx950 device                                     */
+    MC_ERR_UNSUPPORTED = 4
+};
+/* Text of the last failure on this thread ("" if none). */
+const char *mc_last_error(void);
+
+/* Default seed of the legacy entry points (the reference's device seed is fixed too:
+ * dp/MonteCarloKernel.cu:289). */
+#define MC_DEFAULT_SEED 0x4D435F4D49333535ull
+
+/* Stream domains (Philox counter word 3). */
+#define MC_DOMAIN_VANILLA 1u
+#define MC_DOMAIN_BASKET 2u
+#define MC_DOMAIN_CVA 3u
+
+#define MC_MAX_ASSETS 16 /* compiled basket sizes: 1..16 */
+
+/* ---- inputs (layouts == reference MonteCarlo.h of that precision) ------------------- */
+typedef struct { float s, k, r, v, t; } mc_option_f32;   /* OptionData, sp/MonteCarlo.h:33-39 */
+typedef struct { double s, k, r, v, t; } mc_option_f64;  /* OptionData, dp/MonteCarlo.h:32-38 */
+
+/* Basket with a RUNTIME asset count (the reference fixes N at compile time,
+ * dp/MonteCarlo.h:16,41-50).  p = row-major n x n lower-triangular Cholesky factor. */
+typedef struct {
+    int n;
+    const float *s, *v, *p, *d, *w;
+    float k, t, r;
+} mc_basket_f32;
+typedef struct {
+    int n;
+    const double *s, *v, *p, *d, *w;
+    double k, t, r;
+} mc_basket_f64;
+
+/* CVA of one call: dp/MonteCarlo.h:57-65 without the unused `ns`. */
+typedef struct { float defint, lgd; mc_option_f32 option; int n_grid; } mc_cva_f32;
+typedef struct { double defint, lgd; mc_option_f64 option; int n_grid; } mc_cva_f64;
+
+/* ---- outputs ------------------------------------------------------------------------ */
+typedef struct {
+    double expected;    /* discounted mean payoff (price) or CVA                           */
+    double confidence;  /* 1.96 s / sqrt(n)        dp/MonteCarloKernel.cu:421-422          */
+    double sum, sum2;   /* sum and sum of squares of the per-path values                   */
+    uint64_t n;         /* paths simulated                                                 */
+    float kernel_ms;    /* device time of the simulation + reduction kernels (HIP events)  */
+} mc_result;
+
+/* ---- context ------------------------------------------------------------------------ */
+typedef struct mc_context mc_context;
+
+int mc_device_count(void);
+/* Create the per-GPU context (replaces dp/MonteCarloKernel.cu:296 MonteCarlo_init).
+ * blocks = simulation grid size; 0 picks the default (8 workgroups of 256 per CU). */
+int mc_context_create(int device, int blocks, mc_context **out);
+/* Replaces dp/MonteCarloKernel.cu:344 MonteCarlo_closing. */
+void mc_context_destroy(mc_context *ctx);
+int mc_context_device(const mc_context *ctx);
+int mc_context_blocks(const mc_context *ctx);
+/* Name / CU count / clock of the context's device, for logs. */
+int mc_context_info(const mc_context *ctx, char *name, int name_len, int *compute_units, int *clock_mhz);
+
+/* ---- asynchronous launches ------------------------------------------------------------
+ * d_triple: DEVICE pointer to 3 doubles, overwritten with {sum, sum2, n}.
+ * stream  : hipStream_t passed as void*; NULL = the context's own stream.
+ * Replace the kernel launch + D2H + host block-sum of dp/MonteCarloKernel.cu:365-419
+ * (vanilla :381, basket :394) and :433-465 (CVA :448). */
+int mc_vanilla_launch_f32(mc_context *ctx, const mc_option_f32 *opt, uint64_t seed,
+                          uint64_t first_path, uint64_t n_paths, double *d_triple, void *stream);
+int mc_vanilla_launch_f64(mc_context *ctx, const mc_option_f64 *opt, uint64_t seed,
+                          uint64_t first_path, uint64_t n_paths, double *d_triple, void *stream);
+int mc_basket_launch_f32(mc_context *ctx, const mc_basket_f32 *opt, uint64_t seed,
+                         uint64_t first_path, uint64_t n_paths, double *d_triple, void *stream);
+int mc_basket_launch_f64(mc_context *ctx, const mc_basket_f64 *opt, uint64_t seed,
+                         uint64_t first_path, uint64_t n_paths, double *d_triple, void *stream);
+int mc_cva_launch_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
+                      uint64_t first_path, uint64_t n_paths, double *d_triple, void *stream);
+int mc_cva_launch_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
+                      uint64_t first_path, uint64_t n_paths, double *d_triple, void *stream);
+
+/* ---- synchronous runs (launch + wait + closing formulas) --------------------------------
+ * Replace dev_vanillaOpt / dev_basketOpt / dev_cvaEquityOption (dp/MonteCarloKernel.cu:
+ * 500,483,517) with an explicit seed, a 64-bit path range and a status code. */
+int mc_vanilla_run_f32(mc_context *ctx, const mc_option_f32 *opt, uint64_t seed,
+                       uint64_t first_path, uint64_t n_paths, mc_result *out);
+int mc_vanilla_run_f64(mc_context *ctx, const mc_option_f64 *opt, uint64_t seed,
+                       uint64_t first_path, uint64_t n_paths, mc_result *out);
+int mc_basket_run_f32(mc_context *ctx, const mc_basket_f32 *opt, uint64_t seed,
+                      uint64_t first_path, uint64_t n_paths, mc_result *out);
+int mc_basket_run_f64(mc_context *ctx, const mc_basket_f64 *opt, uint64_t seed,
+                      uint64_t first_path, uint64_t n_paths, mc_result *out);
+int mc_cva_run_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
+                   uint64_t first_path, uint64_t n_paths, mc_result *out);
+int mc_cva_run_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
+                   uint64_t first_path, uint64_t n_paths, mc_result *out);
+
+/* ---- per-path values, for parity tests ---------------------------------------------------
+ * h_out: HOST pointer to n_paths values (undiscounted payoffs / per-path CVA).  Same kernels
+ * as above with a store of every value added; n_paths <= 2^26. */
+int mc_vanilla_paths_f32(mc_context *ctx, const mc_option_f32 *opt, uint64_t seed,
+                         uint64_t first_path, uint64_t n_paths, float *h_out);
+int mc_vanilla_paths_f64(mc_context *ctx, const mc_option_f64 *opt, uint64_t seed,
+                         uint64_t first_path, uint64_t n_paths, double *h_out);
+int mc_basket_paths_f32(mc_context *ctx, const mc_basket_f32 *opt, uint64_t seed,
+                        uint64_t first_path, uint64_t n_paths, float *h_out);
+int mc_basket_paths_f64(mc_context *ctx, const mc_basket_f64 *opt, uint64_t seed,
+                        uint64_t first_path, uint64_t n_paths, double *h_out);
+int mc_cva_paths_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
+                     uint64_t first_path, uint64_t n_paths, float *h_out);
+int mc_cva_paths_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
+                     uint64_t first_path, uint64_t n_paths, double *h_out);
+/* The normals of Philox blocks (unit = first_unit .. first_unit+n_units-1, block, domain):
+ * 4 per unit in f32, 2 per unit in f64, written unit-major to the HOST array h_out. */
+int mc_normals_f32(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,
+                   uint64_t n_units, uint32_t block, float *h_out);
+int mc_normals_f64(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,
+                   uint64_t n_units, uint32_t block, double *h_out);
+
+/* ---- host-side helpers -------------------------------------------------------------- */
+/* Closing formulas of dp/MonteCarloKernel.cu:420-423 (discount = exp(-rT)) and :466-468
+ * (discount = 1), in fp64, from an (all-reduced) triple. */
+void mc_closing(double sum, double sum2, uint64_t n, double discount, double *expected,
+                double *confidence);
+/* Contiguous shard of `total` paths owned by `rank` of `world`: [*first, *first + *count).
+ * rank g owns [floor(gP/G), floor((g+1)P/G)). */
+void mc_shard_range(uint64_t total, int rank, int world, uint64_t *first, uint64_t *count);
+/* Cholesky with the reference's semantics (dp/MonteCarloHost.c:90-105: column-oriented,
+ * a non-positive pivot leaves its column zero).  Row-major n x n; returns the number of
+ * non-positive pivots met (0 = the input was positive definite). */
+int mc_chol_f32(int n, const float *c, float *a);
+int mc_chol_f64(int n, const double *c, double *a);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_MI355X_H_ */

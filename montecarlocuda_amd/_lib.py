@@ -1,0 +1,122 @@
+"""ctypes declarations for libmc_mi355x.so (include/mc_mi355x.h).
+
+Loading is strict: if the shared library is missing the import of this module raises -- there
+is no Python or CPU fallback for the simulation path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(CSRC, "libmc_mi355x.so")
+LEGACY = {"f64": os.path.join(CSRC, "libmcgpu_f64.so"), "f32": os.path.join(CSRC, "libmcgpu_f32.so")}
+
+MC_OK = 0
+MC_DEFAULT_SEED = 0x4D435F4D49333535
+DOMAIN_VANILLA, DOMAIN_BASKET, DOMAIN_CVA = 1, 2, 3
+MAX_ASSETS = 16
+NPB = {"f32": 4, "f64": 2}
+CT = {"f32": C.c_float, "f64": C.c_double}
+
+
+def build(verbose: bool = False) -> None:
+    """Compile every HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", CSRC, "all"], stdout=out)
+
+
+class OptionF32(C.Structure):
+    _fields_ = [("s", C.c_float), ("k", C.c_float), ("r", C.c_float), ("v", C.c_float), ("t", C.c_float)]
+
+
+class OptionF64(C.Structure):
+    _fields_ = [("s", C.c_double), ("k", C.c_double), ("r", C.c_double), ("v", C.c_double), ("t", C.c_double)]
+
+
+def _basket(R):
+    P = C.POINTER(R)
+
+    class Basket(C.Structure):
+        _fields_ = [("n", C.c_int), ("s", P), ("v", P), ("p", P), ("d", P), ("w", P), ("k", R), ("t", R), ("r", R)]
+    return Basket
+
+
+BasketF32, BasketF64 = _basket(C.c_float), _basket(C.c_double)
+
+
+class CvaF32(C.Structure):
+    _fields_ = [("defint", C.c_float), ("lgd", C.c_float), ("option", OptionF32), ("n_grid", C.c_int)]
+
+
+class CvaF64(C.Structure):
+    _fields_ = [("defint", C.c_double), ("lgd", C.c_double), ("option", OptionF64), ("n_grid", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("expected", C.c_double), ("confidence", C.c_double), ("sum", C.c_double), ("sum2", C.c_double),
+                ("n", C.c_uint64), ("kernel_ms", C.c_float)]
+
+
+OPTION = {"f32": OptionF32, "f64": OptionF64}
+BASKET = {"f32": BasketF32, "f64": BasketF64}
+CVA = {"f32": CvaF32, "f64": CvaF64}
+
+# every symbol include/mc_mi355x.h declares (tests/test_abi.py checks the .so exports them all)
+EXPORTS = ["mc_last_error", "mc_device_count", "mc_context_create", "mc_context_destroy", "mc_context_device",
+           "mc_context_blocks", "mc_context_info", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64"]
+for _x in ("f32", "f64"):
+    for _p in ("vanilla", "basket", "cva"):
+        EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]
+    EXPORTS.append(f"mc_normals_{_x}")
+
+
+def _declare(L: C.CDLL) -> C.CDLL:
+    ctx = C.c_void_p
+    u64 = C.c_uint64
+    L.mc_last_error.restype = C.c_char_p
+    L.mc_last_error.argtypes = []
+    L.mc_device_count.restype = C.c_int
+    L.mc_context_create.argtypes = [C.c_int, C.c_int, C.POINTER(ctx)]
+    L.mc_context_destroy.argtypes = [ctx]
+    L.mc_context_destroy.restype = None
+    L.mc_context_device.argtypes = [ctx]
+    L.mc_context_blocks.argtypes = [ctx]
+    L.mc_context_info.argtypes = [ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mc_closing.argtypes = [C.c_double, C.c_double, u64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.mc_closing.restype = None
+    L.mc_shard_range.argtypes = [u64, C.c_int, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+    L.mc_shard_range.restype = None
+    for X in ("f32", "f64"):
+        R = CT[X]
+        RP = C.POINTER(R)
+        getattr(L, f"mc_chol_{X}").argtypes = [C.c_int, RP, RP]
+        for prod, S in (("vanilla", OPTION[X]), ("basket", BASKET[X]), ("cva", CVA[X])):
+            getattr(L, f"mc_{prod}_launch_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, C.c_void_p, C.c_void_p]
+            getattr(L, f"mc_{prod}_run_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, C.POINTER(Result)]
+            getattr(L, f"mc_{prod}_paths_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, RP]
+        getattr(L, f"mc_normals_{X}").argtypes = [ctx, u64, C.c_uint32, u64, u64, C.c_uint32, RP]
+    return L
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(the HIP engine has no fallback)")
+        _LIB = _declare(C.CDLL(LIB_PATH))
+    return _LIB
+
+
+class McError(RuntimeError):
+    pass
+
+
+def check(rc: int) -> None:
+    if rc != MC_OK:
+        raise McError(f"mc error {rc}: {lib().mc_last_error().decode()}")

@@ -1,0 +1,123 @@
+/*
+ * legacy_abi.c -- the reference's GPU entry points, by name and signature, on the MI355X engine.
+ *
+ * Built twice (see Makefile): libmcgpu_f64.so (default) and libmcgpu_f32.so
+ * (-DMC_SINGLE_PRECISION), each for one asset count N (-DN=<n>, default 3), exactly like the
+ * reference where precision is chosen by directory and N by editing MonteCarlo.h:16.
+ *
+ * Replaces (marcomatteo/MonteCarloCUDA, double_precision/MonteCarloKernel.cu):
+ *   :500 dev_vanillaOpt   :483 dev_basketOpt   :517 dev_cvaEquityOption
+ * Behaviour kept from the reference:
+ *   - paths simulated = numBlocks * (sims / numBlocks)           (:491,508,524 and :413)
+ *   - basket: option->p must already hold the Cholesky factor    (basketOpt.cu:96-99)
+ *   - CVA: cva->n = number of exposure dates, cva->ns ignored    (:527)
+ *   - a fixed seed: the same call returns the same numbers       (:289)
+ *   - any failure prints a message and exits with status 1       (MonteCarlo.h:22-30, :39-46)
+ * Behaviour changed: the device context is created on first use and kept for the
+ * life of the process (the reference allocates, seeds and frees on every call, :296-363);
+ * numThreads is accepted and ignored (it only shaped the reference's reduction, :163);
+ * nothing is printed on success (set MC_VERBOSE=1 for one line per call).
+ * Environment: MC_DEVICE (default 0), MC_SEED (default MC_DEFAULT_SEED), MC_VERBOSE.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "MonteCarlo.h"
+#include "mc_mi355x.h"
+
+#ifdef MC_SINGLE_PRECISION
+#define API(name) name##_f32
+typedef mc_option_f32 api_option;
+typedef mc_basket_f32 api_basket;
+typedef mc_cva_f32 api_cva;
+#else
+#define API(name) name##_f64
+typedef mc_option_f64 api_option;
+typedef mc_basket_f64 api_basket;
+typedef mc_cva_f64 api_cva;
+#endif
+
+static mc_context *g_ctx;
+
+static void die(const char *what)
+{
+    fprintf(stderr, "Error %s: %s\n", what, mc_last_error());
+    exit(1);
+}
+
+static void drop_context(void)
+{
+    mc_context_destroy(g_ctx);
+    g_ctx = NULL;
+}
+
+static mc_context *context(void)
+{
+    if (!g_ctx) {
+        const char *dev = getenv("MC_DEVICE");
+        if (mc_context_create(dev ? atoi(dev) : 0, 0, &g_ctx) != MC_OK)
+            die("creating the device context");
+        atexit(drop_context);
+    }
+    return g_ctx;
+}
+
+static uint64_t seed(void)
+{
+    const char *s = getenv("MC_SEED");
+    return s ? strtoull(s, NULL, 0) : MC_DEFAULT_SEED;
+}
+
+/* the reference's path-count rule; also guards the divisions it leaves unguarded */
+static uint64_t path_count(int numBlocks, int sims)
+{
+    if (numBlocks <= 0 || sims <= 0 || sims / numBlocks <= 0) {
+        fprintf(stderr, "Error: numBlocks=%d, sims=%d give no paths\n", numBlocks, sims);
+        exit(1);
+    }
+    return (uint64_t)numBlocks * (uint64_t)(sims / numBlocks);
+}
+
+static OptionValue finish(const mc_result *r, const char *what)
+{
+    OptionValue v;
+    v.Expected = (mc_real)r->expected;
+    v.Confidence = (mc_real)r->confidence;
+    if (getenv("MC_VERBOSE"))
+        printf("%s: %llu paths, kernel %.3f ms, value %.9g +- %.3g\n", what, (unsigned long long)r->n,
+               r->kernel_ms, r->expected, r->confidence);
+    return v;
+}
+
+OptionValue dev_vanillaOpt(OptionData *opt, int numBlocks, int numThreads, int sims)
+{
+    (void)numThreads;
+    const api_option o = {opt->s, opt->k, opt->r, opt->v, opt->t};
+    mc_result r;
+    if (API(mc_vanilla_run)(context(), &o, seed(), 0, path_count(numBlocks, sims), &r) != MC_OK)
+        die("in dev_vanillaOpt");
+    return finish(&r, "dev_vanillaOpt");
+}
+
+OptionValue dev_basketOpt(MultiOptionData *option, int numBlocks, int numThreads, int sims)
+{
+    (void)numThreads;
+    const api_basket b = {N, option->s, option->v, &option->p[0][0], option->d, option->w,
+                          option->k, option->t, option->r};
+    mc_result r;
+    if (API(mc_basket_run)(context(), &b, seed(), 0, path_count(numBlocks, sims), &r) != MC_OK)
+        die("in dev_basketOpt");
+    return finish(&r, "dev_basketOpt");
+}
+
+OptionValue dev_cvaEquityOption(CVA *cva, int numBlocks, int numThreads, int sims)
+{
+    (void)numThreads;
+    const api_cva c = {cva->defInt, cva->lgd,
+                       {cva->option.s, cva->option.k, cva->option.r, cva->option.v, cva->option.t}, cva->n};
+    mc_result r;
+    if (API(mc_cva_run)(context(), &c, seed(), 0, path_count(numBlocks, sims), &r) != MC_OK)
+        die("in dev_cvaEquityOption");
+    return finish(&r, "dev_cvaEquityOption");
+}

@@ -1,0 +1,670 @@
+// mc_api.hip -- host side of libmc_mi355x.so: the C ABI of include/mc_mi355x.h.
+//
+// Replaces the launcher half of the reference (dp/MonteCarloKernel.cu:296-532): context
+// set-up/tear-down, option upload, kernel launch, partial-sum collection, closing formulas.
+// Differences by design: buffers live in a persistent context instead of being
+// allocated per call; no RNG state; the cross-workgroup reduction runs on the device and the
+// host reads 24 bytes; every entry point returns a status instead of exit(1).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mc_mi355x.h"
+#include "mc_kernels.hpp"
+
+using namespace mc;
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+extern "C" const char *mc_last_error(void) { return g_last_error.c_str(); }
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                            \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(MC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),      \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+static constexpr int MAX_SEGMENTS = 8;  // per call: segments of <= 2^31 units, same high word
+
+struct mc_context {
+    int device = 0;
+    int blocks = 0;
+    int compute_units = 0;
+    int clock_mhz = 0;
+    char name[128] = {0};
+    hipStream_t stream = nullptr;
+    double2 *partials = nullptr;  // MAX_SEGMENTS * blocks + 2 (vanilla edge launches)
+    double *d_triple = nullptr;   // result slot of the synchronous runs
+    double *h_triple = nullptr;   // pinned
+    void *d_out = nullptr;        // per-path dump buffer (tests), grown on demand
+    size_t d_out_bytes = 0;
+    void *d_table = nullptr;      // CVA per-date table
+    void *h_table = nullptr;      // pinned staging for it
+    size_t table_bytes = 0;
+    std::vector<char> table_key;  // inputs the cached table was built from
+    hipEvent_t table_copied = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+extern "C" int mc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+extern "C" int mc_context_create(int device, int blocks, mc_context **out)
+{
+    if (!out)
+        return fail(MC_ERR_INVALID, "mc_context_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(MC_ERR_NO_DEVICE, "no HIP device visible (the HIP engine has no CPU fallback)");
+    if (device < 0 || device >= n)
+        return fail(MC_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    mc_context *c = new mc_context;
+    c->device = device;
+    c->compute_units = prop.multiProcessorCount;
+    c->clock_mhz = prop.clockRate / 1000;
+    snprintf(c->name, sizeof c->name, "%s (%s)", prop.name, prop.gcnArchName);
+    // 8 workgroups of 256 lanes per CU = 8 waves per SIMD: full occupancy for kernels that
+    // stay within 64 VGPRs; enough workgroups (2048 on 256 CUs) to fill all 8 XCDs evenly.
+    c->blocks = blocks > 0 ? blocks : 8 * c->compute_units;
+    if (c->blocks > 65536) {
+        delete c;
+        return fail(MC_ERR_INVALID, "blocks=%d too large", blocks);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&c->partials, sizeof(double2) * ((size_t)MAX_SEGMENTS * c->blocks + 2)));
+    HIPCHK(hipMalloc(&c->d_triple, 3 * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->h_triple, 3 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipEventCreateWithFlags(&c->table_copied, hipEventDisableTiming));
+    *out = c;
+    return MC_OK;
+}
+
+extern "C" void mc_context_destroy(mc_context *c)
+{
+    if (!c)
+        return;
+    (void)hipSetDevice(c->device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->partials);
+    (void)hipFree(c->d_triple);
+    (void)hipHostFree(c->h_triple);
+    (void)hipFree(c->d_out);
+    (void)hipFree(c->d_table);
+    (void)hipHostFree(c->h_table);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->table_copied) (void)hipEventDestroy(c->table_copied);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mc_context_device(const mc_context *c) { return c ? c->device : -1; }
+extern "C" int mc_context_blocks(const mc_context *c) { return c ? c->blocks : 0; }
+extern "C" int mc_context_info(const mc_context *c, char *name, int name_len, int *cus, int *mhz)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    if (name && name_len > 0)
+        snprintf(name, (size_t)name_len, "%s", c->name);
+    if (cus) *cus = c->compute_units;
+    if (mhz) *mhz = c->clock_mhz;
+    return MC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// work planning
+// ---------------------------------------------------------------------------------------
+struct Segment {
+    uint64_t first;
+    uint32_t count;
+};
+
+// Split units [first, first+count) so that no segment crosses a multiple of 2^32 (the high
+// counter word stays wave-uniform) nor exceeds 2^31 units (32-bit strided loop cannot wrap).
+static int plan_segments(uint64_t first, uint64_t count, std::vector<Segment> &out)
+{
+    out.clear();
+    while (count) {
+        uint64_t room = (1ull << 32) - (first & 0xFFFFFFFFull);
+        uint64_t n = count < room ? count : room;
+        if (n > (1ull << 31))
+            n = 1ull << 31;
+        out.push_back({first, (uint32_t)n});
+        first += n;
+        count -= n;
+        if ((int)out.size() > MAX_SEGMENTS)
+            return fail(MC_ERR_INVALID, "path range too large for one call (more than %d segments of 2^31 units); split it",
+                        MAX_SEGMENTS);
+    }
+    return MC_OK;
+}
+
+static Work make_work(uint64_t seed, const Segment &s, uint64_t first_path, uint64_t end_path)
+{
+    Work w;
+    w.seed_lo = (uint32_t)seed;
+    w.seed_hi = (uint32_t)(seed >> 32);
+    w.unit_lo = (uint32_t)s.first;
+    w.unit_hi = (uint32_t)(s.first >> 32);
+    w.n_units = s.count;
+    w.first_path = first_path;
+    w.end_path = end_path;
+    return w;
+}
+
+static int grid_for(const mc_context *c, uint32_t n_units)
+{
+    uint64_t need = ((uint64_t)n_units + GROUP - 1) / GROUP;
+    return (int)(need < (uint64_t)c->blocks ? (need ? need : 1) : c->blocks);
+}
+
+static hipStream_t pick_stream(mc_context *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+
+static int check_common(mc_context *c, const void *opt, uint64_t first, uint64_t n, const void *dst)
+{
+    if (!c) return fail(MC_ERR_INVALID, "NULL context");
+    if (!opt) return fail(MC_ERR_INVALID, "NULL option");
+    if (!dst) return fail(MC_ERR_INVALID, "NULL output pointer");
+    if (n == 0) return fail(MC_ERR_INVALID, "n_paths == 0");
+    if (first + n < first) return fail(MC_ERR_INVALID, "path range overflows 64 bits");
+    if (n > (1ull << 52)) return fail(MC_ERR_INVALID, "n_paths > 2^52 is not exactly representable in the fp64 triple");
+    return MC_OK;
+}
+
+static int ensure_out(mc_context *c, size_t bytes)
+{
+    if (c->d_out_bytes >= bytes)
+        return MC_OK;
+    if (c->d_out) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipFree(c->d_out));
+        c->d_out = nullptr;
+        c->d_out_bytes = 0;
+    }
+    HIPCHK(hipMalloc(&c->d_out, bytes));
+    c->d_out_bytes = bytes;
+    return MC_OK;
+}
+
+static constexpr uint64_t MAX_DUMP_PATHS = 1ull << 26;
+
+// ---------------------------------------------------------------------------------------
+// vanilla
+// ---------------------------------------------------------------------------------------
+static inline bool finite_pos(double x) { return std::isfinite(x) && x > 0; }
+
+template <class Real> struct VanillaTraits;
+template <> struct VanillaTraits<float> {
+    using Opt = VanillaF32;
+    using In = mc_option_f32;
+    static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
+    {
+        if (!finite_pos(o.s) || !finite_pos(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
+            return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
+        const double log2e = 1.4426950408889634074;
+        const double drift = ((double)o.r - 0.5 * (double)o.v * (double)o.v) * (double)o.t;
+        const double vol = (double)o.v * std::sqrt((double)o.t);
+        const double b2 = vol * log2e;
+        k.a2 = (float)(drift * log2e);
+        k.radius2 = (float)(-2.0 * 0.69314718055994530942 * b2 * b2);
+        k.kappa = (float)((double)o.k / (double)o.s);
+        k.spot = o.s;
+        scale1 = (double)o.s;
+        scale2 = (double)o.s * (double)o.s;
+        return MC_OK;
+    }
+};
+template <> struct VanillaTraits<double> {
+    using Opt = VanillaF64;
+    using In = mc_option_f64;
+    static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
+    {
+        if (!finite_pos(o.s) || !finite_pos(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
+            return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
+        k.drift = (o.r - 0.5 * o.v * o.v) * o.t;
+        k.vol = o.v * std::sqrt(o.t);
+        k.strike = o.k;
+        k.spot = o.s;
+        scale1 = scale2 = 1.0;
+        return MC_OK;
+    }
+};
+
+// Enqueue simulation + reduction of paths [first, first+n).  out != nullptr additionally stores
+// every payoff (device buffer of n Reals) and forces the masked kernel for all units.
+template <class Real>
+static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In *opt, uint64_t seed,
+                           uint64_t first, uint64_t n, double *d_triple, hipStream_t st, Real *out)
+{
+    using T = VanillaTraits<Real>;
+    constexpr uint64_t NPB = npb<Real>::value;
+    typename T::Opt k;
+    double scale1, scale2;
+    if (int rc = T::prepare(*opt, k, scale1, scale2))
+        return rc;
+    HIPCHK(hipSetDevice(c->device));
+    const uint64_t end = first + n;
+    int slot = 0;
+    std::vector<Segment> segs;
+    if (out) {
+        const uint64_t u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
+        if (int rc = plan_segments(u0, u1 - u0, segs)) return rc;
+        for (const Segment &s : segs) {
+            const Work w = make_work(seed, s, first, end);
+            const int g = grid_for(c, s.count);
+            vanilla_masked_kernel<typename T::Opt, Real><<<g, GROUP, 0, st>>>(k, w, c->partials + slot, out, (Real)scale1);
+            slot += g;
+        }
+    } else {
+        const uint64_t u_full0 = (first + NPB - 1) / NPB, u_full1 = end / NPB;
+        if (u_full1 > u_full0) {
+            if (int rc = plan_segments(u_full0, u_full1 - u_full0, segs)) return rc;
+            for (const Segment &s : segs) {
+                const Work w = make_work(seed, s, first, end);
+                const int g = grid_for(c, s.count);
+                vanilla_kernel<typename T::Opt, Real><<<g, GROUP, 0, st>>>(k, w, c->partials + slot);
+                slot += g;
+            }
+        }
+        // partial units at the edges of the range (at most two single-unit launches)
+        const uint64_t head = first / NPB, tail = end / NPB;
+        const bool has_head = (first % NPB) != 0;
+        const bool has_tail = (end % NPB) != 0 && !(has_head && tail == head);
+        for (int e = 0; e < 2; ++e) {
+            if (!(e == 0 ? has_head : has_tail))
+                continue;
+            const Work w = make_work(seed, Segment{e == 0 ? head : tail, 1u}, first, end);
+            vanilla_masked_kernel<typename T::Opt, Real><<<1, GROUP, 0, st>>>(k, w, c->partials + slot, nullptr, (Real)1);
+            slot += 1;
+        }
+    }
+    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale1, scale2, (double)n, d_triple);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// basket
+// ---------------------------------------------------------------------------------------
+template <class Real> struct BasketIn;
+template <> struct BasketIn<float> { using type = mc_basket_f32; };
+template <> struct BasketIn<double> { using type = mc_basket_f64; };
+template <class Real> static constexpr double exp_scale() { return 1.0; }
+template <> constexpr double exp_scale<float>() { return 1.4426950408889634074; }  // log2(e): E = 2^x
+
+template <class Real, int NA>
+static int basket_launch_n(mc_context *c, const typename BasketIn<Real>::type &o, uint64_t seed,
+                           const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot)
+{
+    BasketArgs<Real, NA> k;
+    const double sc = exp_scale<Real>();
+    const double sqrt_t = std::sqrt((double)o.t);
+    for (int a = 0; a < NA; ++a) {
+        const double va = (double)o.v[a];
+        for (int b = 0; b <= a; ++b)
+            k.m[a * (a + 1) / 2 + b] = (Real)(va * sqrt_t * (double)o.p[a * NA + b] * sc);
+        k.base[a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
+        k.coef[a] = (Real)((double)o.w[a] * (double)o.s[a]);
+    }
+    k.strike = o.k;
+    uint64_t done = 0;
+    for (const Segment &s : segs) {
+        const Work w = make_work(seed, s, 0, 0);
+        const int g = grid_for(c, s.count);
+        basket_kernel<Real, NA><<<g, GROUP, 0, st>>>(k, w, c->partials + slot, out ? out + done : nullptr);
+        slot += g;
+        done += s.count;
+    }
+    return MC_OK;
+}
+
+template <class Real>
+static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o, uint64_t seed, uint64_t first,
+                          uint64_t n, double *d_triple, hipStream_t st, Real *out)
+{
+    if (o->n < 1 || o->n > MC_MAX_ASSETS)
+        return fail(MC_ERR_UNSUPPORTED, "basket: n=%d outside the compiled range 1..%d", o->n, MC_MAX_ASSETS);
+    if (!o->s || !o->v || !o->p || !o->d || !o->w)
+        return fail(MC_ERR_INVALID, "basket: NULL array");
+    if (!(o->t >= 0) || !std::isfinite((double)o->r) || !std::isfinite((double)o->k))
+        return fail(MC_ERR_INVALID, "basket: need t>=0 and finite r, k");
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<Segment> segs;
+    if (int rc = plan_segments(first, n, segs)) return rc;
+    int slot = 0, rc = MC_OK;
+    switch (o->n) {
+#define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, *o, seed, segs, st, out, slot); break;
+        MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
+        MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
+#undef MC_CASE
+    }
+    if (rc) return rc;
+    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// CVA
+// ---------------------------------------------------------------------------------------
+template <class Real> struct CvaIn;
+template <> struct CvaIn<float> { using type = mc_cva_f32; };
+template <> struct CvaIn<double> { using type = mc_cva_f64; };
+
+// Per-date table, fp64 on the host, rounded once to Real.  Residual maturities follow the
+// reference's rule: t -= dt in Real arithmetic, dates with t < 0 contribute nothing
+// (dp/MonteCarloKernel.cu:234,249-256).
+template <class Real>
+static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaStep<Real>> &tab, CvaArgs<Real> &args)
+{
+    const auto &o = v.option;
+    if (!finite_pos(o.s) || !finite_pos(o.k) || !finite_pos(o.v) || !finite_pos(o.t) || !std::isfinite((double)o.r))
+        return fail(MC_ERR_INVALID, "cva: need s>0, k>0, v>0, t>0, finite r");
+    if (v.n_grid < 1 || v.n_grid > (1 << 20))
+        return fail(MC_ERR_INVALID, "cva: n_grid=%d outside [1, 2^20]", v.n_grid);
+    if (!(v.defint >= 0) || !std::isfinite((double)v.lgd))
+        return fail(MC_ERR_INVALID, "cva: need defint>=0 and finite lgd");
+    const double sc = exp_scale<Real>();
+    const Real dt = o.t / v.n_grid;
+    const Real step_drift = (Real)(((double)o.r - 0.5 * (double)o.v * (double)o.v) * (double)dt);
+    const Real step_vol = (Real)((double)o.v * std::sqrt((double)dt));
+    const double ln_s0 = std::log((double)o.s), ln_k = std::log((double)o.k);
+    const double lam = (double)v.defint;
+    tab.clear();
+    args.n_bs = 0;
+    args.last_intrinsic = 0;
+    Real ttm = o.t;
+    for (int j = 1; j <= v.n_grid; ++j) {
+        ttm -= dt;
+        if (!(ttm >= 0))
+            break;
+        const double tau = (double)ttm;
+        const double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
+        CvaStep<Real> s;
+        s.dp = (Real)(-std::exp(-lam * t_prev) * std::expm1(-lam * (t_now - t_prev)));
+        const double ln_sj = ln_s0 + (double)j * (double)step_drift;  // + step_vol * W_j on the device
+        s.xk = (Real)(ln_sj * sc);
+        if (tau > 0) {
+            const double sig = (double)o.v * std::sqrt(tau);
+            s.g = (Real)((double)step_vol / sig);
+            const double num = ln_sj - ln_k + ((double)o.r + 0.5 * (double)o.v * (double)o.v) * tau;
+            s.e1 = (Real)(num / sig);
+            s.e2 = (Real)(num / sig - sig);
+            s.disc = (Real)((double)o.k * std::exp(-(double)o.r * tau));
+            args.n_bs++;
+        } else {
+            s.g = s.e1 = s.e2 = s.disc = 0;
+            args.last_intrinsic = 1;
+        }
+        tab.push_back(s);
+        if (tau == 0)
+            break;
+    }
+    args.bx = (Real)((double)step_vol * sc);
+    args.lgd = v.lgd;
+    args.strike = o.k;
+    return MC_OK;
+}
+
+template <class Real>
+static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint64_t seed, uint64_t first, uint64_t n,
+                       double *d_triple, hipStream_t st, Real *out)
+{
+    HIPCHK(hipSetDevice(c->device));
+    CvaArgs<Real> args;
+    // the table depends only on the inputs: rebuild and re-upload only when they change
+    const double key_vals[9] = {(double)v->defint, (double)v->lgd, (double)v->option.s, (double)v->option.k,
+                                (double)v->option.r, (double)v->option.v, (double)v->option.t,
+                                (double)v->n_grid, (double)sizeof(Real)};
+    std::vector<char> key(sizeof key_vals);
+    memcpy(key.data(), key_vals, sizeof key_vals);
+    static thread_local std::vector<CvaStep<Real>> tab;
+    if (int rc = build_cva_table<Real>(*v, tab, args)) return rc;
+    const size_t bytes = tab.size() * sizeof(CvaStep<Real>);
+    if (key != c->table_key) {
+        if (bytes > c->table_bytes) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (c->d_table) HIPCHK(hipFree(c->d_table));
+            if (c->h_table) HIPCHK(hipHostFree(c->h_table));
+            c->table_bytes = bytes < 4096 ? 4096 : bytes;
+            HIPCHK(hipMalloc(&c->d_table, c->table_bytes));
+            HIPCHK(hipHostMalloc(&c->h_table, c->table_bytes, hipHostMallocDefault));
+        } else {
+            HIPCHK(hipEventSynchronize(c->table_copied));  // previous upload has left the staging buffer
+        }
+        if (bytes) {
+            memcpy(c->h_table, tab.data(), bytes);
+            HIPCHK(hipMemcpyAsync(c->d_table, c->h_table, bytes, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(hipEventRecord(c->table_copied, st));
+        c->table_key = key;
+    }
+    args.steps = (const CvaStep<Real> *)c->d_table;
+    std::vector<Segment> segs;
+    if (int rc = plan_segments(first, n, segs)) return rc;
+    int slot = 0;
+    uint64_t done = 0;
+    for (const Segment &s : segs) {
+        const Work w = make_work(seed, s, 0, 0);
+        const int g = grid_for(c, s.count);
+        cva_kernel<Real><<<g, GROUP, 0, st>>>(args, w, c->partials + slot, out ? out + done : nullptr);
+        slot += g;
+        done += s.count;
+    }
+    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// closing + sync wrappers
+// ---------------------------------------------------------------------------------------
+extern "C" void mc_closing(double sum, double sum2, uint64_t n, double discount, double *expected, double *confidence)
+{
+    const double dn = (double)n;
+    if (expected) *expected = discount * (sum / dn);
+    if (confidence) {
+        const double dev = std::sqrt((dn * sum2 - sum * sum) / (dn * (double)(n - 1)));
+        *confidence = 1.96 * dev / std::sqrt(dn);
+    }
+}
+
+extern "C" void mc_shard_range(uint64_t total, int rank, int world, uint64_t *first, uint64_t *count)
+{
+    if (world < 1) world = 1;
+    if (rank < 0) rank = 0;
+    if (rank >= world) rank = world - 1;
+    // floor(rank * total / world) without overflowing 64 bits
+    const unsigned __int128 t = total;
+    const uint64_t lo = (uint64_t)(t * (unsigned)rank / (unsigned)world);
+    const uint64_t hi = (uint64_t)(t * (unsigned)(rank + 1) / (unsigned)world);
+    if (first) *first = lo;
+    if (count) *count = hi - lo;
+}
+
+template <class Real>
+static int chol_impl(int n, const Real *c, Real *a)
+{
+    if (n < 1 || !c || !a)
+        return -1;
+    std::vector<Real> work((size_t)n);
+    int bad = 0;
+    for (int col = 0; col < n; ++col) {
+        for (int row = 0; row < n; ++row) {
+            a[row * n + col] = 0;
+            if (row < col)
+                continue;
+            work[row] = c[row * n + col];
+            for (int q = 0; q < col; ++q)
+                work[row] -= a[col * n + q] * a[row * n + q];
+            if (work[col] > 0)
+                a[row * n + col] = work[row] / std::sqrt(work[col]);
+            else if (row == col)
+                ++bad;
+        }
+    }
+    return bad;
+}
+extern "C" int mc_chol_f32(int n, const float *c, float *a) { return chol_impl<float>(n, c, a); }
+extern "C" int mc_chol_f64(int n, const double *c, double *a) { return chol_impl<double>(n, c, a); }
+
+// run = enqueue on the context stream between two events, wait, read 24 bytes, close
+template <class Enq>
+static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, Enq enqueue)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventRecord(c->ev0, c->stream));
+    if (int rc = enqueue(c->stream, c->d_triple)) return rc;
+    HIPCHK(hipEventRecord(c->ev1, c->stream));
+    HIPCHK(hipMemcpyAsync(c->h_triple, c->d_triple, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    out->sum = c->h_triple[0];
+    out->sum2 = c->h_triple[1];
+    out->n = (uint64_t)c->h_triple[2];
+    out->kernel_ms = ms;
+    if (out->n != n)
+        return fail(MC_ERR_HIP, "device returned n=%llu, expected %llu", (unsigned long long)out->n,
+                    (unsigned long long)n);
+    mc_closing(out->sum, out->sum2, out->n, discount, &out->expected, &out->confidence);
+    return MC_OK;
+}
+
+template <class Real, class Enq>
+static int dump_sync(mc_context *c, uint64_t n, Real *h_out, Enq enqueue)
+{
+    if (n > MAX_DUMP_PATHS)
+        return fail(MC_ERR_INVALID, "per-path dump limited to 2^26 paths");
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = ensure_out(c, n * sizeof(Real))) return rc;
+    if (int rc = enqueue(c->stream, c->d_triple, (Real *)c->d_out)) return rc;
+    HIPCHK(hipMemcpyAsync(h_out, c->d_out, n * sizeof(Real), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MC_OK;
+}
+
+#define MC_DEFINE_PRODUCT(X, Real)                                                                           \
+    extern "C" int mc_vanilla_launch_##X(mc_context *c, const mc_option_##X *o, uint64_t seed, uint64_t first, \
+                                         uint64_t n, double *d_triple, void *stream)                         \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, d_triple)) return rc;                                      \
+        return vanilla_enqueue<Real>(c, o, seed, first, n, d_triple, pick_stream(c, stream), nullptr);       \
+    }                                                                                                        \
+    extern "C" int mc_basket_launch_##X(mc_context *c, const mc_basket_##X *o, uint64_t seed, uint64_t first, \
+                                        uint64_t n, double *d_triple, void *stream)                          \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, d_triple)) return rc;                                      \
+        return basket_enqueue<Real>(c, o, seed, first, n, d_triple, pick_stream(c, stream), nullptr);        \
+    }                                                                                                        \
+    extern "C" int mc_cva_launch_##X(mc_context *c, const mc_cva_##X *o, uint64_t seed, uint64_t first,      \
+                                     uint64_t n, double *d_triple, void *stream)                             \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, d_triple)) return rc;                                      \
+        return cva_enqueue<Real>(c, o, seed, first, n, d_triple, pick_stream(c, stream), nullptr);           \
+    }                                                                                                        \
+    extern "C" int mc_vanilla_run_##X(mc_context *c, const mc_option_##X *o, uint64_t seed, uint64_t first,  \
+                                      uint64_t n, mc_result *out)                                            \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, out)) return rc;                                           \
+        return run_sync(c, n, std::exp(-(double)o->r * (double)o->t), out, [&](hipStream_t st, double *t) {  \
+            return vanilla_enqueue<Real>(c, o, seed, first, n, t, st, nullptr);                              \
+        });                                                                                                  \
+    }                                                                                                        \
+    extern "C" int mc_basket_run_##X(mc_context *c, const mc_basket_##X *o, uint64_t seed, uint64_t first,   \
+                                     uint64_t n, mc_result *out)                                             \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, out)) return rc;                                           \
+        return run_sync(c, n, std::exp(-(double)o->r * (double)o->t), out, [&](hipStream_t st, double *t) {  \
+            return basket_enqueue<Real>(c, o, seed, first, n, t, st, nullptr);                               \
+        });                                                                                                  \
+    }                                                                                                        \
+    extern "C" int mc_cva_run_##X(mc_context *c, const mc_cva_##X *o, uint64_t seed, uint64_t first,         \
+                                  uint64_t n, mc_result *out)                                                \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, out)) return rc;                                           \
+        return run_sync(c, n, 1.0, out, [&](hipStream_t st, double *t) {                                     \
+            return cva_enqueue<Real>(c, o, seed, first, n, t, st, nullptr);                                  \
+        });                                                                                                  \
+    }                                                                                                        \
+    extern "C" int mc_vanilla_paths_##X(mc_context *c, const mc_option_##X *o, uint64_t seed, uint64_t first, \
+                                        uint64_t n, Real *h_out)                                             \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, h_out)) return rc;                                         \
+        return dump_sync<Real>(c, n, h_out, [&](hipStream_t st, double *t, Real *d) {                        \
+            return vanilla_enqueue<Real>(c, o, seed, first, n, t, st, d);                                    \
+        });                                                                                                  \
+    }                                                                                                        \
+    extern "C" int mc_basket_paths_##X(mc_context *c, const mc_basket_##X *o, uint64_t seed, uint64_t first, \
+                                       uint64_t n, Real *h_out)                                              \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, h_out)) return rc;                                         \
+        return dump_sync<Real>(c, n, h_out, [&](hipStream_t st, double *t, Real *d) {                        \
+            return basket_enqueue<Real>(c, o, seed, first, n, t, st, d);                                     \
+        });                                                                                                  \
+    }                                                                                                        \
+    extern "C" int mc_cva_paths_##X(mc_context *c, const mc_cva_##X *o, uint64_t seed, uint64_t first,       \
+                                    uint64_t n, Real *h_out)                                                 \
+    {                                                                                                        \
+        if (int rc = check_common(c, o, first, n, h_out)) return rc;                                         \
+        return dump_sync<Real>(c, n, h_out, [&](hipStream_t st, double *t, Real *d) {                        \
+            return cva_enqueue<Real>(c, o, seed, first, n, t, st, d);                                        \
+        });                                                                                                  \
+    }                                                                                                        \
+    extern "C" int mc_normals_##X(mc_context *c, uint64_t seed, uint32_t domain, uint64_t first_unit,        \
+                                  uint64_t n_units, uint32_t block, Real *h_out)                             \
+    {                                                                                                        \
+        if (int rc = check_common(c, h_out, first_unit, n_units, h_out)) return rc;                          \
+        constexpr uint64_t NPB = npb<Real>::value;                                                           \
+        return dump_sync<Real>(c, n_units * NPB, h_out, [&](hipStream_t st, double *, Real *d) -> int {      \
+            std::vector<Segment> segs;                                                                       \
+            if (int rc = plan_segments(first_unit, n_units, segs)) return rc;                                \
+            uint64_t done = 0;                                                                               \
+            for (const Segment &s : segs) {                                                                  \
+                const Work w = make_work(seed, s, 0, 0);                                                     \
+                normals_kernel<Real><<<grid_for(c, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
+                done += s.count;                                                                             \
+            }                                                                                                \
+            HIPCHK(hipGetLastError());                                                                       \
+            return MC_OK;                                                                                    \
+        });                                                                                                  \
+    }
+
+MC_DEFINE_PRODUCT(f32, float)
+MC_DEFINE_PRODUCT(f64, double)

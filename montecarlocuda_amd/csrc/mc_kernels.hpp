@@ -1,0 +1,320 @@
+// mc_kernels.hpp -- the simulation kernels (gfx950, wave64).
+//
+// Shape common to all three products (replaces the kernel skeleton of
+// dp/MonteCarloKernel.cu:133-177,179-220,222-283):
+//   * a persistent-style grid (blocks x 256 lanes) strides over "units" of work; a unit is one
+//     Philox block of vanilla paths (4 in f32, 2 in f64) or one whole basket / CVA path;
+//   * everything a lane needs is in registers: counter-based normals (mc_rng.hpp), option
+//     constants in SGPRs (kernel arguments), per-lane fp64 (sum, sum2) accumulators;
+//   * one DPP+LDS reduction and one 16-byte store per workgroup at the end (mc_reduce.hpp).
+// HBM traffic per launch: kernel arguments in, 16 B per workgroup out -- the kernels are bound
+// by VALU/transcendental issue, not by memory (DESIGN.md "Roofline").
+//
+// `Work` describes one segment: units [unit_lo, unit_lo + n_units) with a common high word
+// (the host splits a range so that unit_lo + n_units <= 2^32 and n_units <= 2^31; keeping the
+// high counter word wave-uniform moves a multiply per Philox block to the scalar unit).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mc_reduce.hpp"
+#include "mc_rng.hpp"
+
+namespace mc {
+
+constexpr int GROUP = 256;  // lanes per workgroup = 4 waves = one wave per SIMD
+
+// precision-generic fused multiply-add (__builtin_fma alone is the double form)
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+
+struct Work {
+    uint32_t seed_lo, seed_hi;  // Philox key
+    uint32_t unit_lo, unit_hi;  // first unit of the segment (64-bit counter, split)
+    uint32_t n_units;           // units in the segment
+    // path window for masked launches (vanilla edges, per-path dumps): a path is live iff
+    // first_path <= p < end_path.  Ignored by the unmasked kernels.
+    uint64_t first_path, end_path;
+};
+
+// =========================================================================================
+// Vanilla call.  Reference device formula, dp/MonteCarloKernel.cu:67-71:
+//     payoff = max(S exp((r - v^2/2) T + v sqrt(T) z) - K, 0)
+// =========================================================================================
+
+// f32 constants, all prepared in fp64 on the host:
+//   payoff / S = max(2^(a2 + b2 z) - kappa, 0),  a2 = (r - v^2/2) T log2(e),
+//   b2 = v sqrt(T) log2(e), kappa = K / S;  radius2 = -2 ln2 * b2^2 folds b2 into Box-Muller's
+//   radius so each path costs one fma + one v_exp_f32 after its normal.
+struct VanillaF32 {
+    float a2, radius2, kappa, spot;
+};
+struct VanillaF64 {
+    double drift, vol, strike, spot;
+};
+
+// 4 normalised payoffs of one unit (one Philox block)
+__device__ __forceinline__ void vanilla_unit(const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
+{
+    const u32x4 r = philox4x32_10(c0, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi);
+    float bz[4];
+    box_muller_f32(r.x, r.y, o.radius2, bz[0], bz[1]);
+    box_muller_f32(r.z, r.w, o.radius2, bz[2], bz[3]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        p[j] = fmaxf(__builtin_amdgcn_exp2f(bz[j] + o.a2) - o.kappa, 0.0f);
+}
+__device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w, uint32_t c0, double (&p)[2])
+{
+    double z[2];
+    block_normals(c0, w.unit_hi, 0u, 1u, w.seed_lo, w.seed_hi, z);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        p[j] = fmax(o.spot * exp(o.drift + o.vol * z[j]) - o.strike, 0.0);
+}
+
+// Hot kernel: every unit is complete.  f32 payoffs are in units of S (scaled back by the
+// finishing kernel); each unit's 4 payoffs are added in fp32 and flushed to the lane's fp64
+// accumulators straight away (never a long fp32 running sum: SURVEY 2.3 #2).
+template <class Opt, class Real>
+__global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work w, double2 *__restrict__ partials)
+{
+    constexpr int NPB = npb<Real>::value;
+    const uint32_t stride = gridDim.x * GROUP;
+    const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = gtid; i < w.n_units; i += stride) {
+        Real p[NPB];
+        vanilla_unit(o, w, w.unit_lo + i, p);
+        Real s = p[0], q = p[0] * p[0];
+#pragma unroll
+        for (int j = 1; j < NPB; ++j) {
+            s += p[j];
+            q = fma_r(p[j], p[j], q);
+        }
+        acc_s += (double)s;
+        acc_q += (double)q;
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
+// Masked kernel: honours the path window (partial first/last units) and optionally stores
+// every per-path payoff (currency units) to `out[p - first_path]`.  Used for range edges and
+// by the parity tests; never on the hot path.
+template <class Opt, class Real>
+__global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Opt o, const Work w,
+                                                               double2 *__restrict__ partials,
+                                                               Real *__restrict__ out, Real out_scale)
+{
+    constexpr int NPB = npb<Real>::value;
+    const uint32_t stride = gridDim.x * GROUP;
+    const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = gtid; i < w.n_units; i += stride) {
+        Real p[NPB];
+        vanilla_unit(o, w, w.unit_lo + i, p);
+        const uint64_t unit = ((uint64_t)w.unit_hi << 32) | (uint32_t)(w.unit_lo + i);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) {
+            const uint64_t path = unit * NPB + j;
+            if (path >= w.first_path && path < w.end_path) {
+                acc_s += (double)p[j];
+                acc_q += (double)p[j] * (double)p[j];
+                if (out)
+                    out[path - w.first_path] = p[j] * out_scale;
+            }
+        }
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
+// =========================================================================================
+// Basket call.  Reference device formulas, dp/MonteCarloKernel.cu:74-101:
+//     bt = L g + d;  s_a = S_a exp((r - v_a^2/2) T + v_a sqrt(T) bt_a);
+//     payoff = max(sum_a w_a s_a - K, 0)
+// folded on the host (fp64) into  payoff = max(sum_a coef_a E(base_a + sum_{b<=a} m_ab g_b) - K, 0)
+// with m = diag(v sqrt T) L (lower triangle only: the reference multiplies the structural
+// zeros too, :79-84), base_a = (r - v_a^2/2) T + v_a sqrt(T) d_a, coef_a = w_a S_a;
+// in f32 m and base are pre-multiplied by log2(e) and E = 2^x (v_exp_f32).
+// =========================================================================================
+template <class Real, int NA>
+struct BasketArgs {
+    Real m[NA * (NA + 1) / 2];  // packed rows: m[a(a+1)/2 + b], b <= a
+    Real base[NA];
+    Real coef[NA];
+    Real strike;
+};
+
+__device__ __forceinline__ float exp_model(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ double exp_model(double x) { return exp(x); }
+
+template <class Real, int NA>
+__device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const Work &w, uint32_t c0)
+{
+    constexpr int NPB = npb<Real>::value;
+    constexpr int NBLK = (NA + NPB - 1) / NPB;
+    Real g[NBLK * NPB];
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        Real z[NPB];
+        block_normals(c0, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j)
+            g[b * NPB + j] = z[j];
+    }
+    Real basket = 0;
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        Real x = o.base[a];
+#pragma unroll
+        for (int b = 0; b <= a; ++b)
+            x = fma_r(o.m[a * (a + 1) / 2 + b], g[b], x);
+        basket = fma_r(o.coef[a], exp_model(x), basket);
+    }
+    const Real v = basket - o.strike;
+    return v > 0 ? v : 0;
+}
+
+template <class Real, int NA>
+__global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA> o, const Work w,
+                                                       double2 *__restrict__ partials,
+                                                       Real *__restrict__ out)
+{
+    const uint32_t stride = gridDim.x * GROUP;
+    const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = gtid; i < w.n_units; i += stride) {
+        const Real p = basket_path<Real, NA>(o, w, w.unit_lo + i);
+        acc_s += (double)p;
+        acc_q = __builtin_fma((double)p, (double)p, acc_q);
+        if (out)  // wave-uniform: per-path dump for the parity tests
+            out[i] = p;
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
+// =========================================================================================
+// CVA of one call.  Reference device loop, dp/MonteCarloKernel.cu:241-262 (spot advanced
+// first, exposure = Black-Scholes value at the NEW spot and residual maturity :125-129, with
+// the Hastings CDF :110-123).  Everything that depends only on the date j is tabulated once
+// per call on the host in fp64 (the reference recomputes it per path per step, :248):
+//   W_j = z_1 + ... + z_j                       (the lane's only state)
+//   d1 = W_j g_j + e1_j,  d2 = W_j g_j + e2_j   g_j = v sqrt(dt) / (v sqrt(tau_j))
+//   s_j = E(W_j bx + xk_j)                      ln s_j = ln S0 + j a + v sqrt(dt) W_j
+//   ee_j = s_j cnd(d1) - disc_j cnd(d2)         disc_j = K exp(-r tau_j)
+//   cva  = LGD * sum_j dp_j ee_j
+// A final date with residual maturity exactly 0 uses the intrinsic value.
+// =========================================================================================
+template <class Real>
+struct CvaStep {
+    Real g, e1, e2, xk, disc, dp;
+};
+template <class Real>
+struct CvaArgs {
+    const CvaStep<Real> *steps;  // n_bs Black-Scholes dates (+1 intrinsic date if last_intrinsic)
+    int n_bs;                    // dates priced with the closed form
+    int last_intrinsic;          // 1: one more date, residual maturity == 0
+    Real bx;                     // v sqrt(dt) (times log2 e in f32)
+    Real lgd, strike;
+};
+
+// Hastings 26.2.17 tail: phi(d) * poly(1/(1+0.2316419|d|)); cnd = d > 0 ? 1 - tail : tail
+__device__ __forceinline__ float cnd_model(float d)
+{
+    const float k = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2316419f, fabsf(d), 1.0f));
+    float poly = __builtin_fmaf(k, 1.330274429f, -1.821255978f);
+    poly = __builtin_fmaf(k, poly, 1.781477937f);
+    poly = __builtin_fmaf(k, poly, -0.356563782f);
+    poly = __builtin_fmaf(k, poly, 0.31938153f);
+    poly *= k;
+    // exp(-d^2/2) = 2^(-d^2 log2(e)/2)
+    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(d * d * -0.72134752044448170f);
+    const float tail = pdf * poly;
+    return d > 0 ? 1.0f - tail : tail;
+}
+__device__ __forceinline__ double cnd_model(double d)
+{
+    const double k = 1.0 / __builtin_fma(0.2316419, fabs(d), 1.0);
+    double poly = __builtin_fma(k, 1.330274429, -1.821255978);
+    poly = __builtin_fma(k, poly, 1.781477937);
+    poly = __builtin_fma(k, poly, -0.356563782);
+    poly = __builtin_fma(k, poly, 0.31938153);
+    poly *= k;
+    const double pdf = 0.39894228040143267793994605993438 * exp(-0.5 * d * d);
+    const double tail = pdf * poly;
+    return d > 0 ? 1.0 - tail : tail;
+}
+
+template <class Real>
+__device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, uint32_t c0)
+{
+    constexpr int NPB = npb<Real>::value;
+    Real W = 0, acc = 0;
+    Real z[NPB];
+    const int n_dates = o.n_bs + o.last_intrinsic;
+    for (int j0 = 0; j0 < n_dates; j0 += NPB) {
+        block_normals(c0, w.unit_hi, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, w.seed_lo, w.seed_hi, z);
+#pragma unroll
+        for (int jj = 0; jj < NPB; ++jj) {
+            const int j = j0 + jj;  // wave-uniform: the table is read through scalar loads
+            if (j < n_dates) {
+                const CvaStep<Real> st = o.steps[j];
+                W += z[jj];
+                const Real spot = exp_model(fma_r(W, o.bx, st.xk));
+                Real ee;
+                if (j < o.n_bs) {
+                    const Real d1 = fma_r(W, st.g, st.e1);
+                    const Real d2 = fma_r(W, st.g, st.e2);
+                    ee = spot * cnd_model(d1) - st.disc * cnd_model(d2);
+                } else {
+                    const Real iv = spot - o.strike;
+                    ee = iv > 0 ? iv : 0;
+                }
+                acc = fma_r(st.dp, ee, acc);
+            }
+        }
+    }
+    return acc * o.lgd;
+}
+
+template <class Real>
+__global__ __launch_bounds__(GROUP) void cva_kernel(const CvaArgs<Real> o, const Work w,
+                                                    double2 *__restrict__ partials, Real *__restrict__ out)
+{
+    const uint32_t stride = gridDim.x * GROUP;
+    const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = gtid; i < w.n_units; i += stride) {
+        const Real p = cva_path<Real>(o, w, w.unit_lo + i);
+        acc_s += (double)p;
+        acc_q = __builtin_fma((double)p, (double)p, acc_q);
+        if (out)  // wave-uniform: per-path dump for the parity tests
+            out[i] = p;
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
+// =========================================================================================
+// Normals dump (parity tests of the generator itself).
+// =========================================================================================
+template <class Real>
+__global__ __launch_bounds__(GROUP) void normals_kernel(const Work w, uint32_t block, uint32_t domain,
+                                                        Real *__restrict__ out)
+{
+    constexpr int NPB = npb<Real>::value;
+    const uint32_t stride = gridDim.x * GROUP;
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
+        Real z[NPB];
+        block_normals(w.unit_lo + i, w.unit_hi, block, domain, w.seed_lo, w.seed_hi, z);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j)
+            out[(uint64_t)i * NPB + j] = z[j];
+    }
+}
+
+}  // namespace mc

@@ -1,0 +1,108 @@
+// mc_rng.hpp -- counter-based random normals for gfx950 (device code).
+//
+// Replaces the reference's cuRAND XORWOW state array (dp/MonteCarloKernel.cu:285-290 set-up
+// kernel, 48 B of state read per thread at :143,189,232): there is NO generator state in HBM.
+// A path's normals are a pure function of (seed, counter):
+//
+//     Philox4x32-10( counter = {unit_lo, unit_hi, block, domain}, key = {seed_lo, seed_hi} )
+//
+// One Philox block gives four 32-bit words = 4 normals in f32 (one word per uniform) or
+// 2 normals in f64 (two words per uniform), by two-branch Box-Muller.  The oracle twin of
+// this file is oracle/mc_oracle_impl.h:orc_dev_normals (tests compare them word for word).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mc {
+
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
+constexpr uint32_t PHILOX_W0 = 0x9E3779B9u, PHILOX_W1 = 0xBB67AE85u;
+
+struct u32x4 { uint32_t x, y, z, w; };
+
+// Ten rounds.  The key schedule is wave-uniform (seed is a kernel argument) and lives in
+// SGPRs; each round is two v_mad_u64_u32 (full 64-bit product: hi and lo in one instruction)
+// and four v_xor_b32.  Counter words that are wave-uniform (unit_hi, block, domain) let the
+// compiler move the first rounds' second multiply to the scalar unit.
+__device__ __forceinline__ u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1;
+        c3 = (uint32_t)p0;
+        c0 = n0;
+        c2 = n2;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    return {c0, c1, c2, c3};
+}
+
+// ---- f32 ---------------------------------------------------------------------------------
+// u = x * 2^-32 + 2^-33  in (0, 1]   (one v_cvt_f32_u32 + one v_fma_f32)
+__device__ __forceinline__ float u01_f32(uint32_t x)
+{
+    return __builtin_fmaf((float)x, 0x1p-32f, 0x1p-33f);
+}
+
+// Box-Muller on hardware transcendentals: v_log_f32 is log2, v_sin/v_cos_f32 take their
+// argument in revolutions, so 2*pi never appears.  `scale2` multiplies the squared radius:
+//   scale2 = -2 ln2        ->  plain N(0,1) pair
+//   scale2 = -2 ln2 * b^2  ->  pair already multiplied by b (saves the multiply per normal)
+__device__ __forceinline__ void box_muller_f32(uint32_t xa, uint32_t xb, float scale2, float &z_cos,
+                                               float &z_sin)
+{
+    const float ua = u01_f32(xa);
+    const float ub = u01_f32(xb);
+    const float radius = __builtin_amdgcn_sqrtf(scale2 * __builtin_amdgcn_logf(ua));
+    z_cos = radius * __builtin_amdgcn_cosf(ub);
+    z_sin = radius * __builtin_amdgcn_sinf(ub);
+}
+
+constexpr float NEG_2LN2_F32 = -1.3862943611198906f;
+
+// ---- f64 ---------------------------------------------------------------------------------
+// 52-bit uniform strictly inside (0,1): ((hi:lo >> 12) + 0.5) * 2^-52, exact in double.
+__device__ __forceinline__ double u01_f64(uint32_t lo, uint32_t hi)
+{
+    const double top = (double)hi;          // * 2^20 * 2^-52
+    const double bot = (double)(lo >> 12);  // * 2^-52
+    return __builtin_fma(top, 0x1p-32, __builtin_fma(bot, 0x1p-52, 0x1p-53));
+}
+
+__device__ __forceinline__ void box_muller_f64(const u32x4 r, double &z_cos, double &z_sin)
+{
+    const double ua = u01_f64(r.x, r.y);
+    const double ub = u01_f64(r.z, r.w);
+    const double radius = sqrt(-2.0 * log(ua));
+    double s, c;
+    sincospi(2.0 * ub, &s, &c);  // angle in half-turns: exact range reduction
+    z_cos = radius * c;
+    z_sin = radius * s;
+}
+
+template <class Real> struct npb;           // normals per Philox block
+template <> struct npb<float> { static constexpr int value = 4; };
+template <> struct npb<double> { static constexpr int value = 2; };
+
+// All normals of one Philox block, precision-generic: out[0..npb)
+__device__ __forceinline__ void block_normals(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, float (&out)[4])
+{
+    const u32x4 r = philox4x32_10(c0, c1, c2, c3, k0, k1);
+    box_muller_f32(r.x, r.y, NEG_2LN2_F32, out[0], out[1]);
+    box_muller_f32(r.z, r.w, NEG_2LN2_F32, out[2], out[3]);
+}
+__device__ __forceinline__ void block_normals(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, double (&out)[2])
+{
+    const u32x4 r = philox4x32_10(c0, c1, c2, c3, k0, k1);
+    box_muller_f64(r, out[0], out[1]);
+}
+
+}  // namespace mc

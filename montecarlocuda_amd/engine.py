@@ -1,0 +1,245 @@
+"""Host-side mirror of the reference's GPU interface on top of the C ABI (ctypes, no torch).
+
+Names follow the reference (marcomatteo/MonteCarloCUDA): ``OptionData``, ``MultiOptionData``,
+``CVA``, ``OptionValue`` (MonteCarlo.h:32-65) and ``dev_vanillaOpt`` / ``dev_basketOpt`` /
+``dev_cvaEquityOption`` (MonteCarloKernel.cu:500,483,517).  ``Engine`` is the persistent
+per-GPU context underneath, with the explicit-seed / path-range API the multi-GPU harness uses.
+The simulation itself always runs in libmc_mi355x.so on the GPU; nothing here computes paths.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import MC_DEFAULT_SEED, check, lib
+
+NP = {"f32": np.float32, "f64": np.float64}
+
+
+# ---- reference-shaped inputs / outputs ----------------------------------------------------
+@dataclass
+class OptionData:           # MonteCarlo.h:32-38
+    s: float
+    k: float
+    r: float
+    v: float
+    t: float
+
+
+@dataclass
+class MultiOptionData:      # MonteCarlo.h:41-50; p = Cholesky factor at call time
+    s: Sequence[float]
+    v: Sequence[float]
+    p: Sequence[Sequence[float]]
+    d: Sequence[float]
+    w: Sequence[float]
+    k: float
+    t: float
+    r: float
+
+
+@dataclass
+class CVA:                  # MonteCarlo.h:57-65
+    defInt: float
+    lgd: float
+    option: OptionData
+    n: int
+    ns: int = 0
+
+
+@dataclass
+class OptionValue:          # MonteCarlo.h:52-55
+    Expected: float
+    Confidence: float
+
+
+@dataclass
+class Estimate:
+    expected: float
+    confidence: float
+    sum: float
+    sum2: float
+    n: int
+    kernel_ms: float = 0.0
+
+    def value(self) -> OptionValue:
+        return OptionValue(self.expected, self.confidence)
+
+
+def _as_option(X, o) -> C.Structure:
+    if isinstance(o, dict):
+        o = OptionData(**{k: o[k] for k in "skrvt"})
+    return _lib.OPTION[X](o.s, o.k, o.r, o.v, o.t)
+
+
+class _BasketHolder:
+    """Keeps the numpy arrays alive for as long as the ctypes struct is in use."""
+
+    def __init__(self, X, b):
+        if isinstance(b, dict):
+            b = MultiOptionData(**{k: b[k] for k in ("s", "v", "p", "d", "w", "k", "t", "r")})
+        dt = NP[X]
+        self.n = len(b.s)
+        self.arrs = [np.ascontiguousarray(a, dtype=dt) for a in (b.s, b.v, np.asarray(b.p, dtype=dt).reshape(-1),
+                                                                  b.d, b.w)]
+        if self.arrs[2].size != self.n * self.n or any(a.size != self.n for a in (self.arrs[0], self.arrs[1],
+                                                                               self.arrs[3], self.arrs[4])):
+            raise ValueError("basket arrays disagree on n")
+        P = C.POINTER(_lib.CT[X])
+        self.struct = _lib.BASKET[X](self.n, *[a.ctypes.data_as(P) for a in self.arrs], b.k, b.t, b.r)
+
+
+def _as_cva(X, c) -> C.Structure:
+    if isinstance(c, dict):
+        c = CVA(c["defint"], c["lgd"], OptionData(*(c[k] for k in "skrvt")), c["n_grid"])
+    return _lib.CVA[X](c.defInt, c.lgd, _as_option(X, c.option), c.n)
+
+
+def _estimate(r: _lib.Result) -> Estimate:
+    return Estimate(r.expected, r.confidence, r.sum, r.sum2, int(r.n), float(r.kernel_ms))
+
+
+class Engine:
+    """One persistent context on one MI355X (mc_context_create / mc_context_destroy)."""
+
+    def __init__(self, device: int = 0, blocks: int = 0):
+        self._ctx = C.c_void_p()
+        check(lib().mc_context_create(device, blocks, C.byref(self._ctx)))
+        self.device = device
+        self.blocks = lib().mc_context_blocks(self._ctx)
+
+    def close(self):
+        if self._ctx:
+            lib().mc_context_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        name = C.create_string_buffer(128)
+        cus, mhz = C.c_int(), C.c_int()
+        check(lib().mc_context_info(self._ctx, name, 128, C.byref(cus), C.byref(mhz)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value,
+                "blocks": self.blocks}
+
+    # ---- synchronous estimators --------------------------------------------------------
+    def _run(self, prod, X, struct, seed, first, n):
+        r = _lib.Result()
+        check(getattr(lib(), f"mc_{prod}_run_{X}")(self._ctx, C.byref(struct), seed, first, n, C.byref(r)))
+        return _estimate(r)
+
+    def vanilla(self, opt, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:
+        return self._run("vanilla", precision, _as_option(precision, opt), seed, first_path, n_paths)
+
+    def basket(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:
+        h = _BasketHolder(precision, b)
+        return self._run("basket", precision, h.struct, seed, first_path, n_paths)
+
+    def cva(self, c, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:
+        return self._run("cva", precision, _as_cva(precision, c), seed, first_path, n_paths)
+
+    # ---- asynchronous launches (device triple, caller's stream) ------------------------
+    def launch(self, prod, precision, struct, seed, first_path, n_paths, d_triple_ptr: int, stream: int = 0):
+        """Enqueue; d_triple_ptr = device address of 3 doubles, stream = hipStream_t handle (0 = context's)."""
+        check(getattr(lib(), f"mc_{prod}_launch_{precision}")(self._ctx, C.byref(struct), seed, first_path,
+                                                               n_paths, C.c_void_p(d_triple_ptr),
+                                                               C.c_void_p(stream)))
+
+    def prepared(self, prod, precision, inputs):
+        """ctypes struct (plus whatever must stay alive) for repeated launch() calls."""
+        if prod == "vanilla":
+            return _as_option(precision, inputs), None
+        if prod == "basket":
+            h = _BasketHolder(precision, inputs)
+            return h.struct, h
+        return _as_cva(precision, inputs), None
+
+    # ---- per-path values (parity tests) ------------------------------------------------
+    def _paths(self, prod, X, struct, seed, first, n):
+        out = np.empty(n, dtype=NP[X])
+        check(getattr(lib(), f"mc_{prod}_paths_{X}")(self._ctx, C.byref(struct), seed, first, n,
+                                                      out.ctypes.data_as(C.POINTER(_lib.CT[X]))))
+        return out
+
+    def vanilla_paths(self, opt, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
+        return self._paths("vanilla", precision, _as_option(precision, opt), seed, first_path, n_paths)
+
+    def basket_paths(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
+        h = _BasketHolder(precision, b)
+        return self._paths("basket", precision, h.struct, seed, first_path, n_paths)
+
+    def cva_paths(self, c, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
+        return self._paths("cva", precision, _as_cva(precision, c), seed, first_path, n_paths)
+
+    def normals(self, seed, domain, first_unit, n_units, block=0, precision="f64"):
+        out = np.empty(n_units * _lib.NPB[precision], dtype=NP[precision])
+        check(getattr(lib(), f"mc_normals_{precision}")(self._ctx, seed, domain, first_unit, n_units, block,
+                                                         out.ctypes.data_as(C.POINTER(_lib.CT[precision]))))
+        return out.reshape(n_units, _lib.NPB[precision])
+
+
+# ---- host helpers (no GPU needed) -----------------------------------------------------------
+def closing(sum_, sum2, n, discount=1.0):
+    e, c = C.c_double(), C.c_double()
+    lib().mc_closing(sum_, sum2, n, discount, C.byref(e), C.byref(c))
+    return e.value, c.value
+
+
+def shard_range(total, rank, world):
+    first, count = C.c_uint64(), C.c_uint64()
+    lib().mc_shard_range(total, rank, world, C.byref(first), C.byref(count))
+    return first.value, count.value
+
+
+def chol(c, precision="f64"):
+    """Cholesky with the reference's semantics (MonteCarloHost.c:90-105).  Returns (factor, bad_pivots)."""
+    c = np.ascontiguousarray(c, dtype=NP[precision])
+    n = c.shape[0]
+    a = np.zeros_like(c)
+    P = C.POINTER(_lib.CT[precision])
+    bad = getattr(lib(), f"mc_chol_{precision}")(n, c.ctypes.data_as(P), a.ctypes.data_as(P))
+    return a, bad
+
+
+# ---- the reference's three entry points ------------------------------------------------------
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+def _path_count(numBlocks, sims):
+    if numBlocks <= 0 or sims // numBlocks <= 0:
+        raise ValueError("numBlocks / sims give no paths")
+    return numBlocks * (sims // numBlocks)   # MonteCarloKernel.cu:491,508,524 with :413
+
+
+def dev_vanillaOpt(opt, numBlocks, numThreads, sims, precision="f64") -> OptionValue:
+    return default_engine().vanilla(opt, _path_count(numBlocks, sims), precision=precision).value()
+
+
+def dev_basketOpt(option, numBlocks, numThreads, sims, precision="f64") -> OptionValue:
+    return default_engine().basket(option, _path_count(numBlocks, sims), precision=precision).value()
+
+
+def dev_cvaEquityOption(cva, numBlocks, numThreads, sims, precision="f64") -> OptionValue:
+    return default_engine().cva(cva, _path_count(numBlocks, sims), precision=precision).value()
