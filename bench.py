@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's throughput on N MI355X, one JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A STEP is one pass of the hot path over one batch: one pricing call of the workload's path count
+on every GPU (simulation kernel + on-device reduction -> {sum, sum2, n} in HBM) and, for N > 1,
+the RCCL all-reduce of that 24-byte triple.  Default workload = BASELINE.json configs[1]:
+European vanilla call, 1 asset, 1e8 paths, fp32 simulation (fp64 accumulation), per GPU.
+
+Scaling is WEAK: every GPU simulates `paths` paths per step, rank g taking the contiguous global
+range [(step*N + g) * paths, +paths) of one Philox stream (no data-path collective besides the
+triple).  Steps are pipelined: the all-reduce of step i runs on RCCL's stream while the compute
+stream simulates step i+1; all of them are waited for inside the timed region.
+
+Reported besides the contract fields:
+  roofline      dominant kernel (the simulation kernel) timed with HIP events on its launch stream
+                for every 8th step inside the timed region; achieved = algorithmic flop per launch
+                (15.5 flop/path vanilla, n^2+12.5n+6 basket, 60/path-step CVA) / that
+                duration; the bound is VALU issue, not HBM or MFMA (DESIGN.md "Roofline")
+  cpu_baseline  the reference's own CPU path (oracle/_ref, compiled from MonteCarloHost.c) or, when
+                that build is absent, the oracle port; one host core; rank 0 at N=1 only
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BS_EXACT = 10.386270784322328  # exact Black-Scholes for the vanilla workload
+
+VAN = dict(s=100.0, k=100.0, r=0.048790, v=0.2, t=1.0)                       # reference vanillaOpt.cu:22-26
+CVA = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6, n_grid=256)  # cvaOpt.cu:22-34
+
+
+def basket_inputs(mc, n, X):
+    import numpy as np
+    v = [0.3 if i % 2 == 0 else 0.2 for i in range(n)]
+    L, bad = mc.chol(np.full((n, n), 0.5) + 0.5 * np.eye(n), X)
+    assert bad == 0
+    return dict(s=[100.0] * n, v=v, p=L.tolist(), d=[0.0] * n, w=[1.0 / n] * n, k=100.0, t=1.0, r=0.048790164)
+
+
+def workloads(mc):
+    f_basket = lambda n: n * n + 12.5 * n + 6  # noqa: E731
+    return {
+        # name: (product, precision, inputs, paths per GPU per step, flop per path, description)
+        "vanilla_f32": ("vanilla", "f32", VAN, 10 ** 8, 15.5, "European vanilla call, 1 asset, 1e8 paths, fp32 (BASELINE configs[1])"),
+        "vanilla_f64": ("vanilla", "f64", VAN, 10 ** 8, 15.5, "European vanilla call, 1 asset, 1e8 paths, fp64"),
+        "basket4_f32": ("basket", "f32", lambda: basket_inputs(mc, 4, "f32"), 10 ** 8, f_basket(4), "Basket call, 4 correlated assets, 1e8 paths, fp32 (BASELINE configs[2])"),
+        "basket16_f64": ("basket", "f64", lambda: basket_inputs(mc, 16, "f64"), 125 * 10 ** 6, f_basket(16), "Basket call, 16 correlated assets, 1e9/8 paths per GPU, fp64 (BASELINE configs[3])"),
+        "cva256_f64": ("cva", "f64", CVA, 1250000, 60.0 * 256 + 5, "CVA on vanilla call, 256 dates x 1e7/8 paths per GPU, fp64 (BASELINE configs[4])"),
+        "cva256_f32": ("cva", "f32", CVA, 1250000, 60.0 * 256 + 5, "CVA on vanilla call, 256 dates x 1e7/8 paths per GPU, fp32"),
+    }
+
+
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md; fp64 vector = half)
+
+
+def cpu_baseline(prod, X, inputs, seconds):
+    """Time the reference's CPU path on ONE host core for about `seconds` seconds."""
+    from oracle import pyoracle as po   # checker / baseline only
+    po.build()
+    n_assets = len(inputs["s"]) if prod == "basket" else 3
+    use_ref = po.ref_available(X, n_assets)
+    if prod == "vanilla":
+        run = (lambda n: po.Ref(X, 3).vanilla(inputs, n, 12345)) if use_ref else (lambda n: po.host_vanilla(X, inputs, n, 12345))
+        rate_guess, per_unit, unit = 1.5e7, 1, "paths/s"
+    elif prod == "basket":
+        run = (lambda n: po.Ref(X, n_assets).basket(inputs, n, 12345)) if use_ref else (lambda n: po.host_basket(X, inputs, n, 12345))
+        rate_guess, per_unit, unit = 1.5e7 / n_assets, 1, "paths/s"
+    else:
+        run = (lambda n: po.Ref(X, 3).cva(inputs, n, 12345)) if use_ref else (lambda n: po.host_cva(X, inputs, n, 12345))
+        rate_guess, per_unit, unit = 8e6 / inputs["n_grid"], 1, "paths/s"
+    n = max(1000, int(rate_guess * 0.5))
+    t0 = time.perf_counter(); run(n); dt = time.perf_counter() - t0   # calibration pass
+    n = int(min(2 ** 31 - 1, max(n, n * seconds / max(dt, 1e-3))))
+    t0 = time.perf_counter(); run(n); dt = time.perf_counter() - t0
+    return {"value": n * per_unit / dt, "unit": unit, "cores": 1, "kind": "reference" if use_ref else "port",
+            "sample": f"{n} paths of the same workload in {dt:.1f} s, single thread (the reference is single-threaded: "
+                      f"MonteCarloHost.c:185-229), gcc -O2 -ffp-contract=off",
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="vanilla_f32")
+    ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--profile-every", type=int, default=8)
+    ap.add_argument("--sync-allreduce", action="store_true", help="wait for each step's all-reduce before the next launch")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import montecarlocuda_amd as mc
+    from montecarlocuda_amd import distributed as D
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    rank, world, local = D.init_from_env("nccl")
+    if world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    eng = mc.Engine(local)
+    prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
+    if callable(inputs):
+        inputs = inputs()
+    if args.paths:
+        paths = args.paths
+    K, W = args.steps, args.warmup
+    struct, keep = eng.prepared(prod, X, inputs)
+    seed = mc.MC_DEFAULT_SEED
+    stream = torch.cuda.current_stream()
+    triples = torch.zeros((K + W, 3), dtype=torch.float64, device="cuda")
+    works = []
+
+    def step(i):
+        first = (i * world + rank) * paths
+        eng.launch(prod, X, struct, seed, first, paths, triples[i].data_ptr(), stream.cuda_stream)
+        if world > 1:
+            w = dist.all_reduce(triples[i], op=dist.ReduceOp.SUM, async_op=True)
+            if args.sync_allreduce:
+                w.wait()
+            else:
+                works.append(w)
+
+    def drain():
+        for w in works:
+            w.wait()
+        works.clear()
+        torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i)
+    drain()
+    eng.profile(args.profile_every)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(W, W + K):
+        step(i)
+    drain()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    samples, kernel_ms_total = eng.profile_read()
+    eng.profile(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        tot = triples[W:].sum(dim=0).cpu().tolist()           # every step's triple is already all-reduced
+        r, t_ = float(inputs["r"]), float(inputs["t"])
+        if X == "f32":
+            import numpy as np
+            r, t_ = float(np.float32(r)), float(np.float32(t_))
+        disc = 1.0 if prod == "cva" else math.exp(-r * t_)
+        price, ci = mc.closing(tot[0], tot[1], int(tot[2]), disc)
+        assert int(tot[2]) == K * world * paths, (tot[2], K * world * paths)
+        units_per_step = world * paths
+        value = units_per_step * K / elapsed
+        kernel_s = (kernel_ms_total / samples) * 1e-3 if samples else None
+        ach = flop_per_path * paths / kernel_s / 1e12 if kernel_s else None
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Monte Carlo paths/sec", "value": value, "unit": "paths/s", "n_gpus": world, "steps": K,
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": X, "data": "synthetic",
+            "config": {"workload": desc, "paths_per_gpu_per_step": paths, "global_paths_per_step": units_per_step,
+                       "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triple",
+                       "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
+                       "grid": f"{eng.blocks}x256"},
+            "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
+            "roofline": {"bound": "valu", "achieved": ach, "peak": PEAK_TFLOPS[X], "unit": "TFLOP/s",
+                         "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,
+                         "kernel": f"mc::{prod}_kernel<{X}>", "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
+                         "kernel_samples": samples, "flop_per_path": flop_per_path,
+                         "kernel_paths_per_s": paths / kernel_s if kernel_s else None},
+        }
+        if prod == "vanilla":
+            out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
+        if world == 1 and args.cpu_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

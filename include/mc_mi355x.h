@@ -98,6 +98,14 @@ int mc_context_blocks(const mc_context *ctx);
 /* Name / CU count / clock of the context's device, for logs. */
 int mc_context_info(const mc_context *ctx, char *name, int name_len, int *compute_units, int *clock_mhz);
 
+/* Sampled device timing of the simulation kernel (not the finishing kernel): every `every`-th
+ * launch is bracketed by two HIP events on its launch stream (0 = off; at most 512 samples are
+ * kept between reads).  Replaces the reference's cudaEvent pair around each launch
+ * (dp/MonteCarloKernel.cu:380-386,393-399,447-453), returned instead of printed. */
+int mc_context_profile(mc_context *ctx, int every);
+/* Waits for the sampled launches; returns their count and summed duration, then resets. */
+int mc_context_profile_read(mc_context *ctx, int *samples, double *total_ms);
+
 /* ---- asynchronous launches ------------------------------------------------------------
  * d_triple: DEVICE pointer to 3 doubles, overwritten with {sum, sum2, n}.
  * stream  : hipStream_t passed as void*; NULL = the context's own stream.

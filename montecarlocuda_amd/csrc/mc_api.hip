@@ -68,6 +68,36 @@ struct mc_context {
     std::vector<char> table_key;  // inputs the cached table was built from
     hipEvent_t table_copied = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // sampled device timing of the simulation kernels (mc_context_profile)
+    int profile_every = 0;
+    uint64_t launches = 0;
+    std::vector<hipEvent_t> prof_start, prof_stop;
+    int prof_used = 0;
+};
+
+static constexpr int PROFILE_RING = 512;
+
+// Brackets the simulation kernel(s) of one call with two events on the launch stream when this
+// call is one of the sampled ones; the finishing kernel stays outside the bracket.
+struct ProfileScope {
+    mc_context *c;
+    hipStream_t st;
+    int slot = -1;
+    ProfileScope(mc_context *ctx, hipStream_t s) : c(ctx), st(s)
+    {
+        const uint64_t id = c->launches++;
+        if (c->profile_every > 0 && id % (uint64_t)c->profile_every == 0 && c->prof_used < PROFILE_RING) {
+            slot = c->prof_used++;
+            (void)hipEventRecord(c->prof_start[slot], st);
+        }
+    }
+    void stop()
+    {
+        if (slot >= 0)
+            (void)hipEventRecord(c->prof_stop[slot], st);
+        slot = -1;
+    }
+    ~ProfileScope() { stop(); }
 };
 
 extern "C" int mc_device_count(void)
@@ -130,6 +160,8 @@ extern "C" void mc_context_destroy(mc_context *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->table_copied) (void)hipEventDestroy(c->table_copied);
+    for (hipEvent_t e : c->prof_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->prof_stop) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -144,6 +176,44 @@ extern "C" int mc_context_info(const mc_context *c, char *name, int name_len, in
         snprintf(name, (size_t)name_len, "%s", c->name);
     if (cus) *cus = c->compute_units;
     if (mhz) *mhz = c->clock_mhz;
+    return MC_OK;
+}
+
+extern "C" int mc_context_profile(mc_context *c, int every)
+{
+    if (!c || every < 0)
+        return fail(MC_ERR_INVALID, "mc_context_profile: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    if (every > 0 && c->prof_start.empty()) {
+        c->prof_start.resize(PROFILE_RING);
+        c->prof_stop.resize(PROFILE_RING);
+        for (int i = 0; i < PROFILE_RING; ++i) {
+            HIPCHK(hipEventCreate(&c->prof_start[i]));
+            HIPCHK(hipEventCreate(&c->prof_stop[i]));
+        }
+    }
+    c->profile_every = every;
+    c->prof_used = 0;
+    c->launches = 0;
+    return MC_OK;
+}
+
+extern "C" int mc_context_profile_read(mc_context *c, int *samples, double *total_ms)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    HIPCHK(hipSetDevice(c->device));
+    double total = 0;
+    for (int i = 0; i < c->prof_used; ++i) {
+        HIPCHK(hipEventSynchronize(c->prof_stop[i]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_start[i], c->prof_stop[i]));
+        total += ms;
+    }
+    if (samples) *samples = c->prof_used;
+    if (total_ms) *total_ms = total;
+    c->prof_used = 0;
+    c->launches = 0;
     return MC_OK;
 }
 
@@ -282,6 +352,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     const uint64_t end = first + n;
     int slot = 0;
     std::vector<Segment> segs;
+    ProfileScope prof(c, st);
     if (out) {
         const uint64_t u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
         if (int rc = plan_segments(u0, u1 - u0, segs)) return rc;
@@ -314,6 +385,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
             slot += 1;
         }
     }
+    prof.stop();
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale1, scale2, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;
@@ -368,6 +440,7 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;
     int slot = 0, rc = MC_OK;
+    ProfileScope prof(c, st);
     switch (o->n) {
 #define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, *o, seed, segs, st, out, slot); break;
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
@@ -375,6 +448,7 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
 #undef MC_CASE
     }
     if (rc) return rc;
+    prof.stop();
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;
@@ -480,6 +554,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     if (int rc = plan_segments(first, n, segs)) return rc;
     int slot = 0;
     uint64_t done = 0;
+    ProfileScope prof(c, st);
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
@@ -487,6 +562,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         slot += g;
         done += s.count;
     }
+    prof.stop();
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;

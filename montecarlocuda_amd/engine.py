@@ -137,6 +137,16 @@ class Engine:
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value,
                 "blocks": self.blocks}
 
+    def profile(self, every: int):
+        """Sample the simulation kernel's device time on every `every`-th launch (0 = off)."""
+        check(lib().mc_context_profile(self._ctx, every))
+
+    def profile_read(self):
+        """(samples, total_ms) of the sampled simulation-kernel launches since the last read."""
+        n, ms = C.c_int(), C.c_double()
+        check(lib().mc_context_profile_read(self._ctx, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     # ---- synchronous estimators --------------------------------------------------------
     def _run(self, prod, X, struct, seed, first, n):
         r = _lib.Result()

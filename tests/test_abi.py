@@ -1,0 +1,98 @@
+"""The C-ABI boundary, checked without a GPU: the library loads, exports every symbol
+include/mc_mi355x.h declares, the legacy libraries export the reference's three entry points,
+and include/MonteCarlo.h has the reference's struct layouts (measured with gcc on
+the reference header: dp 40/192/16/72, sp 20/96/8/36 for N=3)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import montecarlocuda_amd as mc
+    if not os.path.exists(mc._lib.LIB_PATH):
+        mc.build()
+    return mc
+
+
+def test_library_exports_every_declared_symbol(mc):
+    L = mc._lib.lib()
+    header = open(os.path.join(INC, "mc_mi355x.h")).read()
+    declared = set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mc_context"}
+    assert declared == set(mc._lib.EXPORTS), declared ^ set(mc._lib.EXPORTS)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_legacy_library_exports_reference_entry_points(mc, X):
+    path = mc._lib.LEGACY[X]
+    assert os.path.exists(path)
+    L = C.CDLL(path)
+    for name in ("dev_vanillaOpt", "dev_basketOpt", "dev_cvaEquityOption"):
+        assert hasattr(L, name)
+
+
+LAYOUT_C = r"""
+#include <stddef.h>
+#include "MonteCarlo.h"
+int main(void){
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(OptionData), sizeof(MultiOptionData), sizeof(OptionValue),
+         sizeof(CVA), offsetof(CVA, option), offsetof(CVA, n), sizeof(MonteCarloData));
+  return 0; }
+"""
+
+# (precision flag, N) -> sizes measured on the REFERENCE header (SURVEY 8a "Types")
+EXPECTED = {("", 3): (40, 192, 16, 72, 24, 64, 256), ("-DMC_SINGLE_PRECISION", 3): (20, 96, 8, 36, 12, 32, 132),
+            ("", 4): (40, 280, 16, 72, 24, 64, None), ("-DMC_SINGLE_PRECISION", 4): (20, 140, 8, 36, 12, 32, None),
+            ("", 16): (40, 2584, 16, 72, 24, 64, None), ("-DMC_SINGLE_PRECISION", 16): (20, 1292, 8, 36, 12, 32, None)}
+
+
+@pytest.mark.parametrize("key", sorted(EXPECTED))
+def test_dropin_header_layout(tmp_path, key):
+    flag, n = key
+    src = tmp_path / "layout.c"
+    src.write_text(LAYOUT_C)
+    exe = tmp_path / "layout"
+    cmd = ["gcc", "-std=c11", f"-I{INC}", f"-DN={n}", str(src), "-o", str(exe)] + ([flag] if flag else [])
+    subprocess.check_call(cmd)
+    got = tuple(int(x) for x in subprocess.check_output([str(exe)]).split())
+    want = EXPECTED[key]
+    for g, w in zip(got, want):
+        if w is not None:
+            assert g == w, (key, got, want)
+
+
+def test_layout_matches_live_reference_header(tmp_path):
+    """Where the reference is mounted, compile the same probe against ITS header and compare."""
+    ref = "/root/reference/double_precision"
+    if not os.path.isdir(ref):
+        pytest.skip("reference not mounted")
+    src = tmp_path / "layout.c"
+    src.write_text(LAYOUT_C)
+    outs = []
+    for inc, flags in ((ref, []), (INC, [])), (("/root/reference/single_precision", []), (INC, ["-DMC_SINGLE_PRECISION"])):
+        pair = []
+        for i, f in (inc, flags):
+            exe = tmp_path / "p"
+            subprocess.check_call(["gcc", "-w", f"-I{i}", str(src), "-o", str(exe)] + f)
+            pair.append(subprocess.check_output([str(exe)]))
+        outs.append(pair)
+    for a, b in outs:
+        assert a == b
+
+
+def test_no_gpu_is_a_loud_error(mc):
+    """Without a device the engine refuses to run -- there is no CPU fallback to fall into."""
+    if mc._lib.lib().mc_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(mc.McError, match="no HIP device"):
+        mc.Engine(0)

@@ -1,0 +1,325 @@
+"""Hop B and C on a real MI355X: the HIP engine, called through the C ABI, against the oracle on
+identical Philox counters (per path and per sum), against closed-form Black-Scholes, and -- at
+BASELINE.json's full sizes -- through size-independent properties (shard additivity, geometry
+independence, statistical agreement with analytic targets).
+
+TOLERANCES (north_star: "within a stated fp32/fp64 tolerance").  Both sides evaluate the same
+real-number formulas on the same uniforms; they differ only in rounding:
+  f32  device uses v_log/v_sqrt/v_sin/v_cos/v_exp_f32 (about 1 ulp each) and base-2 folding;
+       the oracle uses glibc float libm.  Measured on MI355X (profiles/r01_first_contact_explore.log):
+       normals 4.8e-7 abs, payoffs 3e-5..4.6e-5 abs on values of O(10..100), CVA 2.5e-6 abs,
+       sums 1e-8..4e-7 rel.  Stated bounds carry a 4-6x margin:
+           normal        |dz|  <= 2e-6
+           payoff        |dp|  <= 2e-6 * spot      (2e-4 at S=100)
+           CVA per path  |dv|  <= 2e-5, sums/estimates rel <= 3e-6
+  f64  device uses ocml double log/exp/sincospi (<= 1-2 ulp), the oracle glibc (< 1 ulp).
+       Measured: normals 1.7e-15, payoffs 1.1e-13 abs, CVA 6e-15, sums 5e-15 rel.  Stated bounds:
+           normal <= 2e-14, payoff <= 1e-14 * spot (1e-12 at S=100), CVA <= 1e-13,
+           sums/estimates rel <= 1e-12
+Integer work (Philox words -> uniforms) is exact on both sides; any mismatch there would show
+as O(1) differences, not as rounding.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+VAN = dict(s=100.0, k=100.0, r=0.048790, v=0.2, t=1.0)          # reference vanillaOpt.cu:22-26
+CVA0 = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6)  # reference cvaOpt.cu:22-34
+BS_EXACT = 10.386270784322328   # exact Black-Scholes for VAN
+TOL = {
+    "f32": dict(z=2e-6, pay=2e-6, cva=2e-5, rel=3e-6),
+    "f64": dict(z=2e-14, pay=1e-14, cva=1e-13, rel=1e-12),
+}
+
+
+@pytest.fixture(scope="module")
+def mc():
+    import montecarlocuda_amd as mc
+    return mc
+
+
+@pytest.fixture(scope="module")
+def eng(mc):
+    e = mc.Engine(0)
+    yield e
+    e.close()
+
+
+SEED = 0x4D435F4D49333535
+
+
+def basket_inputs(mc, n, X, rho=0.5):
+    """S=100, w=1/n, vols alternating 0.3/0.2, K=100, r=0.048790164, T=1, equicorrelation."""
+    v = [0.3 if i % 2 == 0 else 0.2 for i in range(n)]
+    corr = np.full((n, n), rho) + (1 - rho) * np.eye(n)
+    L, bad = mc.chol(corr, X)
+    assert bad == 0
+    return dict(s=[100.0] * n, v=v, p=L.tolist(), d=[0.0] * n, w=[1.0 / n] * n, k=100.0, t=1.0, r=0.048790164)
+
+
+def f64(a):
+    return np.asarray(a, dtype=np.float64)
+
+
+# ---- the generator ------------------------------------------------------------------------
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("domain,block,first", [(1, 0, 0), (2, 3, 12345), (3, 63, (1 << 32) - 100), (1, 0, (7 << 32) + 5)])
+def test_normals_match_oracle(eng, po, X, domain, block, first):
+    n = 512
+    got = f64(eng.normals(SEED, domain, first, n, block, X))
+    want = np.array([po.dev_normals(X, SEED, domain, first + u, block) for u in range(n)], dtype=np.float64)
+    assert np.abs(got - want).max() <= TOL[X]["z"]
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_normals_are_standard(eng, X):
+    z = f64(eng.normals(SEED + 1, 1, 0, 1 << 20, 0, X)).ravel()
+    n = z.size
+    assert abs(z.mean()) < 5 / math.sqrt(n)
+    assert abs(z.var() - 1) < 5 * math.sqrt(2 / n)
+    assert abs((z ** 3).mean()) < 5 * math.sqrt(15 / n)
+    assert abs((z ** 4).mean() - 3) < 5 * math.sqrt(96 / n)
+
+
+# ---- vanilla ------------------------------------------------------------------------------
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("first,n", [(0, 1), (0, 2), (1, 1), (3, 1), (1, 3), (2, 4), (3, 9), (5, 20000),
+                                     ((1 << 34) - 7, 40), ((3 << 33) + 1, 1001)])
+def test_vanilla_per_path_and_sums(eng, po, X, first, n):
+    got = f64(eng.vanilla_paths(VAN, n, SEED, first, X))
+    want, o = po.dev_vanilla(X, VAN, SEED, first, n)
+    assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * VAN["s"]
+    e = eng.vanilla(VAN, n, SEED, first, X)
+    assert e.n == n
+    assert e.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"], abs=TOL[X]["pay"] * VAN["s"])
+    assert e.sum2 == pytest.approx(o["sum2"], rel=TOL[X]["rel"], abs=TOL[X]["pay"] * VAN["s"] ** 2)
+    if n > 1000:
+        assert e.expected == pytest.approx(o["expected"], rel=TOL[X]["rel"])
+        assert e.confidence == pytest.approx(o["confidence"], rel=TOL[X]["rel"])
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("opt", [dict(s=105.0, k=95.0, r=0.02, v=0.35, t=2.5), dict(s=40.0, k=55.0, r=0.0, v=0.6, t=0.25),
+                                 dict(s=1.0, k=1.0, r=0.1, v=0.05, t=10.0), dict(s=100.0, k=100.0, r=0.05, v=0.0, t=1.0)])
+def test_vanilla_other_options(eng, po, X, opt):
+    n = 30000
+    got = f64(eng.vanilla_paths(opt, n, 77, 0, X))
+    want, o = po.dev_vanilla(X, opt, 77, 0, n)
+    scale = opt["s"] * math.exp(abs(opt["r"]) * opt["t"] + 3 * opt["v"] * math.sqrt(opt["t"]))  # size of S_T in play
+    assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * max(scale, opt["s"]) * 4
+    e = eng.vanilla(opt, n, 77, 0, X)
+    assert e.sum == pytest.approx(o["sum"], rel=4 * TOL[X]["rel"])
+
+
+def test_vanilla_c2_full_size_vs_black_scholes(eng):
+    """BASELINE configs[1]: 1e8 fp32 paths on one GPU vs closed form.  At 1e8 paths CI ~ 0.003, so
+    the 1e-3 target is checked on the 1e10-path run (CI ~ 3e-4); both must sit inside 3.5 CI."""
+    e = eng.vanilla(VAN, 10 ** 8, SEED, 0, "f32")
+    assert e.confidence == pytest.approx(0.003022, rel=2e-3)
+    assert abs(e.expected - BS_EXACT) < 3.5 / 1.96 * e.confidence
+    big = eng.vanilla(VAN, 10 ** 10, SEED, 0, "f32")
+    assert big.n == 10 ** 10
+    assert abs(big.expected - BS_EXACT) < 1e-3
+    assert abs(big.expected - BS_EXACT) < 3.5 / 1.96 * big.confidence
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_vanilla_shards_add_up_and_geometry_does_not_matter(mc, eng, X):
+    """Size-independent properties at 1e8 paths: the union of 8 contiguous shards equals the whole
+    range (what the multi-GPU path relies on), and the grid size only changes summation order."""
+    total = 10 ** 8 + 3
+    whole = eng.vanilla(VAN, total, SEED, 0, X)
+    s = s2 = 0.0
+    n = 0
+    for r in range(8):
+        first, cnt = mc.shard_range(total, r, 8)
+        e = eng.vanilla(VAN, cnt, SEED, first, X)
+        s, s2, n = s + e.sum, s2 + e.sum2, n + e.n
+    assert n == total
+    assert s == pytest.approx(whole.sum, rel=1e-12) and s2 == pytest.approx(whole.sum2, rel=1e-12)
+    with mc.Engine(0, blocks=311) as small:
+        other = small.vanilla(VAN, total, SEED, 0, X)
+    assert other.sum == pytest.approx(whole.sum, rel=1e-12) and other.sum2 == pytest.approx(whole.sum2, rel=1e-12)
+    # bitwise reproducible for a fixed geometry
+    again = eng.vanilla(VAN, total, SEED, 0, X)
+    assert (again.sum, again.sum2) == (whole.sum, whole.sum2)
+    # a different seed is a different sample
+    assert eng.vanilla(VAN, total, SEED + 1, 0, X).sum != whole.sum
+
+
+# ---- basket -------------------------------------------------------------------------------
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("n_assets", [1, 2, 3, 4, 5, 7, 8, 13, 16])
+def test_basket_per_path_and_sums(mc, eng, po, X, n_assets):
+    b = basket_inputs(mc, n_assets, X)
+    n = 6000
+    first = 7 if n_assets != 4 else (1 << 32) - 3000   # one case straddles the 2^32 unit boundary
+    got = f64(eng.basket_paths(b, n, SEED, first, X))
+    want, o = po.dev_basket(X, b, SEED, first, n)
+    assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * 100.0 * 2
+    e = eng.basket(b, n, SEED, first, X)
+    assert e.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"]) and e.sum2 == pytest.approx(o["sum2"], rel=TOL[X]["rel"])
+    assert e.expected == pytest.approx(o["expected"], rel=TOL[X]["rel"])
+    assert e.confidence == pytest.approx(o["confidence"], rel=TOL[X]["rel"])
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_basket_reference_n3_inputs(mc, eng, po, X):
+    """The reference driver's own 3-asset data incl. its singular correlation matrix (basketOpt.cu:34-61):
+    the factor has a zero last column (zero-pivot rule), weights 1/3, drift 0 plus a non-zero drift variant."""
+    L, bad = mc.chol([[1, -.5, -.5], [-.5, 1, -.5], [-.5, -.5, 1]], X)
+    assert bad == 1
+    for d in ([0.0, 0.0, 0.0], [0.01, -0.02, 0.03]):
+        b = dict(s=[100.0] * 3, v=[0.2, 0.3, 0.2], p=L.tolist(), d=d, w=[1 / 3] * 3, k=100.0, t=1.0, r=0.048790164)
+        got = f64(eng.basket_paths(b, 5000, SEED, 0, X))
+        want, o = po.dev_basket(X, b, SEED, 0, 5000)
+        assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * 200.0
+
+
+def test_basket_collapses_to_black_scholes(mc, eng):
+    """n identical, perfectly correlated assets are one asset: the basket price must agree with
+    closed-form Black-Scholes within the CI (SURVEY 8c hop C)."""
+    n = 4
+    L = np.zeros((n, n))
+    L[:, 0] = 1.0   # Cholesky factor of the all-ones correlation matrix
+    b = dict(s=[100.0] * n, v=[0.2] * n, p=L.tolist(), d=[0.0] * n, w=[0.25] * n, k=100.0, t=1.0, r=0.048790)
+    for X in ("f32", "f64"):
+        e = eng.basket(b, 4 * 10 ** 7, SEED, 0, X)
+        assert abs(e.expected - BS_EXACT) < 3.5 / 1.96 * e.confidence
+
+
+def test_basket_c3_c4_full_size_properties(mc, eng, po):
+    """BASELINE configs[2] (n=4, 1e8 paths, f32) and configs[3] (n=16, 1e9 paths, f64) at full
+    size on one GPU: shard additivity, f32-vs-f64 statistical agreement, and agreement with the
+    reference CPU path (sp host at 1e6 paths, seed 12345: tests/golden/ref_mc.json ~10.33 / 9.71)."""
+    b4 = basket_inputs(mc, 4, "f32")
+    whole = eng.basket(b4, 10 ** 8, SEED, 0, "f32")
+    s = sum(eng.basket(b4, cnt, SEED, first, "f32").sum for first, cnt in (mc.shard_range(10 ** 8, r, 8) for r in range(8)))
+    assert s == pytest.approx(whole.sum, rel=1e-12)
+    d4 = eng.basket(basket_inputs(mc, 4, "f64"), 10 ** 8, SEED + 9, 0, "f64")
+    assert abs(whole.expected - d4.expected) < 4 / 1.96 * math.hypot(whole.confidence, d4.confidence)
+    host4 = po.host_basket("f32", b4, 200000, 12345)   # reference CPU algorithm (sp formula), own stream
+    assert abs(whole.expected - host4["expected"]) < 4 / 1.96 * host4["confidence"]
+    b16 = basket_inputs(mc, 16, "f64")
+    whole16 = eng.basket(b16, 10 ** 9, SEED, 0, "f64")
+    assert whole16.n == 10 ** 9
+    s = sum(eng.basket(b16, cnt, SEED, first, "f64").sum for first, cnt in (mc.shard_range(10 ** 9, r, 8) for r in range(8)))
+    assert s == pytest.approx(whole16.sum, rel=1e-12)
+    host16 = po.host_basket("f32", basket_inputs(mc, 16, "f32"), 100000, 12345)
+    assert abs(whole16.expected - host16["expected"]) < 4 / 1.96 * host16["confidence"]
+
+
+# ---- CVA ----------------------------------------------------------------------------------
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("n_grid", [1, 2, 3, 25, 50, 75, 250, 256, 500])
+def test_cva_per_path_and_sums(eng, po, X, n_grid):
+    """Grid sizes of the reference driver (cvaOpt.cu:70-75) plus 256 (BASELINE C5) and tiny grids.
+    250 in f64 ends with a NEGATIVE residual maturity (last date contributes 0), 256 with exactly 0
+    (intrinsic value), 500 in f32 with a small positive one."""
+    c = dict(CVA0, n_grid=n_grid)
+    n = 3000
+    got = f64(eng.cva_paths(c, n, SEED, 11, X))
+    want, o = po.dev_cva(X, c, SEED, 11, n)
+    assert np.abs(got - f64(want)).max() <= TOL[X]["cva"]
+    e = eng.cva(c, n, SEED, 11, X)
+    assert e.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"]) and e.sum2 == pytest.approx(o["sum2"], rel=2 * TOL[X]["rel"])
+    assert e.expected == pytest.approx(o["expected"], rel=TOL[X]["rel"])
+    assert e.confidence == pytest.approx(o["confidence"], rel=10 * TOL[X]["rel"])
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_cva_other_inputs(eng, po, X):
+    c = dict(s=90.0, k=100.0, r=0.01, v=0.4, t=2.0, defint=0.1, lgd=0.45, n_grid=37)
+    got = f64(eng.cva_paths(c, 4000, 5, 0, X))
+    want, _ = po.dev_cva(X, c, 5, 0, 4000)
+    assert np.abs(got - f64(want)).max() <= 4 * TOL[X]["cva"]
+
+
+def cva_analytic(c):
+    """E[C(S_t, T-t)] = C_0 e^{rt} under the pricing measure, so
+    E[CVA] = LGD * sum_j dp_j * C_0 * e^{r t_j}   (SURVEY 8d C5), with C_0 the Black-Scholes value."""
+    from math import erf, exp, log, sqrt
+    s, k, r, v, t = (c[x] for x in "skrvt")
+    d1 = (log(s / k) + (r + 0.5 * v * v) * t) / (v * sqrt(t))
+    d2 = d1 - v * sqrt(t)
+    phi = lambda x: 0.5 * (1 + erf(x / sqrt(2)))  # noqa: E731
+    c0 = s * phi(d1) - k * exp(-r * t) * phi(d2)
+    dt = t / c["n_grid"]
+    return c["lgd"] * sum((exp(-c["defint"] * dt * (j - 1)) - exp(-c["defint"] * dt * j)) * c0 * exp(r * dt * j)
+                          for j in range(1, c["n_grid"] + 1))
+
+
+def test_cva_c5_full_size_vs_analytic(mc, eng):
+    """BASELINE configs[4]: 256 dates x 1e7 paths, fp64, full size on one GPU: within 3.5 CI of the
+    analytic target (the Hastings CDF's 1e-5 price error is far below the CI), shards add up."""
+    c = dict(CVA0, n_grid=256)
+    whole = eng.cva(c, 10 ** 7, SEED, 0, "f64")
+    target = cva_analytic(c)
+    assert abs(whole.expected - target) < 3.5 / 1.96 * whole.confidence + 2e-6
+    s = sum(eng.cva(c, cnt, SEED, first, "f64").sum for first, cnt in (mc.shard_range(10 ** 7, r, 8) for r in range(8)))
+    assert s == pytest.approx(whole.sum, rel=1e-12)
+    f = eng.cva(c, 10 ** 7, SEED, 0, "f32")
+    assert abs(f.expected - target) < 3.5 / 1.96 * f.confidence + 2e-6
+    assert f.expected == pytest.approx(whole.expected, abs=4 / 1.96 * whole.confidence)
+
+
+# ---- the legacy entry points and the error contract ---------------------------------------------
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_legacy_symbols_drop_in(mc, eng, po, X):
+    """dev_vanillaOpt / dev_basketOpt / dev_cvaEquityOption with the reference's structs and the
+    reference's path-count rule numBlocks * (sims / numBlocks) (MonteCarloKernel.cu:491,508,524)."""
+    L = C.CDLL(mc._lib.LEGACY[X])
+    OptionData, MultiOptionData, OptionValue, CVA = po.ref_types(X, 3)
+    L.dev_vanillaOpt.argtypes = [C.POINTER(OptionData), C.c_int, C.c_int, C.c_int]
+    L.dev_vanillaOpt.restype = OptionValue
+    L.dev_basketOpt.argtypes = [C.POINTER(MultiOptionData), C.c_int, C.c_int, C.c_int]
+    L.dev_basketOpt.restype = OptionValue
+    L.dev_cvaEquityOption.argtypes = [C.POINTER(CVA), C.c_int, C.c_int, C.c_int]
+    L.dev_cvaEquityOption.restype = OptionValue
+    R = np.dtype(po.NP[X]).type
+    sims, blocks = 131072 * 3 + 77, 512
+    paths = blocks * (sims // blocks)
+    o = OptionData(*[VAN[k] for k in "skrvt"])
+    v = L.dev_vanillaOpt(C.byref(o), blocks, 128, sims)
+    e = eng.vanilla(VAN, paths, SEED, 0, X)
+    assert (v.Expected, v.Confidence) == (R(e.expected), R(e.confidence))
+    b = basket_inputs(mc, 3, X)
+    m = MultiOptionData()
+    for i in range(3):
+        m.s[i], m.v[i], m.d[i], m.w[i] = b["s"][i], b["v"][i], b["d"][i], b["w"][i]
+        for j in range(3):
+            m.p[i][j] = b["p"][i][j]
+    m.k, m.t, m.r = b["k"], b["t"], b["r"]
+    v = L.dev_basketOpt(C.byref(m), blocks, 128, sims)
+    e = eng.basket(b, paths, SEED, 0, X)
+    assert (v.Expected, v.Confidence) == (R(e.expected), R(e.confidence))
+    c = dict(CVA0, n_grid=50)
+    s = CVA(c["defint"], c["lgd"], 0, OptionData(*[c[k] for k in "skrvt"]), c["n_grid"])
+    v = L.dev_cvaEquityOption(C.byref(s), 1024, 256, 131072)
+    e = eng.cva(c, 131072, SEED, 0, X)
+    assert (v.Expected, v.Confidence) == (R(e.expected), R(e.confidence))
+
+
+def test_python_mirror_of_reference_interface(mc, eng):
+    v = mc.dev_vanillaOpt(mc.OptionData(**VAN), 512, 128, 131072 * 8)
+    e = eng.vanilla(VAN, 131072 * 8, SEED, 0, "f64")
+    assert (v.Expected, v.Confidence) == (e.expected, e.confidence)
+
+
+def test_invalid_arguments_are_errors_not_crashes(mc, eng):
+    with pytest.raises(mc.McError):
+        eng.vanilla(VAN, 0)
+    with pytest.raises(mc.McError):
+        eng.vanilla(dict(VAN, s=-1.0), 10)
+    with pytest.raises(mc.McError):
+        eng.cva(dict(CVA0, n_grid=0), 10)
+    n = 17
+    with pytest.raises(mc.McError, match="1..16"):
+        eng.basket(dict(s=[1.0] * n, v=[.1] * n, p=np.eye(n).tolist(), d=[0.0] * n, w=[1 / n] * n, k=1.0, t=1.0, r=0.0), 10)
+    with pytest.raises(mc.McError):
+        mc.Engine(99)
