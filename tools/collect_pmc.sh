@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collect PMC counters for one bench workload on the GPU box, one rocprofv3 pass per counter group
+# (FETCH_SIZE and WRITE_SIZE cannot share a pass: MI355X_MICROARCH.md "rocprofv3 PMC slots").
+#   gpurun -- bash tools/collect_pmc.sh vanilla_f32
+# Results: gpurun_out/pmc_<workload>/<group>/  (then: python tools/summarize_pmc.py)
+set -o pipefail
+W=${1:-vanilla_f32}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TMPDIR=/tmp
+cd "$R"
+OUT=$R/gpurun_out/pmc_$W
+mkdir -p "$OUT"
+run() { # name, counters...
+  local name=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --workload "$W" --steps 20 --warmup 2 --cpu-seconds 0 --profile-every 0 > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+  echo "pass $name ok"
+}
+run fetch FETCH_SIZE &&
+run write WRITE_SIZE &&
+run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY &&
+run sq2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS &&
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+find "$OUT" -name "*counter_collection.csv" | head

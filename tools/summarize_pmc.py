@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/pmc_<workload>/ (tools/collect_pmc.sh) into per-kernel averages.
+
+    python tools/summarize_pmc.py vanilla_f32 [round-tag]
+
+Writes profiles/<tag>_pmc_<workload>.txt (readable) and updates profiles/pmc_traffic.json, which
+bench.py reads for roofline.traffic.  HBM traffic follows MI355X_MICROARCH.md "HBM": FETCH_SIZE and
+WRITE_SIZE are in KiB; FETCH_SIZE counts a wide coalesced read stream at half its bytes, so the
+read side is reported both raw and doubled (upper bound) -- for these kernels both are ~KiB.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+w = sys.argv[1] if len(sys.argv) > 1 else "vanilla_f32"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+base = os.path.join(ROOT, "gpurun_out", f"pmc_{w}")
+acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
+for f in glob.glob(os.path.join(base, "*", "*", "*counter_collection.csv")):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "mc::" not in k:
+            continue
+        k = k.split("(")[0].replace("void ", "")
+        acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+lines = []
+summary = {}
+for k in sorted(acc):
+    lines.append(f"kernel {k}")
+    avg = {}
+    for c in sorted(acc[k]):
+        v = acc[k][c]
+        avg[c] = sum(v) / len(v)
+        lines.append(f"    {c:28s} dispatches={len(v):4d}  avg={avg[c]:.6g}  min={min(v):.6g}  max={max(v):.6g}")
+    summary[k] = avg
+    if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+        rd, wr = avg["FETCH_SIZE"] * 1024, avg["WRITE_SIZE"] * 1024
+        lines.append(f"    -> HBM bytes per launch: read {rd:.0f} (x2 correction: {2*rd:.0f}), write {wr:.0f}")
+    if "SQ_INSTS_VALU" in avg and "SQ_WAVES" in avg:
+        lines.append(f"    -> VALU instructions per wave: {avg['SQ_INSTS_VALU']/avg['SQ_WAVES']:.1f}"
+                     f", transcendental f32 per wave: {avg.get('SQ_INSTS_VALU_TRANS_F32',0)/avg['SQ_WAVES']:.1f}")
+    if "SQ_ACTIVE_INST_VALU" in avg and "SQ_BUSY_CYCLES" in avg:
+        lines.append(f"    -> SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {avg['SQ_ACTIVE_INST_VALU']/avg['SQ_WAVE_CYCLES']:.3f}"
+                     f"; SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = {avg['SQ_ACTIVE_INST_ANY']/avg['SQ_WAVE_CYCLES']:.3f}")
+text = "\n".join(lines)
+print(text)
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{w}.txt"), "w").write(
+    f"# rocprofv3 --pmc passes of `python3 bench.py --workload {w} --steps 20 --warmup 2` (tools/collect_pmc.sh)\n" + text + "\n")
+main = [k for k in summary if "finish" not in k and "masked" not in k]
+if main and "FETCH_SIZE" in summary[main[0]]:
+    a = summary[main[0]]
+    j = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    d = json.load(open(j)) if os.path.exists(j) else {}
+    d[w] = {"kernel": main[0], "fetch_bytes_raw": a["FETCH_SIZE"] * 1024, "write_bytes": a["WRITE_SIZE"] * 1024,
+            "hbm_bytes_per_launch": 2 * a["FETCH_SIZE"] * 1024 + a["WRITE_SIZE"] * 1024,
+            "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts wide reads at half); per simulation-kernel launch",
+            "source": f"profiles/{tag}_pmc_{w}.txt"}
+    json.dump(d, open(j, "w"), indent=1)
