@@ -303,26 +303,40 @@ template <class Real> struct VanillaTraits;
 template <> struct VanillaTraits<float> {
     using Opt = VanillaF32;
     using In = mc_option_f32;
-    static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
+    static void launch_hot(const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
+    {
+        vanilla_f32_kernel<<<grid, GROUP, 0, st>>>(k, w, partials);
+    }
+    static int prepare(const In &o, Opt &k_, double &scale1, double &scale2)
     {
         if (!finite_pos(o.s) || !finite_pos(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
             return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
         const double log2e = 1.4426950408889634074;
         const double drift = ((double)o.r - 0.5 * (double)o.v * (double)o.v) * (double)o.t;
         const double vol = (double)o.v * std::sqrt((double)o.t);
-        const double b2 = vol * log2e;
-        k.a2 = (float)(drift * log2e);
-        k.radius2 = (float)(-2.0 * 0.69314718055994530942 * b2 * b2);
-        k.kappa = (float)((double)o.k / (double)o.s);
-        k.spot = o.s;
-        scale1 = (double)o.s;
-        scale2 = (double)o.s * (double)o.s;
+        const double a2 = drift * log2e, b2 = vol * log2e;
+        // Box-Muller on 32-bit uniforms cannot exceed |z| = sqrt(2 * 33 ln 2) = 6.764 (u >= 2^-33);
+        // k makes 2^(a2 - k + b2 z) <= 1 for all of them, so the device's [0,1] clamp is exact.
+        const double zmax = 6.77;
+        const double k = std::ceil(a2 + b2 * zmax);
+        if (!(std::fabs(k) < 100))
+            return fail(MC_ERR_INVALID, "vanilla f32: drift/volatility out of the float range (k=%g)", k);
+        const double two_k = std::ldexp(1.0, (int)k);
+        k_.a2k = (float)(a2 - k);
+        k_.radius2 = (float)(-2.0 * 0.69314718055994530942 * b2 * b2);
+        k_.kappa_k = (float)((double)o.k / (double)o.s / two_k);
+        scale1 = (double)o.s * two_k;
+        scale2 = scale1 * scale1;
         return MC_OK;
     }
 };
 template <> struct VanillaTraits<double> {
     using Opt = VanillaF64;
     using In = mc_option_f64;
+    static void launch_hot(const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
+    {
+        vanilla_kernel<Opt, double><<<grid, GROUP, 0, st>>>(k, w, partials);
+    }
     static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
     {
         if (!finite_pos(o.s) || !finite_pos(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
@@ -369,7 +383,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
             for (const Segment &s : segs) {
                 const Work w = make_work(seed, s, first, end);
                 const int g = grid_for(c, s.count);
-                vanilla_kernel<typename T::Opt, Real><<<g, GROUP, 0, st>>>(k, w, c->partials + slot);
+                T::launch_hot(k, w, c->partials + slot, g, st);
                 slot += g;
             }
         }

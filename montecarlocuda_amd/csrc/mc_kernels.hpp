@@ -43,27 +43,57 @@ struct Work {
 //     payoff = max(S exp((r - v^2/2) T + v sqrt(T) z) - K, 0)
 // =========================================================================================
 
-// f32 constants, all prepared in fp64 on the host:
-//   payoff / S = max(2^(a2 + b2 z) - kappa, 0),  a2 = (r - v^2/2) T log2(e),
-//   b2 = v sqrt(T) log2(e), kappa = K / S;  radius2 = -2 ln2 * b2^2 folds b2 into Box-Muller's
-//   radius so each path costs one fma + one v_exp_f32 after its normal.
+// f32 constants, all prepared in fp64 on the host (mc_api.hip VanillaTraits<float>::prepare):
+//   payoff = S 2^k * clamp(2^(a2k + b2 z) - kappa_k, 0, 1)
+//   a2k = (r - v^2/2) T log2(e) - k,  b2 = v sqrt(T) log2(e),  kappa_k = (K/S) 2^-k,
+//   radius2 = -2 ln2 * b2^2  (folds b2 into Box-Muller's radius: one fma per path after its normal)
+//   k = integer with 2^(a2k + b2 |z|) <= 1 for every z the generator can produce (|z| < 6.77):
+//       the payoff's max(.,0) then rides on the subtract as the free [0,1] output clamp
+//       (v_sub_f32 ... clamp) instead of a separate v_max_f32; 2^k is exact, so the scaling
+//       costs no precision.  Sums are scaled back by S 2^k and (S 2^k)^2 in the finishing kernel.
 struct VanillaF32 {
-    float a2, radius2, kappa, spot;
+    float a2k, radius2, kappa_k;
 };
 struct VanillaF64 {
     double drift, vol, strike, spot;
 };
 
-// 4 normalised payoffs of one unit (one Philox block)
-__device__ __forceinline__ void vanilla_unit(const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
+typedef float f2 __attribute__((ext_vector_type(2)));  // one VGPR pair: v_pk_{fma,mul,add}_f32 operands
+
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+
+// The 4 scaled payoffs of one Philox block.  Box-Muller pair A = words (x, y), pair B = words
+// (z, w); values are kept as {A, B} register pairs so the uniform scaling, the radius scaling and
+// the exponent fma issue as packed-f32 instructions (2 results per 4-cycle issue slot):
+//   pc = cos-branch payoffs {A, B} = paths 4q+0, 4q+2;  ps = sin-branch {A, B} = paths 4q+1, 4q+3
+__device__ __forceinline__ void vanilla_unit_pk(const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)
 {
     const u32x4 r = philox4x32_10(c0, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi);
-    float bz[4];
-    box_muller_f32(r.x, r.y, o.radius2, bz[0], bz[1]);
-    box_muller_f32(r.z, r.w, o.radius2, bz[2], bz[3]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        p[j] = fmaxf(__builtin_amdgcn_exp2f(bz[j] + o.a2) - o.kappa, 0.0f);
+    const f2 scale = {0x1p-32f, 0x1p-32f}, half = {0x1p-33f, 0x1p-33f};
+    const f2 ua = __builtin_elementwise_fma((f2){(float)r.x, (float)r.z}, scale, half);  // radius uniforms
+    const f2 ub = __builtin_elementwise_fma((f2){(float)r.y, (float)r.w}, scale, half);  // angle uniforms
+    const f2 t = (f2){__builtin_amdgcn_logf(ua.x), __builtin_amdgcn_logf(ua.y)} * (f2){o.radius2, o.radius2};
+    const f2 rad = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+    const f2 c = {__builtin_amdgcn_cosf(ub.x), __builtin_amdgcn_cosf(ub.y)};
+    const f2 s = {__builtin_amdgcn_sinf(ub.x), __builtin_amdgcn_sinf(ub.y)};
+    const f2 a = {o.a2k, o.a2k};
+    const f2 yc = __builtin_elementwise_fma(c, rad, a);
+    const f2 ys = __builtin_elementwise_fma(s, rad, a);
+    pc.x = clamp01(__builtin_amdgcn_exp2f(yc.x) - o.kappa_k);
+    pc.y = clamp01(__builtin_amdgcn_exp2f(yc.y) - o.kappa_k);
+    ps.x = clamp01(__builtin_amdgcn_exp2f(ys.x) - o.kappa_k);
+    ps.y = clamp01(__builtin_amdgcn_exp2f(ys.y) - o.kappa_k);
+}
+
+// path order inside the unit: 4q+0 = cos A, 4q+1 = sin A, 4q+2 = cos B, 4q+3 = sin B
+__device__ __forceinline__ void vanilla_unit(const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
+{
+    f2 pc, ps;
+    vanilla_unit_pk(o, w, c0, pc, ps);
+    p[0] = pc.x;
+    p[1] = ps.x;
+    p[2] = pc.y;
+    p[3] = ps.y;
 }
 __device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w, uint32_t c0, double (&p)[2])
 {
@@ -74,9 +104,50 @@ __device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w,
         p[j] = fmax(o.spot * exp(o.drift + o.vol * z[j]) - o.strike, 0.0);
 }
 
-// Hot kernel: every unit is complete.  f32 payoffs are in units of S (scaled back by the
-// finishing kernel); each unit's 4 payoffs are added in fp32 and flushed to the lane's fp64
-// accumulators straight away (never a long fp32 running sum: SURVEY 2.3 #2).
+// Hot kernels: every unit is complete.
+//
+// f32: per-lane sums live in two packed-f32 pairs for FLUSH iterations (16 values per fp32
+// accumulator) and are then flushed to the lane's fp64 accumulators -- never a long fp32 running
+// sum.  The trip count is wave-uniform (scalar loop control); the one partial
+// trip at the end is peeled.
+constexpr uint32_t VANILLA_F32_FLUSH = 8;
+
+__global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, const Work w,
+                                                            double2 *__restrict__ partials)
+{
+    const uint32_t stride = gridDim.x * GROUP;
+    const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
+    const uint32_t full_trips = w.n_units / stride;
+    double acc_s = 0.0, acc_q = 0.0;
+    f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
+    uint32_t c0 = w.unit_lo + gtid;
+    for (uint32_t trip = 0; trip < full_trips; ++trip, c0 += stride) {
+        f2 pc, ps;
+        vanilla_unit_pk(o, w, c0, pc, ps);
+        s2 += pc;
+        s2 += ps;
+        q2 = __builtin_elementwise_fma(pc, pc, q2);
+        q2 = __builtin_elementwise_fma(ps, ps, q2);
+        if ((trip & (VANILLA_F32_FLUSH - 1)) == VANILLA_F32_FLUSH - 1) {
+            acc_s += (double)(s2.x + s2.y);
+            acc_q += (double)(q2.x + q2.y);
+            s2 = (f2){0.0f, 0.0f};
+            q2 = (f2){0.0f, 0.0f};
+        }
+    }
+    if (full_trips * stride + gtid < w.n_units) {  // the partial last trip
+        f2 pc, ps;
+        vanilla_unit_pk(o, w, c0, pc, ps);
+        s2 += pc + ps;
+        q2 += pc * pc + ps * ps;
+    }
+    acc_s += (double)(s2.x + s2.y);
+    acc_q += (double)(q2.x + q2.y);
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
+// f64 (and the generic form): each unit's payoffs go straight into the fp64 accumulators.
 template <class Opt, class Real>
 __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work w, double2 *__restrict__ partials)
 {

@@ -133,6 +133,11 @@ def test_vanilla_shards_add_up_and_geometry_does_not_matter(mc, eng, X):
     """Size-independent properties at 1e8 paths: the union of 8 contiguous shards equals the whole
     range (what the multi-GPU path relies on), and the grid size only changes summation order."""
     total = 10 ** 8 + 3
+    # f64: only the order of fp64 additions changes.  f32: a lane adds 16 scaled payoffs in fp32 before
+    # each flush to fp64, and which 16 go together depends on the geometry; every such partial carries
+    # a relative rounding error <= 16 * 2^-24, independent and zero-mean over ~6e6 partials
+    # (expected ~1e-7 / sqrt(6e6) = 4e-11, measured 7e-11): bound 2e-9.
+    rel = 1e-12 if X == "f64" else 2e-9
     whole = eng.vanilla(VAN, total, SEED, 0, X)
     s = s2 = 0.0
     n = 0
@@ -141,10 +146,10 @@ def test_vanilla_shards_add_up_and_geometry_does_not_matter(mc, eng, X):
         e = eng.vanilla(VAN, cnt, SEED, first, X)
         s, s2, n = s + e.sum, s2 + e.sum2, n + e.n
     assert n == total
-    assert s == pytest.approx(whole.sum, rel=1e-12) and s2 == pytest.approx(whole.sum2, rel=1e-12)
+    assert s == pytest.approx(whole.sum, rel=rel) and s2 == pytest.approx(whole.sum2, rel=rel)
     with mc.Engine(0, blocks=311) as small:
         other = small.vanilla(VAN, total, SEED, 0, X)
-    assert other.sum == pytest.approx(whole.sum, rel=1e-12) and other.sum2 == pytest.approx(whole.sum2, rel=1e-12)
+    assert other.sum == pytest.approx(whole.sum, rel=rel) and other.sum2 == pytest.approx(whole.sum2, rel=rel)
     # bitwise reproducible for a fixed geometry
     again = eng.vanilla(VAN, total, SEED, 0, X)
     assert (again.sum, again.sum2) == (whole.sum, whole.sum2)
