@@ -111,6 +111,7 @@ def main():
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local)
+    grouped = dist.is_initialized()   # one process per GPU under torch.distributed.run (RCCL), also for N=1
     eng = mc.Engine(local)
     prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
     if callable(inputs):
@@ -127,7 +128,7 @@ def main():
     def step(i):
         first = (i * world + rank) * paths
         eng.launch(prod, X, struct, seed, first, paths, triples[i].data_ptr(), stream.cuda_stream)
-        if world > 1:
+        if grouped:
             w = dist.all_reduce(triples[i], op=dist.ReduceOp.SUM, async_op=True)
             if args.sync_allreduce:
                 w.wait()
@@ -141,7 +142,7 @@ def main():
         torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
@@ -158,7 +159,7 @@ def main():
     elapsed = time.perf_counter() - t0
     samples, kernel_ms_total = eng.profile_read()
     eng.profile(0)
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -203,7 +204,7 @@ def main():
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
     eng.close()

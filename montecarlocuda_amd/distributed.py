@@ -27,11 +27,13 @@ from .engine import Estimate, closing, shard_range
 def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     """Join the process group described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
 
-    Returns (rank, world, local_rank).  With WORLD_SIZE unset or 1 no group is created."""
+    Returns (rank, world, local_rank).  A group is created whenever a launcher set RANK (also for
+    a world of 1, so the collective plumbing is exercised on a one-GPU box); a plain
+    `python bench.py` creates none."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -55,7 +57,7 @@ def my_shard(total_paths: int, rank: Optional[int] = None, world: Optional[int] 
 
 def reduce_triple(triple: torch.Tensor, async_op: bool = False):
     """In-place SUM all-reduce of the {sum, sum2, n} tensor (float64[3]) across ranks."""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         return dist.all_reduce(triple, op=dist.ReduceOp.SUM, async_op=async_op)
     return None
 
