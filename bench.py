@@ -12,8 +12,9 @@ European vanilla call, 1 asset, 1e8 paths, fp32 simulation (fp64 accumulation), 
 
 Scaling is WEAK: every GPU simulates `paths` paths per step, rank g taking the contiguous global
 range [(step*N + g) * paths, +paths) of one Philox stream (no data-path collective besides the
-triple).  Steps are pipelined: the all-reduce of step i runs on RCCL's stream while the compute
-stream simulates step i+1; all of them are waited for inside the timed region.
+triple).  The triples of `--bucket` consecutive steps are all-reduced as ONE message (fewer, larger
+collectives: a 24-byte all-reduce is pure latency), asynchronously on RCCL's stream while the
+compute stream keeps simulating; every bucket is waited for inside the timed region.
 
 Reported besides the contract fields:
   roofline      dominant kernel (the simulation kernel) timed with HIP events on its launch stream
@@ -97,7 +98,8 @@ def main():
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
     ap.add_argument("--profile-every", type=int, default=8)
-    ap.add_argument("--sync-allreduce", action="store_true", help="wait for each step's all-reduce before the next launch")
+    ap.add_argument("--bucket", type=int, default=25,
+                    help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
 
     import torch
@@ -125,17 +127,24 @@ def main():
     triples = torch.zeros((K + W, 3), dtype=torch.float64, device="cuda")
     works = []
 
+    pending = [0, 0]   # [first step not yet all-reduced, one past the last launched step]
+
+    def flush_bucket():
+        # one RCCL all-reduce for the triples of steps [pending[0], pending[1]): the rows are
+        # contiguous, so a bucket is a single (bucket x 3) fp64 message, asynchronous to compute
+        if grouped and pending[1] > pending[0]:
+            works.append(dist.all_reduce(triples[pending[0]:pending[1]], op=dist.ReduceOp.SUM, async_op=True))
+        pending[0] = pending[1]
+
     def step(i):
         first = (i * world + rank) * paths
         eng.launch(prod, X, struct, seed, first, paths, triples[i].data_ptr(), stream.cuda_stream)
-        if grouped:
-            w = dist.all_reduce(triples[i], op=dist.ReduceOp.SUM, async_op=True)
-            if args.sync_allreduce:
-                w.wait()
-            else:
-                works.append(w)
+        pending[1] = i + 1
+        if pending[1] - pending[0] >= max(1, args.bucket):
+            flush_bucket()
 
     def drain():
+        flush_bucket()
         for w in works:
             w.wait()
         works.clear()
@@ -189,7 +198,7 @@ def main():
             "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": X, "data": "synthetic",
             "config": {"workload": desc, "paths_per_gpu_per_step": paths, "global_paths_per_step": units_per_step,
-                       "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triple",
+                       "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
                        "grid": f"{eng.blocks}x256"},
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),

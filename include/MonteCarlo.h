@@ -90,6 +90,17 @@ OptionValue dev_vanillaOpt(OptionData *opt, int numBlocks, int numThreads, int s
 OptionValue dev_basketOpt(MultiOptionData *option, int numBlocks, int numThreads, int sims);
 OptionValue dev_cvaEquityOption(CVA *cva, int numBlocks, int numThreads, int sims);
 
+/* Host entry points (reference MonteCarloHost.c:139,282,292,302,90,42,51; this repo:
+ * libmchost_f64/_f32, montecarlocuda_amd/csrc/host_path.c -- a many-core CPU twin of the GPU
+ * estimator on the same Philox stream, see that file's header). */
+mc_real host_bsCall(OptionData option);
+OptionValue host_vanillaOpt(OptionData option, int path);
+OptionValue host_basketOpt(MultiOptionData *option, int path);
+OptionValue host_cvaEquityOption(CVA *cva, int path);
+void Chol(mc_real c[N][N], mc_real a[N][N]);
+void printOption(OptionData o);
+void printMultiOpt(MultiOptionData *o);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,282 @@
+/*
+ * host_path.c -- the reference's HOST entry points (libmchost_f64.so / libmchost_f32.so).
+ *
+ * Product code, plain C + OpenMP, built once per precision like legacy_abi.c.  It provides the
+ * symbols the reference drivers take from MonteCarloHost.c (SURVEY 8b "host side"):
+ *
+ *   host_bsCall  (MonteCarloHost.c:139)   Chol          (:90)
+ *   host_vanillaOpt (:282)  host_basketOpt (:292)  host_cvaEquityOption (:302)
+ *   printOption  (:42)   printMultiOpt (:51)
+ *
+ * a many-core CPU twin of the GPU engine, NOT a fallback of it (the dev_*
+ * entry points never call into this file) and NOT the oracle (tests check this file against
+ * the oracle like any other product code).  Differences from the reference CPU path, by design:
+ *   - same estimator as the GPU: the reference DEVICE formulas (MonteCarloKernel.cu:67-129,
+ *     241-262) on the engine's Philox4x32-10 stream, so for one seed the CPU and GPU results
+ *     agree path by path to rounding (the reference's CPU and GPU use unrelated streams, its dp
+ *     CPU basket drops the volatility, and its CPU CVA lags the exposure: SURVEY 2.3 #1,#7,#12);
+ *   - all host cores (OpenMP over fixed 65536-path chunks, chunk sums added in index order:
+ *     the result does not depend on the thread count); MC_HOST_THREADS caps the threads;
+ *   - sums in double for both precisions; seed = MC_SEED or MC_DEFAULT_SEED.
+ * host_bsCall and Chol keep the reference's arithmetic (Hastings CDF, zero-pivot rule).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "MonteCarlo.h"
+#include "mc_mi355x.h"
+
+#ifdef MC_SINGLE_PRECISION
+#define NPB 4
+#define R_EXP expf
+#define R_LOG logf
+#define R_SQRT sqrtf
+#else
+#define NPB 2
+#define R_EXP exp
+#define R_LOG log
+#define R_SQRT sqrt
+#endif
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ---- closed forms ----------------------------------------------------------------------- */
+static mc_real hastings_cdf(mc_real d)
+{
+    /* Abramowitz-Stegun 26.2.17, the constants of MonteCarloHost.c:125-130 */
+    static const double c[5] = {0.31938153, -0.356563782, 1.781477937, -1.821255978, 1.330274429};
+    const mc_real k = (mc_real)(1.0 / (1.0 + 0.2316419 * fabs((double)d)));
+    mc_real poly = (mc_real)c[4];
+    for (int i = 3; i >= 0; --i)
+        poly = (mc_real)c[i] + k * poly;
+    poly *= k;
+    const mc_real tail = (mc_real)0.39894228040143267793994605993438 * R_EXP((mc_real)(-0.5 * (double)d * (double)d)) * poly;
+    return d > 0 ? (mc_real)(1.0 - (double)tail) : tail;
+}
+
+static mc_real bs_call(mc_real s, mc_real k, mc_real r, mc_real v, mc_real t)
+{
+    const mc_real vol = v * R_SQRT(t);
+    const mc_real d1 = (mc_real)(((double)R_LOG(s / k) + ((double)r + 0.5 * (double)v * (double)v) * (double)t) / (double)vol);
+    const mc_real d2 = d1 - vol;
+    return s * hastings_cdf(d1) - k * R_EXP(-r * t) * hastings_cdf(d2);
+}
+
+mc_real host_bsCall(OptionData option) { return bs_call(option.s, option.k, option.r, option.v, option.t); }
+
+void Chol(mc_real c[N][N], mc_real a[N][N])
+{
+#ifdef MC_SINGLE_PRECISION
+    mc_chol_f32(N, &c[0][0], &a[0][0]);
+#else
+    mc_chol_f64(N, &c[0][0], &a[0][0]);
+#endif
+}
+
+/* ---- printers (same content as MonteCarloHost.c:42-65, own wording) ------------------------ */
+void printOption(OptionData o)
+{
+    printf("\n-\tOption data\t-\n\n");
+    printf("Underlying asset price:\t %.2f\nStrike price:\t\t %.2f\n", (double)o.s, (double)o.k);
+    printf("Risk free interest rate: %.2f %%\nVolatility:\t\t %.2f %%\n", (double)o.r * 100, (double)o.v * 100);
+    printf("Time to maturity:\t %.2f %s\n", (double)o.t, o.t > 1 ? "years" : "year");
+}
+
+void printMultiOpt(MultiOptionData *o)
+{
+    printf("\n-\tBasket Option data\t-\n\nNumber of assets: %d\n", N);
+    const mc_real *rows[3] = {o->s, o->v, o->w};
+    const char *names[3] = {"Underlying assets prices:", "Volatility:", "Weights:"};
+    for (int k = 0; k < 3; ++k) {
+        printf("%s\n!\t", names[k]);
+        for (int i = 0; i < N; ++i)
+            printf("\t%f\t", (double)rows[k][i]);
+        printf("\t!\n");
+    }
+    printf("Correlation matrix (Cholesky factor at call time):\n");
+    for (int i = 0; i < N; ++i) {
+        printf("!\t");
+        for (int j = 0; j < N; ++j)
+            printf("\t%f\t", (double)o->p[i][j]);
+        printf("\t!\n");
+    }
+    printf("Strike price:\t\t %.2f\nRisk free interest rate: %.2f\nTime to maturity:\t %.2f %s\n", (double)o->k,
+           (double)o->r, (double)o->t, o->t > 1 ? "years" : "year");
+}
+
+/* ---- the engine's random stream on the CPU ---------------------------- */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int round = 0; round < 10; ++round) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (uint32_t)p1, c3 = (uint32_t)p0, c0 = n0, c2 = n2;
+        k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+    }
+    out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, mc_real z[NPB])
+{
+    uint32_t x[4];
+    philox4x32_10((uint32_t)unit, (uint32_t)(unit >> 32), block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+#ifdef MC_SINGLE_PRECISION
+    for (int h = 0; h < 2; ++h) {
+        const float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f), ub = fmaf((float)x[2 * h + 1], 0x1p-32f, 0x1p-33f);
+        const float radius = sqrtf(-1.3862943611198906f * log2f(ua));
+        const double ang = 2.0 * M_PI * (double)ub;
+        z[2 * h] = radius * (float)cos(ang);
+        z[2 * h + 1] = radius * (float)sin(ang);
+    }
+#else
+    const double ua = ((double)(((uint64_t)x[1] << 20) | (x[0] >> 12)) + 0.5) * 0x1p-52;
+    const double ub = ((double)(((uint64_t)x[3] << 20) | (x[2] >> 12)) + 0.5) * 0x1p-52;
+    const double radius = sqrt(-2.0 * log(ua)), ang = 2.0 * M_PI * ub;
+    z[0] = radius * cos(ang);
+    z[1] = radius * sin(ang);
+#endif
+}
+
+static uint64_t seed_from_env(void)
+{
+    const char *s = getenv("MC_SEED");
+    return s ? strtoull(s, NULL, 0) : MC_DEFAULT_SEED;
+}
+
+/* ---- chunked, thread-count-independent accumulation ------------------------------------------ */
+#define CHUNK 65536ll
+typedef void (*chunk_fn)(const void *ctx, uint64_t seed, long long first, long long count, double out[2]);
+
+static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, double discount)
+{
+    OptionValue v = {0, 0};
+    if (paths < 2)
+        return v;
+    const long long n_chunks = (paths + CHUNK - 1) / CHUNK;
+    double *part = (double *)malloc(sizeof(double) * 2 * (size_t)n_chunks);
+    const uint64_t seed = seed_from_env();
+    const char *cap = getenv("MC_HOST_THREADS");
+    (void)cap;
+#ifdef _OPENMP
+    if (cap && atoi(cap) > 0)
+        omp_set_num_threads(atoi(cap));
+#endif
+#pragma omp parallel for schedule(dynamic, 4)
+    for (long long c = 0; c < n_chunks; ++c) {
+        const long long first = c * CHUNK, count = (first + CHUNK <= paths) ? CHUNK : paths - first;
+        fn(ctx, seed, first, count, part + 2 * c);
+    }
+    double sum = 0, sum2 = 0;
+    for (long long c = 0; c < n_chunks; ++c)
+        sum += part[2 * c], sum2 += part[2 * c + 1];
+    free(part);
+    double e, ci;
+    mc_closing(sum, sum2, (uint64_t)paths, discount, &e, &ci);
+    v.Expected = (mc_real)e;
+    v.Confidence = (mc_real)ci;
+    return v;
+}
+
+/* vanilla: MonteCarloKernel.cu:67-71 */
+static void vanilla_chunk(const void *ctx, uint64_t seed, long long first, long long count, double out[2])
+{
+    const OptionData *o = (const OptionData *)ctx;
+    const mc_real drift = (mc_real)(((double)o->r - 0.5 * (double)o->v * (double)o->v) * (double)o->t);
+    const mc_real vol = (mc_real)((double)o->v * sqrt((double)o->t));
+    double s = 0, s2 = 0;
+    mc_real z[NPB];
+    uint64_t have = (uint64_t)-1;
+    for (long long i = 0; i < count; ++i) {
+        const uint64_t p = (uint64_t)(first + i), unit = p / NPB;
+        if (unit != have)
+            block_normals(seed, MC_DOMAIN_VANILLA, unit, 0, z), have = unit;
+        const mc_real v = o->s * R_EXP(drift + vol * z[p % NPB]) - o->k;
+        const double pay = v > 0 ? (double)v : 0.0;
+        s += pay, s2 += pay * pay;
+    }
+    out[0] = s, out[1] = s2;
+}
+
+/* basket: MonteCarloKernel.cu:74-101 (lower triangle of the factor only) */
+static void basket_chunk(const void *ctx, uint64_t seed, long long first, long long count, double out[2])
+{
+    const MultiOptionData *o = (const MultiOptionData *)ctx;
+    const mc_real sqrt_t = (mc_real)sqrt((double)o->t);
+    enum { NBLK = (N + NPB - 1) / NPB };
+    mc_real g[NBLK * NPB];
+    double s = 0, s2 = 0;
+    for (long long i = 0; i < count; ++i) {
+        for (int b = 0; b < NBLK; ++b)
+            block_normals(seed, MC_DOMAIN_BASKET, (uint64_t)(first + i), (uint32_t)b, g + b * NPB);
+        mc_real basket = 0;
+        for (int a = 0; a < N; ++a) {
+            mc_real bt = 0;
+            for (int b = 0; b <= a; ++b)
+                bt += o->p[a][b] * g[b];
+            bt += o->d[a];
+            const mc_real mu = (mc_real)(((double)o->r - 0.5 * (double)o->v[a] * (double)o->v[a]) * (double)o->t);
+            basket += o->s[a] * R_EXP(mu + o->v[a] * bt * sqrt_t) * o->w[a];
+        }
+        const mc_real v = basket - o->k;
+        const double pay = v > 0 ? (double)v : 0.0;
+        s += pay, s2 += pay * pay;
+    }
+    out[0] = s, out[1] = s2;
+}
+
+/* CVA, device ordering: MonteCarloKernel.cu:241-262; product semantics of DESIGN.md 4.4 */
+static void cva_chunk(const void *ctx, uint64_t seed, long long first, long long count, double out[2])
+{
+    const CVA *c = (const CVA *)ctx;
+    const OptionData *o = &c->option;
+    const mc_real dt = o->t / c->n;
+    const mc_real step_drift = (mc_real)(((double)o->r - 0.5 * (double)o->v * (double)o->v) * (double)dt);
+    const mc_real step_vol = (mc_real)((double)o->v * sqrt((double)dt));
+    double s = 0, s2 = 0;
+    mc_real z[NPB];
+    for (long long i = 0; i < count; ++i) {
+        mc_real spot = o->s, ttm = o->t, acc = 0;
+        for (int j = 1; j <= c->n; ++j) {
+            const double t_prev = (double)dt * (j - 1), t_now = (double)dt * j;
+            const mc_real dpd = (mc_real)(-exp(-(double)c->defInt * t_prev) * expm1(-(double)c->defInt * (t_now - t_prev)));
+            mc_real ee = 0;
+            ttm -= dt;
+            if (ttm >= 0) {
+                const int idx = j - 1;
+                if (idx % NPB == 0)
+                    block_normals(seed, MC_DOMAIN_CVA, (uint64_t)(first + i), (uint32_t)(idx / NPB), z);
+                spot = spot * R_EXP(step_drift + step_vol * z[idx % NPB]);
+                if (ttm == 0)
+                    ee = spot > o->k ? spot - o->k : 0;
+                else
+                    ee = bs_call(spot, o->k, o->r, o->v, ttm);
+            }
+            acc += dpd * ee;
+        }
+        acc *= c->lgd;
+        s += (double)acc, s2 += (double)acc * (double)acc;
+    }
+    out[0] = s, out[1] = s2;
+}
+
+OptionValue host_vanillaOpt(OptionData option, int path)
+{
+    return simulate(vanilla_chunk, &option, path, exp(-(double)option.r * (double)option.t));
+}
+
+OptionValue host_basketOpt(MultiOptionData *option, int path)
+{
+    return simulate(basket_chunk, option, path, exp(-(double)option->r * (double)option->t));
+}
+
+OptionValue host_cvaEquityOption(CVA *cva, int path)
+{
+    return simulate(cva_chunk, cva, path, 1.0);
+}

@@ -1,0 +1,55 @@
+"""The plain-C drivers (drivers/*.c) end to end on a real MI355X: host code in C calls
+dev_* (libmcgpu) and host_* (libmchost); CPU and GPU legs share the Philox stream, so for the same
+paths they agree to rounding -- a stronger check than the reference's driver could print."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BS = 10.386270784322328
+
+
+def run(name, *args):
+    exe = os.path.join(ROOT, "drivers", name)
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe, *args], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    return out.stdout
+
+
+def floats_after(text, marker, count):
+    tail = text[text.index(marker) + len(marker):]
+    return [float(x) for x in re.findall(r"^-?\d+\.\d+", tail, flags=re.M)[:count]]
+
+
+@pytest.mark.parametrize("X,tol", [("f64", 1e-9), ("f32", 5e-5)])
+def test_vanilla_driver(X, tol):
+    out = run(f"vanillaOpt_{X}", "64")           # 64 x 131072 = 8.4e6 paths
+    assert "Black & Scholes price: 10.3862" in out
+    cpu = floats_after(out, "time [s]\n", 4)      # price, CI, |price-BS|, time
+    gpu = floats_after(out, "Speedup :\n", 5)[1:]  # (threads is an int line) price, CI, diff, time
+    price_gpu, ci_gpu, diff_gpu = gpu[0], gpu[1], gpu[2]
+    assert abs(price_gpu - BS) < 3.5 / 1.96 * ci_gpu + 1e-5
+    assert abs(diff_gpu - abs(price_gpu - 10.386262)) < 2e-5     # printed diff is vs the Hastings-CDF closed form
+    assert abs(cpu[0] - price_gpu) <= max(tol * price_gpu, 2e-6)  # same stream: CPU == GPU to rounding / print precision
+    assert abs(cpu[1] - ci_gpu) <= 2e-6
+
+
+def test_basket_driver_reference_data():
+    out = run("basketOpt_f64", "16")
+    assert "zero pivot" in out                   # the reference's N=3 correlation matrix is singular
+    cpu = floats_after(out, "Expected price, I.C., time [s]\n", 3)
+    gpu = floats_after(out, "Speedup :\n", 5)[1:]
+    assert abs(cpu[0] - gpu[0]) < 2e-6 and abs(cpu[1] - gpu[1]) < 2e-6
+    assert 4.5 < gpu[0] < 5.0                    # reference sp host at N=3: 4.76
+
+
+def test_cva_driver_all_grids():
+    out = run("cvaOpt_f64", "1", "--no-cpu")
+    assert out.count("--- exposure dates:") == 5
+    vals = [float(x) for x in re.findall(r"^(0\.1[89]\d+) $", out, flags=re.M)]
+    assert len(vals) >= 20 and all(0.17 < v < 0.21 for v in vals)

@@ -1,0 +1,119 @@
+"""libmchost_f64/_f32 (montecarlocuda_amd/csrc/host_path.c): the reference's HOST entry points as a
+many-core CPU twin of the GPU estimator.  Checked here without a GPU against the reference's own
+golden outputs (host_bsCall, Chol: bit for bit) and against the oracle's device-formula family on
+the same Philox stream (host_vanillaOpt / host_basketOpt / host_cvaEquityOption)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import fromhex, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "montecarlocuda_amd", "csrc")
+SEED = 0x4D435F4D49333535
+VAN = dict(s=100.0, k=100.0, r=0.048790, v=0.2, t=1.0)
+
+
+def load(po, X, n=3):
+    path = os.path.join(CSRC, f"libmchost_{X}.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", CSRC, "all"], stdout=subprocess.DEVNULL)
+    L = C.CDLL(path)
+    OptionData, MultiOptionData, OptionValue, CVA = po.ref_types(X, n)
+    R = po.CT[X]
+    L.host_bsCall.argtypes = [OptionData]
+    L.host_bsCall.restype = R
+    L.host_vanillaOpt.argtypes = [OptionData, C.c_int]
+    L.host_vanillaOpt.restype = OptionValue
+    L.host_basketOpt.argtypes = [C.POINTER(MultiOptionData), C.c_int]
+    L.host_basketOpt.restype = OptionValue
+    L.host_cvaEquityOption.argtypes = [C.POINTER(CVA), C.c_int]
+    L.host_cvaEquityOption.restype = OptionValue
+    L.Chol.argtypes = [C.POINTER((R * n) * n), C.POINTER((R * n) * n)]
+    return L, OptionData, MultiOptionData, OptionValue, CVA
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_bs_call_bitwise_vs_reference_golden(po, X):
+    L, OptionData, *_ = load(po, X)
+    n = 0
+    for c in load_golden("ref_bs_call.json")["cases"]:
+        if c["X"] != X:
+            continue
+        got = L.host_bsCall(OptionData(c["s"], c["k"], c["r"], c["v"], c["t"]))
+        assert float(got) == fromhex(c["out"]), c
+        n += 1
+    assert n > 250
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_chol_bitwise_vs_reference_golden(po, X):
+    L, *_ = load(po, X)
+    R = po.CT[X]
+    for c in load_golden("ref_chol.json")["cases"]:
+        if c["X"] != X or c["n"] != 3:
+            continue
+        cc, a = ((R * 3) * 3)(), ((R * 3) * 3)()
+        for i in range(3):
+            for j in range(3):
+                cc[i][j] = fromhex(c["c"][i][j])
+        L.Chol(C.byref(cc), C.byref(a))
+        assert [[float(a[i][j]) for j in range(3)] for i in range(3)] == [[fromhex(x) for x in row] for row in c["a"]]
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_host_monte_carlo_matches_oracle_on_the_engine_stream(po, X):
+    L, OptionData, MultiOptionData, OptionValue, CVA = load(po, X)
+    tol = 1e-12 if X == "f64" else 2e-6      # chunked fp64 summation order; f32 values round to float on return
+    n = 200001
+    v = L.host_vanillaOpt(OptionData(*[VAN[k] for k in "skrvt"]), n)
+    _, o = po.dev_vanilla(X, VAN, SEED, 0, n, want_paths=False)
+    assert float(v.Expected) == pytest.approx(o["expected"], rel=tol)
+    assert float(v.Confidence) == pytest.approx(o["confidence"], rel=tol)
+    # basket, the reference driver's N=3 data (singular correlation, zero-pivot factor)
+    Lf = po.chol(X, [[1, -.5, -.5], [-.5, 1, -.5], [-.5, -.5, 1]])
+    b = dict(s=[100.0] * 3, v=[0.2, 0.3, 0.2], p=Lf.tolist(), d=[0.0, 0.01, -0.01], w=[1 / 3] * 3, k=100.0, t=1.0, r=0.048790164)
+    m = MultiOptionData()
+    for i in range(3):
+        m.s[i], m.v[i], m.d[i], m.w[i] = b["s"][i], b["v"][i], b["d"][i], b["w"][i]
+        for j in range(3):
+            m.p[i][j] = b["p"][i][j]
+    m.k, m.t, m.r = b["k"], b["t"], b["r"]
+    v = L.host_basketOpt(C.byref(m), 70001)
+    _, o = po.dev_basket(X, b, SEED, 0, 70001, want_paths=False)
+    assert float(v.Expected) == pytest.approx(o["expected"], rel=tol)
+    assert float(v.Confidence) == pytest.approx(o["confidence"], rel=tol)
+    # CVA, device ordering; 250 dates ends with a negative residual maturity in f64, 256 with exactly 0
+    for n_grid in (25, 250, 256):
+        c = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6, n_grid=n_grid)
+        s = CVA(c["defint"], c["lgd"], 0, OptionData(*[c[k] for k in "skrvt"]), n_grid)
+        v = L.host_cvaEquityOption(C.byref(s), 3001)
+        _, o = po.dev_cva(X, c, SEED, 0, 3001, want_paths=False)
+        assert float(v.Expected) == pytest.approx(o["expected"], rel=tol)
+        assert float(v.Confidence) == pytest.approx(o["confidence"], rel=10 * tol)
+
+
+def test_result_does_not_depend_on_thread_count(po):
+    """Fixed 65536-path chunks added in index order: 1 thread and all threads give the same bits."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from oracle import pyoracle as po\n"
+            "OD = po.ref_types('f64', 3)[0]; OV = po.ref_types('f64', 3)[2]\n"
+            "L = C.CDLL(%r); L.host_vanillaOpt.argtypes=[OD, C.c_int]; L.host_vanillaOpt.restype = OV\n"
+            "v = L.host_vanillaOpt(OD(100, 100, 0.04879, 0.2, 1), 1000003); print(float(v.Expected).hex(), float(v.Confidence).hex())\n"
+            % (ROOT, os.path.join(CSRC, "libmchost_f64.so")))
+    outs = []
+    for threads in ("1", "3", "8"):
+        env = dict(os.environ, MC_HOST_THREADS=threads)
+        outs.append(subprocess.check_output([sys.executable, "-c", code], env=env).decode().strip())
+    assert outs[0] == outs[1] == outs[2], outs
+
+
+def test_drivers_build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")], stdout=subprocess.DEVNULL)
+    for b in ("vanillaOpt", "basketOpt", "cvaOpt"):
+        for X in ("f64", "f32"):
+            assert os.path.exists(os.path.join(ROOT, "drivers", f"{b}_{X}"))
