@@ -92,12 +92,13 @@ def cpu_baseline(prod, X, inputs, seconds):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="vanilla_f32")
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
     ap.add_argument("--profile-every", type=int, default=8)
+    ap.add_argument("--fp64-steps", type=int, default=100, help="steps of the fp64 side measurement (0 = skip)")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
@@ -173,6 +174,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # BASELINE.json's metric names both precisions: the same step in fp64, measured after (and
+    # outside) the headline region, reported as a side figure.
+    fp64_side = None
+    if args.workload == "vanilla_f32" and args.fp64_steps > 0:
+        s64, _ = eng.prepared("vanilla", "f64", VAN)
+        side = torch.zeros((args.fp64_steps + 5, 3), dtype=torch.float64, device="cuda")
+        for i in range(5):
+            eng.launch("vanilla", "f64", s64, seed, (i * world + rank) * paths, paths, side[i].data_ptr(), stream.cuda_stream)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(5, 5 + args.fp64_steps):
+            eng.launch("vanilla", "f64", s64, seed, (i * world + rank) * paths, paths, side[i].data_ptr(), stream.cuda_stream)
+        if grouped:
+            dist.all_reduce(side[5:], op=dist.ReduceOp.SUM)
+        barrier()
+        dt64 = time.perf_counter() - t1
+        tot64 = side[5:].sum(dim=0).cpu().tolist()
+        p64, ci64 = mc.closing(tot64[0], tot64[1], int(tot64[2]), math.exp(-VAN["r"] * VAN["t"]))
+        fp64_side = {"value": world * paths * args.fp64_steps / dt64, "unit": "paths/s", "steps": args.fp64_steps,
+                     "ms_per_step": dt64 / args.fp64_steps * 1e3, "price": p64, "confidence_95": ci64,
+                     "price_error_vs_black_scholes": abs(p64 - BS_EXACT),
+                     "workload": "same option and path count, fp64 simulation (vanilla_kernel<f64>)"}
+
     if rank == 0:
         tot = triples[W:].sum(dim=0).cpu().tolist()           # every step's triple is already all-reduced
         r, t_ = float(inputs["r"]), float(inputs["t"])
@@ -204,12 +228,14 @@ def main():
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
             "roofline": {"bound": "valu", "achieved": ach, "peak": PEAK_TFLOPS[X], "unit": "TFLOP/s",
                          "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,
-                         "kernel": f"mc::{prod}_kernel<{X}>", "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
+                         "kernel": "mc::vanilla_f32_kernel" if (prod, X) == ("vanilla", "f32") else f"mc::{prod}_kernel<{X}>", "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
                          "kernel_samples": samples, "flop_per_path": flop_per_path,
                          "kernel_paths_per_s": paths / kernel_s if kernel_s else None},
         }
         if prod == "vanilla":
             out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
+        if fp64_side:
+            out["fp64"] = fp64_side
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -5,6 +5,7 @@
 // Differences by design: buffers live in a persistent context instead of being
 // allocated per call; no RNG state; the cross-workgroup reduction runs on the device and the
 // host reads 24 bytes; every entry point returns a status instead of exit(1).
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -77,28 +78,38 @@ struct mc_context {
 
 static constexpr int PROFILE_RING = 512;
 
-// Brackets the simulation kernel(s) of one call with two events on the launch stream when this
-// call is one of the sampled ones; the finishing kernel stays outside the bracket.
+// Sampled calls time their (first) simulation kernel with the dispatch's own start/stop
+// timestamps: hipExtLaunchKernelGGL attaches the two events to that one kernel, so the figure is
+// the kernel's execution time as rocprofv3's kernel trace reports it (no launch latency, no
+// finishing kernel).  A call split into several segments reports its first segment.
 struct ProfileScope {
     mc_context *c;
-    hipStream_t st;
     int slot = -1;
-    ProfileScope(mc_context *ctx, hipStream_t s) : c(ctx), st(s)
+    bool used = false;
+    explicit ProfileScope(mc_context *ctx) : c(ctx)
     {
         const uint64_t id = c->launches++;
-        if (c->profile_every > 0 && id % (uint64_t)c->profile_every == 0 && c->prof_used < PROFILE_RING) {
+        if (c->profile_every > 0 && id % (uint64_t)c->profile_every == 0 && c->prof_used < PROFILE_RING)
             slot = c->prof_used++;
-            (void)hipEventRecord(c->prof_start[slot], st);
-        }
     }
-    void stop()
+    ~ProfileScope()
     {
-        if (slot >= 0)
-            (void)hipEventRecord(c->prof_stop[slot], st);
-        slot = -1;
+        if (slot >= 0 && !used && slot == c->prof_used - 1)
+            c->prof_used--;  // nothing was launched under this sample: give the slot back
     }
-    ~ProfileScope() { stop(); }
 };
+
+template <class... KArgs, class... Args>
+static void launch_sim(ProfileScope &prof, void (*kernel)(KArgs...), int grid, hipStream_t st, Args... args)
+{
+    if (prof.slot >= 0 && !prof.used) {
+        prof.used = true;
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(GROUP), 0, st, prof.c->prof_start[prof.slot],
+                              prof.c->prof_stop[prof.slot], 0, args...);
+    } else {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(GROUP), 0, st, args...);
+    }
+}
 
 extern "C" int mc_device_count(void)
 {
@@ -303,9 +314,9 @@ template <class Real> struct VanillaTraits;
 template <> struct VanillaTraits<float> {
     using Opt = VanillaF32;
     using In = mc_option_f32;
-    static void launch_hot(const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
+    static void launch_hot(ProfileScope &prof, const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
     {
-        vanilla_f32_kernel<<<grid, GROUP, 0, st>>>(k, w, partials);
+        launch_sim(prof, vanilla_f32_kernel, grid, st, k, w, partials);
     }
     static int prepare(const In &o, Opt &k_, double &scale1, double &scale2)
     {
@@ -333,9 +344,9 @@ template <> struct VanillaTraits<float> {
 template <> struct VanillaTraits<double> {
     using Opt = VanillaF64;
     using In = mc_option_f64;
-    static void launch_hot(const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
+    static void launch_hot(ProfileScope &prof, const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
     {
-        vanilla_kernel<Opt, double><<<grid, GROUP, 0, st>>>(k, w, partials);
+        launch_sim(prof, vanilla_kernel<Opt, double>, grid, st, k, w, partials);
     }
     static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
     {
@@ -366,7 +377,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     const uint64_t end = first + n;
     int slot = 0;
     std::vector<Segment> segs;
-    ProfileScope prof(c, st);
+    ProfileScope prof(c);
     if (out) {
         const uint64_t u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
         if (int rc = plan_segments(u0, u1 - u0, segs)) return rc;
@@ -383,7 +394,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
             for (const Segment &s : segs) {
                 const Work w = make_work(seed, s, first, end);
                 const int g = grid_for(c, s.count);
-                T::launch_hot(k, w, c->partials + slot, g, st);
+                T::launch_hot(prof, k, w, c->partials + slot, g, st);
                 slot += g;
             }
         }
@@ -399,7 +410,6 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
             slot += 1;
         }
     }
-    prof.stop();
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale1, scale2, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;
@@ -415,7 +425,7 @@ template <class Real> static constexpr double exp_scale() { return 1.0; }
 template <> constexpr double exp_scale<float>() { return 1.4426950408889634074; }  // log2(e): E = 2^x
 
 template <class Real, int NA>
-static int basket_launch_n(mc_context *c, const typename BasketIn<Real>::type &o, uint64_t seed,
+static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
                            const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot)
 {
     BasketArgs<Real, NA> k;
@@ -433,7 +443,7 @@ static int basket_launch_n(mc_context *c, const typename BasketIn<Real>::type &o
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
-        basket_kernel<Real, NA><<<g, GROUP, 0, st>>>(k, w, c->partials + slot, out ? out + done : nullptr);
+        launch_sim(prof, basket_kernel<Real, NA>, g, st, k, w, c->partials + slot, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;
     }
@@ -454,15 +464,14 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;
     int slot = 0, rc = MC_OK;
-    ProfileScope prof(c, st);
+    ProfileScope prof(c);
     switch (o->n) {
-#define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, *o, seed, segs, st, out, slot); break;
+#define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, slot); break;
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
         MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
 #undef MC_CASE
     }
     if (rc) return rc;
-    prof.stop();
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;
@@ -568,15 +577,14 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     if (int rc = plan_segments(first, n, segs)) return rc;
     int slot = 0;
     uint64_t done = 0;
-    ProfileScope prof(c, st);
+    ProfileScope prof(c);
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
-        cva_kernel<Real><<<g, GROUP, 0, st>>>(args, w, c->partials + slot, out ? out + done : nullptr);
+        launch_sim(prof, cva_kernel<Real>, g, st, args, w, c->partials + slot, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;
     }
-    prof.stop();
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;
