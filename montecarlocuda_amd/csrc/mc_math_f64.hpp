@@ -1,0 +1,111 @@
+// mc_math_f64.hpp -- double-precision elementary functions cut to the Monte Carlo kernels' domains.
+//
+// Why not the library ones: on gfx950 every fp64 VALU instruction costs a 4-cycle issue slot and
+// the kernels are VALU-issue-bound, so instruction count is time.  The general
+// ocml routines pay for double-double intermediates and for arguments these kernels never see
+// (measured VALU instructions: log 98, sincospi 70, sqrt 22, 1/x 12).  The versions below assume
+// what the generator guarantees -- a uniform strictly inside (0,1), a positive finite radicand --
+// and stay within 1 ulp of the correctly rounded result (checked against glibc through the
+// oracle's normals: tests/test_gpu_parity.py, bound 2e-14 absolute on |z| < 8.3):
+//
+//   log_unit(u)        ~36 instructions   fdlibm's e_log scheme: u = 2^k (1+f), s = f/(2+f),
+//                                         7-term minimax in s^2 (max error 0.8 ulp)
+//   sqrt_pos(x)        ~9                 v_rsq_f64 + two coupled Newton steps (ocml's core, no rescaling)
+//   sincos_turns(u)    ~36                quadrant from rint(4u), Taylor to y^15 / y^16 on |y| <= 1/2
+//   recip_pos(d)       ~5                 v_rcp_f64 + two Newton steps
+// exp() stays ocml's: it is already 23 instructions of straight Horner.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mc {
+
+__device__ __forceinline__ double recip_pos(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// natural log of a positive normal double
+__device__ __forceinline__ double log_unit(double x)
+{
+    // x = 2^k * m with m in [sqrt(1/2), sqrt(2)): shift the exponent boundary by adding the
+    // distance between the bit patterns of 1.0 and sqrt(1/2) to the high word
+    const int hi = __double2hiint(x) + (0x3ff00000 - 0x3fe6a09e);
+    const int k = (hi >> 20) - 0x3ff;
+    const double m = __hiloint2double((hi & 0x000fffff) + 0x3fe6a09e, __double2loint(x));
+    const double f = m - 1.0;
+    // s = f / (2 + f), correctly rounded by one residual step
+    const double d = 2.0 + f;
+    const double r = recip_pos(d);
+    double s = f * r;
+    s = __builtin_fma(__builtin_fma(-s, d, f), r, s);
+    const double z = s * s, w = z * z;
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
+                                        3.999999999940941908e-01);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
+                                                         2.857142874366239149e-01),
+                                        6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    // k ln2_hi - ((hfsq - (s (hfsq + R) + k ln2_lo)) - f)
+    const double inner = __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10);
+    return __builtin_fma(dk, 6.93147180369123816490e-01, -((hfsq - inner) - f));
+}
+
+// sqrt of a positive normal double (no rescaling: the callers' radicands lie in (1e-16, 1e3))
+__device__ __forceinline__ double sqrt_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+// (sin, cos) of 2*pi*u for u in [0, 1]: quadrant q = rint(4u), y = 4u - q in [-1/2, 1/2]
+// (both exact), then sin(pi/2 y) and cos(pi/2 y) by Taylor polynomials (remainders 1.2e-17, 2.3e-18).
+__device__ __forceinline__ void sincos_turns(double u, double &sin_out, double &cos_out)
+{
+    const double t = 4.0 * u;
+    const double q = __builtin_rint(t);
+    const double y = t - q;
+    const double z = y * y;
+    double ps = __builtin_fma(z, -6.688035109811468e-10, 5.692172921967927e-08);
+    ps = __builtin_fma(z, ps, -3.598843235212085e-06);
+    ps = __builtin_fma(z, ps, 0.00016044118478735983);
+    ps = __builtin_fma(z, ps, -0.004681754135318688);
+    ps = __builtin_fma(z, ps, 0.07969262624616705);
+    ps = __builtin_fma(z, ps, -0.6459640975062463);
+    ps = __builtin_fma(z, ps, 1.5707963267948966);
+    const double sy = y * ps;
+    double pc = __builtin_fma(z, 6.565963114979473e-11, -6.386603083791852e-09);
+    pc = __builtin_fma(z, pc, 4.710874778818172e-07);
+    pc = __builtin_fma(z, pc, -2.5202042373060607e-05);
+    pc = __builtin_fma(z, pc, 0.0009192602748394266);
+    pc = __builtin_fma(z, pc, -0.02086348076335296);
+    pc = __builtin_fma(z, pc, 0.25366950790104803);
+    pc = __builtin_fma(z, pc, -1.2337005501361697);
+    const double cy = __builtin_fma(z, pc, 1.0);
+    // angle = (pi/2)(q + y):  q mod 4 = 0: (sy, cy)  1: (cy, -sy)  2: (-sy, -cy)  3: (-cy, sy)
+    const int qi = (int)q;
+    const bool odd = (qi & 1) != 0;
+    const double s0 = odd ? cy : sy;
+    const double c0 = odd ? sy : cy;
+    const uint32_t uq = (uint32_t)qi;
+    const uint32_t sin_flip = (uq & 2u) << 30;         // bit 31 set for q mod 4 in {2, 3}
+    const uint32_t cos_flip = ((uq + 1u) & 2u) << 30;  // bit 31 set for q mod 4 in {1, 2}
+    sin_out = __hiloint2double((int)((uint32_t)__double2hiint(s0) ^ sin_flip), __double2loint(s0));
+    cos_out = __hiloint2double((int)((uint32_t)__double2hiint(c0) ^ cos_flip), __double2loint(c0));
+}
+
+}  // namespace mc

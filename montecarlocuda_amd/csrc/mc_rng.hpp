@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "mc_math_f64.hpp"
+
 namespace mc {
 
 constexpr uint32_t PHILOX_M0 = 0xD2511F53u, PHILOX_M1 = 0xCD9E8D57u;
@@ -77,20 +79,22 @@ constexpr float NEG_2LN2_F32 = -1.3862943611198906f;
 
 // ---- f64 ---------------------------------------------------------------------------------
 // 52-bit uniform strictly inside (0,1): ((hi:lo >> 12) + 0.5) * 2^-52, exact in double.
+// Built from bits: [1,2) mantissa fill, then one exact add of -(1 - 2^-53)
+// (v_alignbit, v_lshrrev, v_or, v_add_f64 instead of two int->double conversions and two fmas).
 __device__ __forceinline__ double u01_f64(uint32_t lo, uint32_t hi)
 {
-    const double top = (double)hi;          // * 2^20 * 2^-52
-    const double bot = (double)(lo >> 12);  // * 2^-52
-    return __builtin_fma(top, 0x1p-32, __builtin_fma(bot, 0x1p-52, 0x1p-53));
+    const uint32_t mant_lo = __builtin_amdgcn_alignbit(hi, lo, 12);
+    const uint32_t mant_hi = (hi >> 12) | 0x3ff00000u;
+    return __hiloint2double((int)mant_hi, (int)mant_lo) + (-1.0 + 0x1p-53);
 }
 
 __device__ __forceinline__ void box_muller_f64(const u32x4 r, double &z_cos, double &z_sin)
 {
     const double ua = u01_f64(r.x, r.y);
     const double ub = u01_f64(r.z, r.w);
-    const double radius = sqrt(-2.0 * log(ua));
+    const double radius = sqrt_pos(-2.0 * log_unit(ua));
     double s, c;
-    sincospi(2.0 * ub, &s, &c);  // angle in half-turns: exact range reduction
+    sincos_turns(ub, s, c);  // angle 2*pi*ub, quadrant reduction exact
     z_cos = radius * c;
     z_sin = radius * s;
 }
