@@ -293,31 +293,51 @@ struct CvaArgs {
     Real lgd, strike;
 };
 
-// Hastings 26.2.17 tail: phi(d) * poly(1/(1+0.2316419|d|)); cnd = d > 0 ? 1 - tail : tail
-__device__ __forceinline__ float cnd_model(float d)
+// Black-Scholes exposure at one date, from the lane's state W and the date's table row.
+// Reference: device_bsCall + cnd, dp/MonteCarloKernel.cu:110-129.  With T(d) = phi(d) P(1/(1+c|d|))
+// (Hastings 26.2.17, same constants) cnd(d) = d > 0 ? 1 - T(d) : T(d), and the Black-Scholes
+// identity  S phi(d1) = K e^{-r tau} phi(d2)  lets ONE exponential serve both terms:
+//     A = S phi(d1) = C exp(ln S - d1^2 / 2)
+//     S cnd(d1) = d1 > 0 ? S - A P1 : A P1,      K e^{-r tau} cnd(d2) = d2 > 0 ? disc - A P2 : A P2
+// (the reference evaluates three exponentials per date here: :106,:118 twice,:128).
+// ln S is the value the spot's own exponential is taken of, so A costs one fma + one exponential.
+__device__ __forceinline__ float bs_exposure(float ln2_spot, float W, const CvaStep<float> &st)
 {
-    const float k = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2316419f, fabsf(d), 1.0f));
-    float poly = __builtin_fmaf(k, 1.330274429f, -1.821255978f);
-    poly = __builtin_fmaf(k, poly, 1.781477937f);
-    poly = __builtin_fmaf(k, poly, -0.356563782f);
-    poly = __builtin_fmaf(k, poly, 0.31938153f);
-    poly *= k;
-    // exp(-d^2/2) = 2^(-d^2 log2(e)/2)
-    const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(d * d * -0.72134752044448170f);
-    const float tail = pdf * poly;
-    return d > 0 ? 1.0f - tail : tail;
+    const float spot = __builtin_amdgcn_exp2f(ln2_spot);
+    // d1, d2 and everything downstream as one packed pair
+    const f2 d = __builtin_elementwise_fma((f2){W, W}, (f2){st.g, st.g}, (f2){st.e1, st.e2});
+    const float A = 0.3989422804014327f * __builtin_amdgcn_exp2f(__builtin_fmaf(d.x * -0.72134752044448170f, d.x, ln2_spot));
+    const f2 den = __builtin_elementwise_fma((f2){0.2316419f, 0.2316419f}, __builtin_elementwise_abs(d), (f2){1.0f, 1.0f});
+    const f2 k = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    f2 poly = __builtin_elementwise_fma(k, (f2){1.330274429f, 1.330274429f}, (f2){-1.821255978f, -1.821255978f});
+    poly = __builtin_elementwise_fma(k, poly, (f2){1.781477937f, 1.781477937f});
+    poly = __builtin_elementwise_fma(k, poly, (f2){-0.356563782f, -0.356563782f});
+    poly = __builtin_elementwise_fma(k, poly, (f2){0.31938153f, 0.31938153f});
+    const f2 t = poly * k * (f2){A, A};
+    const float a = d.x > 0 ? spot - t.x : t.x;
+    const float b = d.y > 0 ? st.disc - t.y : t.y;
+    return a - b;
 }
-__device__ __forceinline__ double cnd_model(double d)
+
+__device__ __forceinline__ double hastings_poly(double k)
 {
-    const double k = 1.0 / __builtin_fma(0.2316419, fabs(d), 1.0);
     double poly = __builtin_fma(k, 1.330274429, -1.821255978);
     poly = __builtin_fma(k, poly, 1.781477937);
     poly = __builtin_fma(k, poly, -0.356563782);
     poly = __builtin_fma(k, poly, 0.31938153);
-    poly *= k;
-    const double pdf = 0.39894228040143267793994605993438 * exp(-0.5 * d * d);
-    const double tail = pdf * poly;
-    return d > 0 ? 1.0 - tail : tail;
+    return poly * k;
+}
+
+__device__ __forceinline__ double bs_exposure(double ln_spot, double W, const CvaStep<double> &st)
+{
+    const double spot = exp(ln_spot);
+    const double d1 = __builtin_fma(W, st.g, st.e1), d2 = __builtin_fma(W, st.g, st.e2);
+    const double A = 0.39894228040143267793994605993438 * exp(__builtin_fma(-0.5 * d1, d1, ln_spot));
+    const double t1 = A * hastings_poly(recip_pos(__builtin_fma(0.2316419, fabs(d1), 1.0)));
+    const double t2 = A * hastings_poly(recip_pos(__builtin_fma(0.2316419, fabs(d2), 1.0)));
+    const double a = d1 > 0 ? spot - t1 : t1;
+    const double b = d2 > 0 ? st.disc - t2 : t2;
+    return a - b;
 }
 
 template <class Real>
@@ -335,14 +355,12 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
             if (j < n_dates) {
                 const CvaStep<Real> st = o.steps[j];
                 W += z[jj];
-                const Real spot = exp_model(fma_r(W, o.bx, st.xk));
+                const Real ln_spot = fma_r(W, o.bx, st.xk);  // natural log in f64, log2 in f32
                 Real ee;
                 if (j < o.n_bs) {
-                    const Real d1 = fma_r(W, st.g, st.e1);
-                    const Real d2 = fma_r(W, st.g, st.e2);
-                    ee = spot * cnd_model(d1) - st.disc * cnd_model(d2);
+                    ee = bs_exposure(ln_spot, W, st);
                 } else {
-                    const Real iv = spot - o.strike;
+                    const Real iv = exp_model(ln_spot) - o.strike;
                     ee = iv > 0 ? iv : 0;
                 }
                 acc = fma_r(st.dp, ee, acc);
