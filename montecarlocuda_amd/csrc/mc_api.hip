@@ -424,26 +424,65 @@ template <> struct BasketIn<double> { using type = mc_basket_f64; };
 template <class Real> static constexpr double exp_scale() { return 1.0; }
 template <> constexpr double exp_scale<float>() { return 1.4426950408889634074; }  // log2(e): E = 2^x
 
+// the kernel of each precision: f32 = two paths per lane in packed halves, f64 = one path per lane
+template <int NA>
+static void basket_launch_kernel(ProfileScope &prof, const BasketArgs<float, NA> &k, const Work &w, double2 *partials,
+                                 float *out, double scale, int grid, hipStream_t st)
+{
+    launch_sim(prof, basket_f32_kernel<NA>, grid, st, k, w, partials, out, (float)scale);
+}
+template <int NA>
+static void basket_launch_kernel(ProfileScope &prof, const BasketArgs<double, NA> &k, const Work &w, double2 *partials,
+                                 double *out, double, int grid, hipStream_t st)
+{
+    launch_sim(prof, basket_kernel<double, NA>, grid, st, k, w, partials, out);
+}
+
 template <class Real, int NA>
 static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
-                           const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot)
+                           const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot, double &scale)
 {
     BasketArgs<Real, NA> k;
+    constexpr bool is_f32 = sizeof(Real) == 4;
     const double sc = exp_scale<Real>();
     const double sqrt_t = std::sqrt((double)o.t);
+    double m[NA][NA], base[NA], coef[NA];
     for (int a = 0; a < NA; ++a) {
         const double va = (double)o.v[a];
         for (int b = 0; b <= a; ++b)
-            k.m[a * (a + 1) / 2 + b] = (Real)(va * sqrt_t * (double)o.p[a * NA + b] * sc);
-        k.base[a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
-        k.coef[a] = (Real)((double)o.w[a] * (double)o.s[a]);
+            m[a][b] = va * sqrt_t * (double)o.p[a * NA + b] * sc;
+        base[a] = (((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc;
+        coef[a] = (double)o.w[a] * (double)o.s[a];
     }
-    k.strike = o.k;
+    scale = 1.0;
+    if (is_f32) {
+        // |z| < 6.77 for every normal the f32 generator can produce: bound the basket and rescale by
+        // an exact power of two so that the device's [0,1] clamp is the payoff's max(.,0)
+        const double zmax = 6.77;
+        double bound = 0;
+        for (int a = 0; a < NA; ++a) {
+            double x = base[a];
+            for (int b = 0; b <= a; ++b)
+                x += std::fabs(m[a][b]) * zmax;
+            bound += std::fabs(coef[a]) * std::exp2(x);
+        }
+        const double kk = bound > 0 ? std::ceil(std::log2(bound)) : 0;
+        if (!(std::fabs(kk) < 100))
+            return fail(MC_ERR_INVALID, "basket f32: inputs out of the float range (scale 2^%g)", kk);
+        scale = std::ldexp(1.0, (int)kk);
+    }
+    for (int a = 0; a < NA; ++a) {
+        for (int b = 0; b <= a; ++b)
+            k.m[a * (a + 1) / 2 + b] = (Real)m[a][b];
+        k.base[a] = (Real)base[a];
+        k.coef[a] = (Real)(coef[a] / scale);
+    }
+    k.strike = (Real)((double)o.k / scale);
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
-        const int g = grid_for(c, s.count);
-        launch_sim(prof, basket_kernel<Real, NA>, g, st, k, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+        const int g = grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
+        basket_launch_kernel<NA>(prof, k, w, c->partials + slot, out ? out + done : (Real *)nullptr, scale, g, st);
         slot += g;
         done += s.count;
     }
@@ -464,15 +503,16 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;
     int slot = 0, rc = MC_OK;
+    double scale = 1.0;
     ProfileScope prof(c);
     switch (o->n) {
-#define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, slot); break;
+#define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, slot, scale); break;
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
         MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
 #undef MC_CASE
     }
     if (rc) return rc;
-    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
+    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale, scale * scale, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;
 }

@@ -268,6 +268,98 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA
     store_partial(partials, acc_s, acc_q);
 }
 
+// ---- f32 basket: TWO paths per lane, one in each half of a packed-f32 register pair ----------
+// Everything that is not Philox or a transcendental (uniform scaling, radius scaling, z = r*trig,
+// the whole triangular mat-vec, the weighted sum, the sums) issues as v_pk_*_f32: two paths per
+// 4-cycle slot.  The payoff's max(.,0) is the free [0,1] clamp of the subtract after an exact
+// power-of-two rescale (coef and strike carry 2^-k, k from the generator's |z| < 6.77 bound);
+// the finishing kernel scales the sums back.  Lane pairing: units i and i + stride of one trip.
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 bcast(float x) { return (f2){x, x}; }
+
+template <int NA>
+__device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, const Work &w, uint32_t cA, uint32_t cB)
+{
+    constexpr int NBLK = (NA + 3) / 4;
+    f2 g[NBLK * 4];
+    const f2 scale = bcast(0x1p-32f), half = bcast(0x1p-33f), neg2ln2 = bcast(NEG_2LN2_F32);
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        const u32x4 ra = philox4x32_10(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
+        const u32x4 rb = philox4x32_10(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
+        // Box-Muller pair X = words (x, y), pair Z = words (z, w); halves = {path A, path B}
+        const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
+        const f2 ax = pk_fma((f2){(float)ra.y, (float)rb.y}, scale, half);
+        const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
+        const f2 az = pk_fma((f2){(float)ra.w, (float)rb.w}, scale, half);
+        const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
+        const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
+        const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
+        const f2 rz = {__builtin_amdgcn_sqrtf(tz.x), __builtin_amdgcn_sqrtf(tz.y)};
+        g[4 * b + 0] = rx * (f2){__builtin_amdgcn_cosf(ax.x), __builtin_amdgcn_cosf(ax.y)};
+        g[4 * b + 1] = rx * (f2){__builtin_amdgcn_sinf(ax.x), __builtin_amdgcn_sinf(ax.y)};
+        g[4 * b + 2] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
+        g[4 * b + 3] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
+    }
+    f2 basket = {0.0f, 0.0f};
+#pragma unroll
+    for (int a = 0; a < NA; ++a) {
+        f2 x = bcast(o.base[a]);
+#pragma unroll
+        for (int b = 0; b <= a; ++b)
+            x = pk_fma(bcast(o.m[a * (a + 1) / 2 + b]), g[b], x);
+        basket = pk_fma(bcast(o.coef[a]), (f2){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}, basket);
+    }
+    return (f2){clamp01(basket.x - o.strike), clamp01(basket.y - o.strike)};
+}
+
+constexpr uint32_t BASKET_F32_FLUSH = 8;
+
+template <int NA>
+__global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<float, NA> o, const Work w,
+                                                           double2 *__restrict__ partials, float *__restrict__ out,
+                                                           float out_scale)
+{
+    const uint32_t stride = gridDim.x * GROUP;
+    const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
+    const uint32_t full_trips = w.n_units / (2 * stride);  // trips in which every lane has both units
+    double acc_s = 0.0, acc_q = 0.0;
+    f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
+    uint32_t i = gtid;
+    for (uint32_t trip = 0; trip < full_trips; ++trip, i += 2 * stride) {
+        const f2 p = basket_pair_f32<NA>(o, w, w.unit_lo + i, w.unit_lo + i + stride);
+        s2 += p;
+        q2 = pk_fma(p, p, q2);
+        if (out) {  // wave-uniform: per-path dump for the parity tests
+            out[i] = p.x * out_scale;
+            out[i + stride] = p.y * out_scale;
+        }
+        if ((trip & (BASKET_F32_FLUSH - 1)) == BASKET_F32_FLUSH - 1) {
+            acc_s += (double)(s2.x + s2.y);
+            acc_q += (double)(q2.x + q2.y);
+            s2 = (f2){0.0f, 0.0f};
+            q2 = (f2){0.0f, 0.0f};
+        }
+    }
+    if (i < w.n_units) {  // the partial last trip: unit i, and unit i + stride where it exists
+        const bool has_b = i + stride < w.n_units;
+        f2 p = basket_pair_f32<NA>(o, w, w.unit_lo + i, w.unit_lo + (has_b ? i + stride : i));
+        if (!has_b)
+            p.y = 0.0f;
+        s2 += p;
+        q2 = pk_fma(p, p, q2);
+        if (out) {
+            out[i] = p.x * out_scale;
+            if (has_b)
+                out[i + stride] = p.y * out_scale;
+        }
+    }
+    acc_s += (double)(s2.x + s2.y);
+    acc_q += (double)(q2.x + q2.y);
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
 // =========================================================================================
 // CVA of one call.  Reference device loop, dp/MonteCarloKernel.cu:241-262 (spot advanced
 // first, exposure = Black-Scholes value at the NEW spot and residual maturity :125-129, with

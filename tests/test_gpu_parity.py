@@ -205,7 +205,7 @@ def test_basket_c3_c4_full_size_properties(mc, eng, po):
     b4 = basket_inputs(mc, 4, "f32")
     whole = eng.basket(b4, 10 ** 8, SEED, 0, "f32")
     s = sum(eng.basket(b4, cnt, SEED, first, "f32").sum for first, cnt in (mc.shard_range(10 ** 8, r, 8) for r in range(8)))
-    assert s == pytest.approx(whole.sum, rel=1e-12)
+    assert s == pytest.approx(whole.sum, rel=2e-9)   # f32: which 16 payoffs share an fp32 partial depends on the split
     d4 = eng.basket(basket_inputs(mc, 4, "f64"), 10 ** 8, SEED + 9, 0, "f64")
     assert abs(whole.expected - d4.expected) < 4 / 1.96 * math.hypot(whole.confidence, d4.confidence)
     host4 = po.host_basket("f32", b4, 200000, 12345)   # reference CPU algorithm (sp formula), own stream
