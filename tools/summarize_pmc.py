@@ -20,7 +20,12 @@ w = sys.argv[1] if len(sys.argv) > 1 else "vanilla_f32"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 base = os.path.join(ROOT, "gpurun_out", f"pmc_{w}")
 acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
-for f in glob.glob(os.path.join(base, "*", "*", "*counter_collection.csv")):
+files = []
+for d in glob.glob(os.path.join(base, "*", "")):      # one directory per pass; keep its newest run only
+    runs = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
+    if runs:
+        files.append(runs[-1])
+for f in files:
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
         if "mc::" not in k:
