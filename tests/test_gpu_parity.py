@@ -328,3 +328,65 @@ def test_invalid_arguments_are_errors_not_crashes(mc, eng):
         eng.basket(dict(s=[1.0] * n, v=[.1] * n, p=np.eye(n).tolist(), d=[0.0] * n, w=[1 / n] * n, k=1.0, t=1.0, r=0.0), 10)
     with pytest.raises(mc.McError):
         mc.Engine(99)
+
+
+# ---- randomized inputs ----------------------------------------------------------------------------
+def _rand_inputs(seed):
+    rng = np.random.default_rng(seed)
+    van = dict(s=float(rng.uniform(5, 500)), k=0.0, r=float(rng.uniform(-0.01, 0.12)), v=float(rng.uniform(0.02, 0.9)),
+               t=float(rng.uniform(0.05, 5.0)))
+    van["k"] = van["s"] * float(rng.uniform(0.6, 1.5))
+    n = int(rng.integers(1, 17))
+    a = rng.standard_normal((n, n + 2))
+    corr = a @ a.T
+    d = np.sqrt(np.diag(corr))
+    corr = corr / d[:, None] / d[None, :]
+    w = rng.uniform(0.0, 1.0, n)
+    w /= w.sum()
+    bsk = dict(s=rng.uniform(20, 200, n).tolist(), v=rng.uniform(0.05, 0.6, n).tolist(), corr=corr, d=rng.uniform(-0.05, 0.05, n).tolist(),
+               w=w.tolist(), k=float(rng.uniform(60, 140)), t=float(rng.uniform(0.1, 3.0)), r=float(rng.uniform(0.0, 0.08)))
+    cva = dict(s=float(rng.uniform(50, 150)), k=float(rng.uniform(60, 140)), r=float(rng.uniform(0.0, 0.08)), v=float(rng.uniform(0.1, 0.6)),
+               t=float(rng.uniform(0.25, 3.0)), defint=float(rng.uniform(0.0, 0.2)), lgd=float(rng.uniform(0.1, 1.0)),
+               n_grid=int(rng.integers(1, 200)))
+    return van, bsk, cva
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("case", range(12))
+def test_random_inputs_match_oracle(mc, eng, po, X, case):
+    """Random market data, seeds and unaligned path ranges: per-path parity for all three products.
+    Tolerances scale with the size of the values in play (spot / basket level)."""
+    van, bsk, cva = _rand_inputs(1000 + case)
+    seed = 0xC0FFEE00 + case * 7919
+    first = (case * 1234567) % 1000003
+    # vanilla
+    n = 4001 + case
+    got = f64(eng.vanilla_paths(van, n, seed, first, X))
+    want, o = po.dev_vanilla(X, van, seed, first, n)
+    level = van["s"] * math.exp(abs(van["r"]) * van["t"] + 4.5 * van["v"] * math.sqrt(van["t"]))
+    assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * level * 2
+    e = eng.vanilla(van, n, seed, first, X)
+    assert e.sum == pytest.approx(o["sum"], rel=4 * TOL[X]["rel"], abs=TOL[X]["pay"] * level)
+    # basket (Cholesky by the engine's own mc_chol, compared with the oracle's below)
+    L, bad = mc.chol(bsk["corr"], X)
+    assert bad == 0 and (L == po.chol(X, bsk["corr"])).all()
+    b = dict(bsk, p=L.tolist())
+    got = f64(eng.basket_paths(b, 2001, seed, first, X))
+    want, o = po.dev_basket(X, b, seed, first, 2001)
+    level = sum(wi * si * math.exp(4.5 * vi * math.sqrt(b["t"])) for wi, si, vi in zip(b["w"], b["s"], b["v"]))
+    assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * level * 4
+    # CVA
+    got = f64(eng.cva_paths(cva, 1001, seed, first, X))
+    want, o = po.dev_cva(X, cva, seed, first, 1001)
+    scale = cva["lgd"] * cva["s"] / 100.0 * max(1.0, cva["defint"] * cva["t"] * 10)
+    assert np.abs(got - f64(want)).max() <= TOL[X]["cva"] * max(scale, 0.05) * 4
+
+
+def test_profile_hooks_report_kernel_time(eng):
+    eng.profile(2)
+    for i in range(6):
+        eng.vanilla(VAN, 10 ** 7, SEED, i * 10 ** 7, "f32")
+    samples, total_ms = eng.profile_read()
+    eng.profile(0)
+    assert samples == 3 and 0.003 < total_ms / samples < 0.2   # a 1e7-path launch takes ~10 us
+    assert eng.profile_read() == (0, 0.0)
