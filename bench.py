@@ -98,6 +98,9 @@ def main():
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
     ap.add_argument("--profile-every", type=int, default=8)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default). gloo = rehearsal of the multi-rank logic on a box with fewer "
+                         "GPUs than ranks: ranks share GPUs (LOCAL_RANK mod device count), triples are reduced on the host")
     ap.add_argument("--fp64-steps", type=int, default=100, help="steps of the fp64 side measurement (0 = skip)")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
@@ -110,9 +113,11 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    rank, world, local = D.init_from_env("nccl")
+    rank, world, local = D.init_from_env(args.backend)
     if world != args.gpus:
         sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     grouped = dist.is_initialized()   # one process per GPU under torch.distributed.run (RCCL), also for N=1
     eng = mc.Engine(local)
@@ -124,7 +129,12 @@ def main():
     K, W = args.steps, args.warmup
     struct, keep = eng.prepared(prod, X, inputs)
     seed = mc.MC_DEFAULT_SEED
-    stream = torch.cuda.current_stream()
+    # An explicit side stream: torch's default stream has the NULL handle, which the C ABI reads as
+    # "use the context's own stream" -- the launches would then not be ordered with torch's copies and
+    # RCCL's waits, which key on torch's CURRENT stream.  Make a real stream current for everything.
+    stream = torch.cuda.Stream(device=local)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     triples = torch.zeros((K + W, 3), dtype=torch.float64, device="cuda")
     works = []
 
@@ -134,7 +144,13 @@ def main():
         # one RCCL all-reduce for the triples of steps [pending[0], pending[1]): the rows are
         # contiguous, so a bucket is a single (bucket x 3) fp64 message, asynchronous to compute
         if grouped and pending[1] > pending[0]:
-            works.append(dist.all_reduce(triples[pending[0]:pending[1]], op=dist.ReduceOp.SUM, async_op=True))
+            rows = triples[pending[0]:pending[1]]
+            if args.backend == "nccl":
+                works.append(dist.all_reduce(rows, op=dist.ReduceOp.SUM, async_op=True))
+            else:   # rehearsal path: reduce on the host
+                host = rows.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                rows.copy_(host)
         pending[0] = pending[1]
 
     def step(i):
@@ -153,7 +169,7 @@ def main():
 
     def barrier():
         if grouped:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(W):
@@ -170,7 +186,7 @@ def main():
     samples, kernel_ms_total = eng.profile_read()
     eng.profile(0)
     if grouped:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -187,7 +203,12 @@ def main():
         for i in range(5, 5 + args.fp64_steps):
             eng.launch("vanilla", "f64", s64, seed, (i * world + rank) * paths, paths, side[i].data_ptr(), stream.cuda_stream)
         if grouped:
-            dist.all_reduce(side[5:], op=dist.ReduceOp.SUM)
+            if args.backend == "nccl":
+                dist.all_reduce(side[5:], op=dist.ReduceOp.SUM)
+            else:
+                host = side[5:].cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                side[5:].copy_(host)
         barrier()
         dt64 = time.perf_counter() - t1
         tot64 = side[5:].sum(dim=0).cpu().tolist()
@@ -240,7 +261,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if grouped:
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
     eng.close()
 
