@@ -12,7 +12,10 @@ European vanilla call, 1 asset, 1e8 paths, fp32 simulation (fp64 accumulation), 
 
 Scaling is WEAK: every GPU simulates `paths` paths per step, rank g taking the contiguous global
 range [(step*N + g) * paths, +paths) of one Philox stream (no data-path collective besides the
-triple).  The triples of `--bucket` consecutive steps are all-reduced as ONE message (fewer, larger
+triple).  Steps rotate over `--streams` (default 2) independent context/stream pairs so that one
+pricing call's launch gap and finishing kernel overlap the next call's simulation kernel -- fixed
+per-call costs (~11 us of a ~61 us step) are hidden, each call is still one full launch.
+The triples of `--bucket` consecutive steps are all-reduced as ONE message (fewer, larger
 collectives: a 24-byte all-reduce is pure latency), asynchronously on RCCL's stream while the
 compute stream keeps simulating; every bucket is waited for inside the timed region.
 
@@ -97,6 +100,9 @@ def main():
     ap.add_argument("--workload", default="vanilla_f32")
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent (context, HIP stream) pairs the steps rotate over; >1 lets consecutive pricing "
+                         "calls overlap each other's launch gaps and finishing kernels")
     ap.add_argument("--profile-every", type=int, default=8)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default). gloo = rehearsal of the multi-rank logic on a box with fewer "
@@ -120,7 +126,8 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     grouped = dist.is_initialized()   # one process per GPU under torch.distributed.run (RCCL), also for N=1
-    eng = mc.Engine(local)
+    engines = [mc.Engine(local) for _ in range(max(1, args.streams))]
+    eng = engines[0]
     prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
     if callable(inputs):
         inputs = inputs()
@@ -132,9 +139,11 @@ def main():
     # An explicit side stream: torch's default stream has the NULL handle, which the C ABI reads as
     # "use the context's own stream" -- the launches would then not be ordered with torch's copies and
     # RCCL's waits, which key on torch's CURRENT stream.  Make a real stream current for everything.
-    stream = torch.cuda.Stream(device=local)
+    streams = [torch.cuda.Stream(device=local) for _ in engines]
+    stream = streams[0]
     torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
+    assert all(s_.cuda_stream != 0 for s_ in streams)
+    structs = [e.prepared(prod, X, inputs) for e in engines]
     triples = torch.zeros((K + W, 3), dtype=torch.float64, device="cuda")
     works = []
 
@@ -143,6 +152,8 @@ def main():
     def flush_bucket():
         # one RCCL all-reduce for the triples of steps [pending[0], pending[1]): the rows are
         # contiguous, so a bucket is a single (bucket x 3) fp64 message, asynchronous to compute
+        for s_ in streams[1:]:
+            stream.wait_stream(s_)          # the bucket's triples come from every stream
         if grouped and pending[1] > pending[0]:
             rows = triples[pending[0]:pending[1]]
             if args.backend == "nccl":
@@ -155,7 +166,8 @@ def main():
 
     def step(i):
         first = (i * world + rank) * paths
-        eng.launch(prod, X, struct, seed, first, paths, triples[i].data_ptr(), stream.cuda_stream)
+        e = i % len(engines)
+        engines[e].launch(prod, X, structs[e][0], seed, first, paths, triples[i].data_ptr(), streams[e].cuda_stream)
         pending[1] = i + 1
         if pending[1] - pending[0] >= max(1, args.bucket):
             flush_bucket()
@@ -194,14 +206,21 @@ def main():
     # outside) the headline region, reported as a side figure.
     fp64_side = None
     if args.workload == "vanilla_f32" and args.fp64_steps > 0:
-        s64, _ = eng.prepared("vanilla", "f64", VAN)
+        s64 = [e.prepared("vanilla", "f64", VAN)[0] for e in engines]
         side = torch.zeros((args.fp64_steps + 5, 3), dtype=torch.float64, device="cuda")
+
+        def step64(i):
+            e = i % len(engines)
+            engines[e].launch("vanilla", "f64", s64[e], seed, (i * world + rank) * paths, paths, side[i].data_ptr(),
+                              streams[e].cuda_stream)
         for i in range(5):
-            eng.launch("vanilla", "f64", s64, seed, (i * world + rank) * paths, paths, side[i].data_ptr(), stream.cuda_stream)
+            step64(i)
         barrier()
         t1 = time.perf_counter()
         for i in range(5, 5 + args.fp64_steps):
-            eng.launch("vanilla", "f64", s64, seed, (i * world + rank) * paths, paths, side[i].data_ptr(), stream.cuda_stream)
+            step64(i)
+        for s_ in streams[1:]:
+            stream.wait_stream(s_)
         if grouped:
             if args.backend == "nccl":
                 dist.all_reduce(side[5:], op=dist.ReduceOp.SUM)
@@ -245,13 +264,17 @@ def main():
             "config": {"workload": desc, "paths_per_gpu_per_step": paths, "global_paths_per_step": units_per_step,
                        "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
-                       "grid": f"{eng.blocks}x256"},
+                       "grid": f"{eng.blocks}x256", "streams": len(engines)},
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
             "roofline": {"bound": "valu", "achieved": ach, "peak": PEAK_TFLOPS[X], "unit": "TFLOP/s",
                          "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,
                          "kernel": "mc::vanilla_f32_kernel" if (prod, X) == ("vanilla", "f32") else f"mc::{prod}_kernel<{X}>", "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
                          "kernel_samples": samples, "flop_per_path": flop_per_path,
-                         "kernel_paths_per_s": paths / kernel_s if kernel_s else None},
+                         "kernel_paths_per_s": paths / kernel_s if kernel_s else None,
+                         "concurrent_launches": len(engines), "step_period_us": elapsed / K * 1e6,
+                         "note": "with 2 streams consecutive launches overlap (a launch's tail and finishing kernel run "
+                                 "beside the next launch's head), so per-kernel durations exceed the step period"
+                                 if len(engines) > 1 else "one launch at a time"},
         }
         if prod == "vanilla":
             out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
@@ -263,7 +286,8 @@ def main():
     if grouped:
         barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e in engines:
+        e.close()
 
 
 if __name__ == "__main__":
