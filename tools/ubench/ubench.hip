@@ -164,6 +164,7 @@ K32_2(k_fmac_f32, "v_fmac_f32 %0, %1, %1")
 K32_2(k_min_f32, "v_min_f32 %0, %0, %1")
 K32_2(k_max_i32, "v_max_i32 %0, %0, %1")
 K32_2(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+K32_2(k_bitop3, "v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96")
 K32_2(k_xor3, "v_xor_b32 %0, %0, %1\n v_xor_b32 %0, %0, %1")
 K32_DEP(k_xor_dep, "v_xor_b32 %0, %0, %1")
 K32_DEP(k_add_dep, "v_add_f32 %0, %0, %1")
@@ -324,7 +325,7 @@ int main(int argc, char **argv)
         {"v_xor_b32(sgpr)", k_xor_sgpr}, {"v_add_f32(sgpr)", k_add_f32_sgpr}, {"v_sub_f32 clamp", k_sub_clamp},
         {"v_sub_f32", k_sub_f32}, {"v_and_b32", k_and_b32}, {"v_or_b32", k_or_b32}, {"v_lshlrev_b32", k_lshl_b32},
         {"v_lshrrev_b32", k_lshr_b32}, {"v_mov_b32", k_mov_b32}, {"v_fmac_f32", k_fmac_f32}, {"v_min_f32", k_min_f32},
-        {"v_max_i32", k_max_i32}, {"v_cndmask_b32", k_cndmask}, {"2x v_xor (pair)", k_xor3},
+        {"v_max_i32", k_max_i32}, {"v_cndmask_b32", k_cndmask}, {"v_bitop3_b32", k_bitop3}, {"2x v_xor (pair)", k_xor3},
         {"v_xor dep-chain", k_xor_dep}, {"v_add_f32 dep", k_add_dep}, {"v_fma_f32 dep", k_fma_dep},
         {"philox mix x3", k_philox_mix}, {"philox mix far x3", k_philox_mix_far}, {"v_xor 2 fresh src", k_xor_2src},
         {"v_fma 3 fresh src", k_fma_3src},
