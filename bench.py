@@ -100,6 +100,9 @@ def main():
     ap.add_argument("--workload", default="vanilla_f32")
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU simulates `paths` per step. strong: `paths` per step in total, "
+                         "rank g taking mc_shard_range(paths, g, N) of every step")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent (context, HIP stream) pairs the steps rotate over; >1 lets consecutive pricing "
                          "calls overlap each other's launch gaps and finishing kernels")
@@ -164,10 +167,17 @@ def main():
                 rows.copy_(host)
         pending[0] = pending[1]
 
+    if args.scaling == "strong":
+        shard_first, shard_count = mc.shard_range(paths, rank, world)   # this rank's slice of every step
+        step_total = paths
+    else:
+        shard_first, shard_count = rank * paths, paths
+        step_total = world * paths
+
     def step(i):
-        first = (i * world + rank) * paths
+        first = i * step_total + shard_first
         e = i % len(engines)
-        engines[e].launch(prod, X, structs[e][0], seed, first, paths, triples[i].data_ptr(), streams[e].cuda_stream)
+        engines[e].launch(prod, X, structs[e][0], seed, first, shard_count, triples[i].data_ptr(), streams[e].cuda_stream)
         pending[1] = i + 1
         if pending[1] - pending[0] >= max(1, args.bucket):
             flush_bucket()
@@ -211,7 +221,7 @@ def main():
 
         def step64(i):
             e = i % len(engines)
-            engines[e].launch("vanilla", "f64", s64[e], seed, (i * world + rank) * paths, paths, side[i].data_ptr(),
+            engines[e].launch("vanilla", "f64", s64[e], seed, i * step_total + shard_first, shard_count, side[i].data_ptr(),
                               streams[e].cuda_stream)
         for i in range(5):
             step64(i)
@@ -232,7 +242,7 @@ def main():
         dt64 = time.perf_counter() - t1
         tot64 = side[5:].sum(dim=0).cpu().tolist()
         p64, ci64 = mc.closing(tot64[0], tot64[1], int(tot64[2]), math.exp(-VAN["r"] * VAN["t"]))
-        fp64_side = {"value": world * paths * args.fp64_steps / dt64, "unit": "paths/s", "steps": args.fp64_steps,
+        fp64_side = {"value": step_total * args.fp64_steps / dt64, "unit": "paths/s", "steps": args.fp64_steps,
                      "ms_per_step": dt64 / args.fp64_steps * 1e3, "price": p64, "confidence_95": ci64,
                      "price_error_vs_black_scholes": abs(p64 - BS_EXACT),
                      "workload": "same option and path count, fp64 simulation (vanilla_kernel<f64>)"}
@@ -245,11 +255,11 @@ def main():
             r, t_ = float(np.float32(r)), float(np.float32(t_))
         disc = 1.0 if prod == "cva" else math.exp(-r * t_)
         price, ci = mc.closing(tot[0], tot[1], int(tot[2]), disc)
-        assert int(tot[2]) == K * world * paths, (tot[2], K * world * paths)
-        units_per_step = world * paths
+        assert int(tot[2]) == K * step_total, (tot[2], K * step_total)
+        units_per_step = step_total
         value = units_per_step * K / elapsed
         kernel_s = (kernel_ms_total / samples) * 1e-3 if samples else None
-        ach = flop_per_path * paths / kernel_s / 1e12 if kernel_s else None
+        ach = flop_per_path * shard_count / kernel_s / 1e12 if kernel_s else None
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -259,9 +269,9 @@ def main():
                 traffic = None
         out = {
             "metric": "Monte Carlo paths/sec", "value": value, "unit": "paths/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": X, "data": "synthetic",
-            "config": {"workload": desc, "paths_per_gpu_per_step": paths, "global_paths_per_step": units_per_step,
+            "config": {"workload": desc, "paths_per_gpu_per_step": shard_count, "global_paths_per_step": units_per_step,
                        "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
                        "grid": f"{eng.blocks}x256", "streams": len(engines)},
@@ -270,7 +280,7 @@ def main():
                          "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,
                          "kernel": "mc::vanilla_f32_kernel" if (prod, X) == ("vanilla", "f32") else f"mc::{prod}_kernel<{X}>", "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
                          "kernel_samples": samples, "flop_per_path": flop_per_path,
-                         "kernel_paths_per_s": paths / kernel_s if kernel_s else None,
+                         "kernel_paths_per_s": shard_count / kernel_s if kernel_s else None,
                          "concurrent_launches": len(engines), "step_period_us": elapsed / K * 1e6,
                          "note": "with 2 streams consecutive launches overlap (a launch's tail and finishing kernel run "
                                  "beside the next launch's head), so per-kernel durations exceed the step period"
