@@ -98,6 +98,13 @@ int mc_context_blocks(const mc_context *ctx);
 /* Name / CU count / clock of the context's device, for logs. */
 int mc_context_info(const mc_context *ctx, char *name, int name_len, int *compute_units, int *clock_mhz);
 
+/* Estimator switch (not in the reference, whose estimator is plain Monte Carlo).
+ * on != 0: antithetic variates -- the sample of path p is the mean of the payoff at its normals z
+ * and at -z; n_paths then counts such pairs, the triple and the confidence interval refer to the
+ * pair means.  Same random stream, same path indexing; about 1.2-1.9x the time per sample for a
+ * 2.7-4x smaller variance on the reference's three products. */
+int mc_context_set_antithetic(mc_context *ctx, int on);
+
 /* Sampled device timing of the simulation kernel (not the finishing kernel): every `every`-th
  * launch is bracketed by two HIP events on its launch stream (0 = off; at most 512 samples are
  * kept between reads).  Replaces the reference's cudaEvent pair around each launch

@@ -150,6 +150,10 @@ static uint64_t seed_from_env(void)
     return s ? strtoull(s, NULL, 0) : MC_DEFAULT_SEED;
 }
 
+/* MC_ANTITHETIC=1: the antithetic-variates estimator of the GPU engine (mc_context_set_antithetic):
+ * the sample of a path is the mean of its value at z and at -z.  Read once per call. */
+static int g_antithetic;
+
 /* ---- chunked, thread-count-independent accumulation ------------------------------------------ */
 #define CHUNK 65536ll
 typedef void (*chunk_fn)(const void *ctx, uint64_t seed, long long first, long long count, double out[2]);
@@ -162,6 +166,7 @@ static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, doubl
     const long long n_chunks = (paths + CHUNK - 1) / CHUNK;
     double *part = (double *)malloc(sizeof(double) * 2 * (size_t)n_chunks);
     const uint64_t seed = seed_from_env();
+    g_antithetic = getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC"));
     const char *cap = getenv("MC_HOST_THREADS");
     (void)cap;
 #ifdef _OPENMP
@@ -198,7 +203,12 @@ static void vanilla_chunk(const void *ctx, uint64_t seed, long long first, long 
         if (unit != have)
             block_normals(seed, MC_DOMAIN_VANILLA, unit, 0, z), have = unit;
         const mc_real v = o->s * R_EXP(drift + vol * z[p % NPB]) - o->k;
-        const double pay = v > 0 ? (double)v : 0.0;
+        mc_real payoff = v > 0 ? v : 0;
+        if (g_antithetic) {
+            const mc_real vm = o->s * R_EXP(drift - vol * z[p % NPB]) - o->k;
+            payoff = (mc_real)0.5 * (payoff + (vm > 0 ? vm : 0));
+        }
+        const double pay = (double)payoff;
         s += pay, s2 += pay * pay;
     }
     out[0] = s, out[1] = s2;
@@ -215,17 +225,23 @@ static void basket_chunk(const void *ctx, uint64_t seed, long long first, long l
     for (long long i = 0; i < count; ++i) {
         for (int b = 0; b < NBLK; ++b)
             block_normals(seed, MC_DOMAIN_BASKET, (uint64_t)(first + i), (uint32_t)b, g + b * NPB);
-        mc_real basket = 0;
-        for (int a = 0; a < N; ++a) {
-            mc_real bt = 0;
-            for (int b = 0; b <= a; ++b)
-                bt += o->p[a][b] * g[b];
-            bt += o->d[a];
-            const mc_real mu = (mc_real)(((double)o->r - 0.5 * (double)o->v[a] * (double)o->v[a]) * (double)o->t);
-            basket += o->s[a] * R_EXP(mu + o->v[a] * bt * sqrt_t) * o->w[a];
+        mc_real payoff = 0;
+        for (int sign = 1; sign >= (g_antithetic ? -1 : 1); sign -= 2) {
+            mc_real basket = 0;
+            for (int a = 0; a < N; ++a) {
+                mc_real bt = 0;
+                for (int b = 0; b <= a; ++b)
+                    bt += o->p[a][b] * ((mc_real)sign * g[b]);
+                bt += o->d[a];
+                const mc_real mu = (mc_real)(((double)o->r - 0.5 * (double)o->v[a] * (double)o->v[a]) * (double)o->t);
+                basket += o->s[a] * R_EXP(mu + o->v[a] * bt * sqrt_t) * o->w[a];
+            }
+            const mc_real v = basket - o->k;
+            payoff += v > 0 ? v : 0;
         }
-        const mc_real v = basket - o->k;
-        const double pay = v > 0 ? (double)v : 0.0;
+        if (g_antithetic)
+            payoff *= (mc_real)0.5;
+        const double pay = (double)payoff;
         s += pay, s2 += pay * pay;
     }
     out[0] = s, out[1] = s2;
@@ -242,7 +258,7 @@ static void cva_chunk(const void *ctx, uint64_t seed, long long first, long long
     double s = 0, s2 = 0;
     mc_real z[NPB];
     for (long long i = 0; i < count; ++i) {
-        mc_real spot = o->s, ttm = o->t, acc = 0;
+        mc_real spot = o->s, mirror = o->s, ttm = o->t, acc = 0;
         for (int j = 1; j <= c->n; ++j) {
             const double t_prev = (double)dt * (j - 1), t_now = (double)dt * j;
             const mc_real dpd = (mc_real)(-exp(-(double)c->defInt * t_prev) * expm1(-(double)c->defInt * (t_now - t_prev)));
@@ -253,10 +269,16 @@ static void cva_chunk(const void *ctx, uint64_t seed, long long first, long long
                 if (idx % NPB == 0)
                     block_normals(seed, MC_DOMAIN_CVA, (uint64_t)(first + i), (uint32_t)(idx / NPB), z);
                 spot = spot * R_EXP(step_drift + step_vol * z[idx % NPB]);
-                if (ttm == 0)
-                    ee = spot > o->k ? spot - o->k : 0;
-                else
-                    ee = bs_call(spot, o->k, o->r, o->v, ttm);
+                mirror = mirror * R_EXP(step_drift - step_vol * z[idx % NPB]);
+                for (int leg = 0; leg < (g_antithetic ? 2 : 1); ++leg) {
+                    const mc_real sx = leg ? mirror : spot;
+                    if (ttm == 0)
+                        ee += sx > o->k ? sx - o->k : 0;
+                    else
+                        ee += bs_call(sx, o->k, o->r, o->v, ttm);
+                }
+                if (g_antithetic)
+                    ee *= (mc_real)0.5;
             }
             acc += dpd * ee;
         }

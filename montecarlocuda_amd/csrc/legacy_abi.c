@@ -17,7 +17,8 @@
  * life of the process (the reference allocates, seeds and frees on every call, :296-363);
  * numThreads is accepted and ignored (it only shaped the reference's reduction, :163);
  * nothing is printed on success (set MC_VERBOSE=1 for one line per call).
- * Environment: MC_DEVICE (default 0), MC_SEED (default MC_DEFAULT_SEED), MC_VERBOSE.
+ * Environment: MC_DEVICE (default 0), MC_SEED (default MC_DEFAULT_SEED), MC_VERBOSE,
+ * MC_ANTITHETIC=1 (antithetic-variates estimator instead of the reference's plain one).
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -58,6 +59,8 @@ static mc_context *context(void)
         const char *dev = getenv("MC_DEVICE");
         if (mc_context_create(dev ? atoi(dev) : 0, 0, &g_ctx) != MC_OK)
             die("creating the device context");
+        if (getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC")))
+            mc_context_set_antithetic(g_ctx, 1);
         atexit(drop_context);
     }
     return g_ctx;

@@ -69,6 +69,7 @@ struct mc_context {
     std::vector<char> table_key;  // inputs the cached table was built from
     hipEvent_t table_copied = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool antithetic = false;      // estimator: plain (reference) or antithetic variates
     // sampled device timing of the simulation kernels (mc_context_profile)
     int profile_every = 0;
     uint64_t launches = 0;
@@ -187,6 +188,14 @@ extern "C" int mc_context_info(const mc_context *c, char *name, int name_len, in
         snprintf(name, (size_t)name_len, "%s", c->name);
     if (cus) *cus = c->compute_units;
     if (mhz) *mhz = c->clock_mhz;
+    return MC_OK;
+}
+
+extern "C" int mc_context_set_antithetic(mc_context *c, int on)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    c->antithetic = on != 0;
     return MC_OK;
 }
 
@@ -314,9 +323,13 @@ template <class Real> struct VanillaTraits;
 template <> struct VanillaTraits<float> {
     using Opt = VanillaF32;
     using In = mc_option_f32;
-    static void launch_hot(ProfileScope &prof, const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
+    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, double2 *partials, int grid,
+                           hipStream_t st)
     {
-        launch_sim(prof, vanilla_f32_kernel, grid, st, k, w, partials);
+        if (anti)
+            launch_sim(prof, vanilla_f32_kernel<true>, grid, st, k, w, partials);
+        else
+            launch_sim(prof, vanilla_f32_kernel<false>, grid, st, k, w, partials);
     }
     static int prepare(const In &o, Opt &k_, double &scale1, double &scale2)
     {
@@ -344,9 +357,13 @@ template <> struct VanillaTraits<float> {
 template <> struct VanillaTraits<double> {
     using Opt = VanillaF64;
     using In = mc_option_f64;
-    static void launch_hot(ProfileScope &prof, const Opt &k, const Work &w, double2 *partials, int grid, hipStream_t st)
+    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, double2 *partials, int grid,
+                           hipStream_t st)
     {
-        launch_sim(prof, vanilla_kernel<Opt, double>, grid, st, k, w, partials);
+        if (anti)
+            launch_sim(prof, vanilla_kernel<Opt, double, true>, grid, st, k, w, partials);
+        else
+            launch_sim(prof, vanilla_kernel<Opt, double, false>, grid, st, k, w, partials);
     }
     static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
     {
@@ -373,6 +390,12 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     double scale1, scale2;
     if (int rc = T::prepare(*opt, k, scale1, scale2))
         return rc;
+    const bool anti = c->antithetic;
+    if (anti && sizeof(Real) == 4) {  // f32 kernels hand back the SUM of the two mirrored payoffs
+        scale1 *= 0.5;
+        scale2 *= 0.25;
+    }
+    const auto masked = anti ? vanilla_masked_kernel<typename T::Opt, Real, true> : vanilla_masked_kernel<typename T::Opt, Real, false>;
     HIPCHK(hipSetDevice(c->device));
     const uint64_t end = first + n;
     int slot = 0;
@@ -384,7 +407,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         for (const Segment &s : segs) {
             const Work w = make_work(seed, s, first, end);
             const int g = grid_for(c, s.count);
-            vanilla_masked_kernel<typename T::Opt, Real><<<g, GROUP, 0, st>>>(k, w, c->partials + slot, out, (Real)scale1);
+            masked<<<g, GROUP, 0, st>>>(k, w, c->partials + slot, out, (Real)scale1);
             slot += g;
         }
     } else {
@@ -394,7 +417,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
             for (const Segment &s : segs) {
                 const Work w = make_work(seed, s, first, end);
                 const int g = grid_for(c, s.count);
-                T::launch_hot(prof, k, w, c->partials + slot, g, st);
+                T::launch_hot(prof, anti, k, w, c->partials + slot, g, st);
                 slot += g;
             }
         }
@@ -406,7 +429,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
             if (!(e == 0 ? has_head : has_tail))
                 continue;
             const Work w = make_work(seed, Segment{e == 0 ? head : tail, 1u}, first, end);
-            vanilla_masked_kernel<typename T::Opt, Real><<<1, GROUP, 0, st>>>(k, w, c->partials + slot, nullptr, (Real)1);
+            masked<<<1, GROUP, 0, st>>>(k, w, c->partials + slot, nullptr, (Real)1);
             slot += 1;
         }
     }
@@ -426,16 +449,22 @@ template <> constexpr double exp_scale<float>() { return 1.4426950408889634074; 
 
 // the kernel of each precision: f32 = two paths per lane in packed halves, f64 = one path per lane
 template <int NA>
-static void basket_launch_kernel(ProfileScope &prof, const BasketArgs<float, NA> &k, const Work &w, double2 *partials,
-                                 float *out, double scale, int grid, hipStream_t st)
+static void basket_launch_kernel(ProfileScope &prof, bool anti, const BasketArgs<float, NA> &k, const Work &w,
+                                 double2 *partials, float *out, double scale, int grid, hipStream_t st)
 {
-    launch_sim(prof, basket_f32_kernel<NA>, grid, st, k, w, partials, out, (float)scale);
+    if (anti)
+        launch_sim(prof, basket_f32_kernel<NA, true>, grid, st, k, w, partials, out, (float)scale);
+    else
+        launch_sim(prof, basket_f32_kernel<NA, false>, grid, st, k, w, partials, out, (float)scale);
 }
 template <int NA>
-static void basket_launch_kernel(ProfileScope &prof, const BasketArgs<double, NA> &k, const Work &w, double2 *partials,
-                                 double *out, double, int grid, hipStream_t st)
+static void basket_launch_kernel(ProfileScope &prof, bool anti, const BasketArgs<double, NA> &k, const Work &w,
+                                 double2 *partials, double *out, double, int grid, hipStream_t st)
 {
-    launch_sim(prof, basket_kernel<double, NA>, grid, st, k, w, partials, out);
+    if (anti)
+        launch_sim(prof, basket_kernel<double, NA, true>, grid, st, k, w, partials, out);
+    else
+        launch_sim(prof, basket_kernel<double, NA, false>, grid, st, k, w, partials, out);
 }
 
 template <class Real, int NA>
@@ -471,6 +500,7 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
             return fail(MC_ERR_INVALID, "basket f32: inputs out of the float range (scale 2^%g)", kk);
         scale = std::ldexp(1.0, (int)kk);
     }
+    const double out_scale = (is_f32 && c->antithetic) ? 0.5 * scale : scale;  // f32 anti: kernel returns the SUM
     for (int a = 0; a < NA; ++a) {
         for (int b = 0; b <= a; ++b)
             k.m[a * (a + 1) / 2 + b] = (Real)m[a][b];
@@ -482,10 +512,12 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
-        basket_launch_kernel<NA>(prof, k, w, c->partials + slot, out ? out + done : (Real *)nullptr, scale, g, st);
+        basket_launch_kernel<NA>(prof, c->antithetic, k, w, c->partials + slot, out ? out + done : (Real *)nullptr,
+                                 out_scale, g, st);
         slot += g;
         done += s.count;
     }
+    scale = out_scale;
     return MC_OK;
 }
 
@@ -621,7 +653,10 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
-        launch_sim(prof, cva_kernel<Real>, g, st, args, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+        if (c->antithetic)
+            launch_sim(prof, cva_kernel<Real, true>, g, st, args, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+        else
+            launch_sim(prof, cva_kernel<Real, false>, g, st, args, w, c->partials + slot, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;
     }

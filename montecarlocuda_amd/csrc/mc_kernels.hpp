@@ -66,6 +66,11 @@ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f),
 // (z, w); values are kept as {A, B} register pairs so the uniform scaling, the radius scaling and
 // the exponent fma issue as packed-f32 instructions (2 results per 4-cycle issue slot):
 //   pc = cos-branch payoffs {A, B} = paths 4q+0, 4q+2;  ps = sin-branch {A, B} = paths 4q+1, 4q+3
+//
+// ANTI = antithetic variates (not in the reference): every normal z also prices the
+// mirrored path -z; the sample is the mean of the two payoffs (here their sum: the 1/2 rides on the
+// finishing kernel's scale).  Costs one more fma + exponential + clamp-subtract per path.
+template <bool ANTI>
 __device__ __forceinline__ void vanilla_unit_pk(const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)
 {
     const u32x4 r = philox4x32_10(c0, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi);
@@ -83,25 +88,38 @@ __device__ __forceinline__ void vanilla_unit_pk(const VanillaF32 &o, const Work 
     pc.y = clamp01(__builtin_amdgcn_exp2f(yc.y) - o.kappa_k);
     ps.x = clamp01(__builtin_amdgcn_exp2f(ys.x) - o.kappa_k);
     ps.y = clamp01(__builtin_amdgcn_exp2f(ys.y) - o.kappa_k);
+    if (ANTI) {
+        const f2 mc_ = __builtin_elementwise_fma(-c, rad, a);
+        const f2 ms_ = __builtin_elementwise_fma(-s, rad, a);
+        pc.x += clamp01(__builtin_amdgcn_exp2f(mc_.x) - o.kappa_k);
+        pc.y += clamp01(__builtin_amdgcn_exp2f(mc_.y) - o.kappa_k);
+        ps.x += clamp01(__builtin_amdgcn_exp2f(ms_.x) - o.kappa_k);
+        ps.y += clamp01(__builtin_amdgcn_exp2f(ms_.y) - o.kappa_k);
+    }
 }
 
 // path order inside the unit: 4q+0 = cos A, 4q+1 = sin A, 4q+2 = cos B, 4q+3 = sin B
+template <bool ANTI>
 __device__ __forceinline__ void vanilla_unit(const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
 {
     f2 pc, ps;
-    vanilla_unit_pk(o, w, c0, pc, ps);
+    vanilla_unit_pk<ANTI>(o, w, c0, pc, ps);
     p[0] = pc.x;
     p[1] = ps.x;
     p[2] = pc.y;
     p[3] = ps.y;
 }
+template <bool ANTI>
 __device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w, uint32_t c0, double (&p)[2])
 {
     double z[2];
     block_normals(c0, w.unit_hi, 0u, 1u, w.seed_lo, w.seed_hi, z);
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < 2; ++j) {
         p[j] = fmax(o.spot * exp(o.drift + o.vol * z[j]) - o.strike, 0.0);
+        if (ANTI)
+            p[j] = 0.5 * (p[j] + fmax(o.spot * exp(o.drift - o.vol * z[j]) - o.strike, 0.0));
+    }
 }
 
 // Hot kernels: every unit is complete.
@@ -112,6 +130,7 @@ __device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w,
 // trip at the end is peeled.
 constexpr uint32_t VANILLA_F32_FLUSH = 8;
 
+template <bool ANTI>
 __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, const Work w,
                                                             double2 *__restrict__ partials)
 {
@@ -123,7 +142,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, 
     uint32_t c0 = w.unit_lo + gtid;
     for (uint32_t trip = 0; trip < full_trips; ++trip, c0 += stride) {
         f2 pc, ps;
-        vanilla_unit_pk(o, w, c0, pc, ps);
+        vanilla_unit_pk<ANTI>(o, w, c0, pc, ps);
         s2 += pc;
         s2 += ps;
         q2 = __builtin_elementwise_fma(pc, pc, q2);
@@ -137,7 +156,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, 
     }
     if (full_trips * stride + gtid < w.n_units) {  // the partial last trip
         f2 pc, ps;
-        vanilla_unit_pk(o, w, c0, pc, ps);
+        vanilla_unit_pk<ANTI>(o, w, c0, pc, ps);
         s2 += pc + ps;
         q2 += pc * pc + ps * ps;
     }
@@ -148,7 +167,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, 
 }
 
 // f64 (and the generic form): each unit's payoffs go straight into the fp64 accumulators.
-template <class Opt, class Real>
+template <class Opt, class Real, bool ANTI>
 __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work w, double2 *__restrict__ partials)
 {
     constexpr int NPB = npb<Real>::value;
@@ -157,7 +176,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work 
     double acc_s = 0.0, acc_q = 0.0;
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p[NPB];
-        vanilla_unit(o, w, w.unit_lo + i, p);
+        vanilla_unit<ANTI>(o, w, w.unit_lo + i, p);
         Real s = p[0], q = p[0] * p[0];
 #pragma unroll
         for (int j = 1; j < NPB; ++j) {
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work 
 // Masked kernel: honours the path window (partial first/last units) and optionally stores
 // every per-path payoff (currency units) to `out[p - first_path]`.  Used for range edges and
 // by the parity tests; never on the hot path.
-template <class Opt, class Real>
+template <class Opt, class Real, bool ANTI>
 __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Opt o, const Work w,
                                                                double2 *__restrict__ partials,
                                                                Real *__restrict__ out, Real out_scale)
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Opt o, cons
     double acc_s = 0.0, acc_q = 0.0;
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p[NPB];
-        vanilla_unit(o, w, w.unit_lo + i, p);
+        vanilla_unit<ANTI>(o, w, w.unit_lo + i, p);
         const uint64_t unit = ((uint64_t)w.unit_hi << 32) | (uint32_t)(w.unit_lo + i);
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
@@ -222,7 +241,7 @@ struct BasketArgs {
 __device__ __forceinline__ float exp_model(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ double exp_model(double x) { return exp(x); }
 
-template <class Real, int NA>
+template <class Real, int NA, bool ANTI>
 __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const Work &w, uint32_t c0)
 {
     constexpr int NPB = npb<Real>::value;
@@ -236,7 +255,7 @@ __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const
         for (int j = 0; j < NPB; ++j)
             g[b * NPB + j] = z[j];
     }
-    Real basket = 0;
+    Real basket = 0, mirror = 0;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         Real x = o.base[a];
@@ -244,12 +263,19 @@ __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const
         for (int b = 0; b <= a; ++b)
             x = fma_r(o.m[a * (a + 1) / 2 + b], g[b], x);
         basket = fma_r(o.coef[a], exp_model(x), basket);
+        if (ANTI)  // exponent of the mirrored path: base - m g = 2 base - x
+            mirror = fma_r(o.coef[a], exp_model(fma_r((Real)-1, x, 2 * o.base[a])), mirror);
     }
     const Real v = basket - o.strike;
-    return v > 0 ? v : 0;
+    Real pay = v > 0 ? v : 0;
+    if (ANTI) {
+        const Real vm = mirror - o.strike;
+        pay = (Real)0.5 * (pay + (vm > 0 ? vm : 0));
+    }
+    return pay;
 }
 
-template <class Real, int NA>
+template <class Real, int NA, bool ANTI>
 __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA> o, const Work w,
                                                        double2 *__restrict__ partials,
                                                        Real *__restrict__ out)
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
-        const Real p = basket_path<Real, NA>(o, w, w.unit_lo + i);
+        const Real p = basket_path<Real, NA, ANTI>(o, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests
@@ -277,7 +303,7 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 bcast(float x) { return (f2){x, x}; }
 
-template <int NA>
+template <int NA, bool ANTI>
 __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, const Work &w, uint32_t cA, uint32_t cB)
 {
     constexpr int NBLK = (NA + 3) / 4;
@@ -301,7 +327,7 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, co
         g[4 * b + 2] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
         g[4 * b + 3] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
     }
-    f2 basket = {0.0f, 0.0f};
+    f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f};
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         f2 x = bcast(o.base[a]);
@@ -309,13 +335,20 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, co
         for (int b = 0; b <= a; ++b)
             x = pk_fma(bcast(o.m[a * (a + 1) / 2 + b]), g[b], x);
         basket = pk_fma(bcast(o.coef[a]), (f2){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}, basket);
+        if (ANTI) {  // mirrored path: base - m g = 2 base - x
+            const f2 xm = pk_fma(bcast(-1.0f), x, bcast(2.0f * o.base[a]));
+            mirror = pk_fma(bcast(o.coef[a]), (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
+        }
     }
-    return (f2){clamp01(basket.x - o.strike), clamp01(basket.y - o.strike)};
+    f2 pay = {clamp01(basket.x - o.strike), clamp01(basket.y - o.strike)};
+    if (ANTI)  // sum of the two payoffs; the 1/2 rides on the finishing kernel's scale
+        pay += (f2){clamp01(mirror.x - o.strike), clamp01(mirror.y - o.strike)};
+    return pay;
 }
 
 constexpr uint32_t BASKET_F32_FLUSH = 8;
 
-template <int NA>
+template <int NA, bool ANTI>
 __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<float, NA> o, const Work w,
                                                            double2 *__restrict__ partials, float *__restrict__ out,
                                                            float out_scale)
@@ -327,7 +360,7 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
     f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
     uint32_t i = gtid;
     for (uint32_t trip = 0; trip < full_trips; ++trip, i += 2 * stride) {
-        const f2 p = basket_pair_f32<NA>(o, w, w.unit_lo + i, w.unit_lo + i + stride);
+        const f2 p = basket_pair_f32<NA, ANTI>(o, w, w.unit_lo + i, w.unit_lo + i + stride);
         s2 += p;
         q2 = pk_fma(p, p, q2);
         if (out) {  // wave-uniform: per-path dump for the parity tests
@@ -343,7 +376,7 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
     }
     if (i < w.n_units) {  // the partial last trip: unit i, and unit i + stride where it exists
         const bool has_b = i + stride < w.n_units;
-        f2 p = basket_pair_f32<NA>(o, w, w.unit_lo + i, w.unit_lo + (has_b ? i + stride : i));
+        f2 p = basket_pair_f32<NA, ANTI>(o, w, w.unit_lo + i, w.unit_lo + (has_b ? i + stride : i));
         if (!has_b)
             p.y = 0.0f;
         s2 += p;
@@ -432,7 +465,7 @@ __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const Cv
     return a - b;
 }
 
-template <class Real>
+template <class Real, bool ANTI>
 __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, uint32_t c0)
 {
     constexpr int NPB = npb<Real>::value;
@@ -448,21 +481,28 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
                 const CvaStep<Real> st = o.steps[j];
                 W += z[jj];
                 const Real ln_spot = fma_r(W, o.bx, st.xk);  // natural log in f64, log2 in f32
+                const Real ln_mirror = fma_r(-W, o.bx, st.xk);  // the path driven by -z (ANTI only)
                 Real ee;
                 if (j < o.n_bs) {
                     ee = bs_exposure(ln_spot, W, st);
+                    if (ANTI)
+                        ee += bs_exposure(ln_mirror, -W, st);
                 } else {
                     const Real iv = exp_model(ln_spot) - o.strike;
                     ee = iv > 0 ? iv : 0;
+                    if (ANTI) {
+                        const Real ivm = exp_model(ln_mirror) - o.strike;
+                        ee += ivm > 0 ? ivm : 0;
+                    }
                 }
                 acc = fma_r(st.dp, ee, acc);
             }
         }
     }
-    return acc * o.lgd;
+    return acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);
 }
 
-template <class Real>
+template <class Real, bool ANTI>
 __global__ __launch_bounds__(GROUP) void cva_kernel(const CvaArgs<Real> o, const Work w,
                                                     double2 *__restrict__ partials, Real *__restrict__ out)
 {
@@ -470,7 +510,7 @@ __global__ __launch_bounds__(GROUP) void cva_kernel(const CvaArgs<Real> o, const
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
-        const Real p = cva_path<Real>(o, w, w.unit_lo + i);
+        const Real p = cva_path<Real, ANTI>(o, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests

@@ -137,6 +137,10 @@ class Engine:
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value,
                 "blocks": self.blocks}
 
+    def set_antithetic(self, on: bool):
+        """Plain Monte Carlo (the reference's estimator) or antithetic variates (pair means)."""
+        check(lib().mc_context_set_antithetic(self._ctx, 1 if on else 0))
+
     def profile(self, every: int):
         """Sample the simulation kernel's device time on every `every`-th launch (0 = off)."""
         check(lib().mc_context_profile(self._ctx, every))

@@ -20,7 +20,9 @@
  *  orc_dev_*   : the reference DEVICE formulas (MonteCarloKernel.cu:67-129,222-262) evaluated
  *                on the product's counter-based Philox4x32-10 stream, path by path, in the
  *                stated precision with libm.  This is what the HIP kernels are compared
- *                against on identical counters -- "hop B".
+ *                against on identical counters -- "hop B".  `antithetic` != 0 selects the
+ *                antithetic-variates estimator (not in the reference): the
+ *                sample of path p is the mean of the values at its normals z and at -z.
  */
 #ifndef MC_ORACLE_H_
 #define MC_ORACLE_H_
@@ -72,15 +74,15 @@ void orc_closing(double sum, double sum2, long long n, double discount,
     void orc_dev_normals_##X(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block,      \
                              REAL *z);                                                           \
     void orc_dev_vanilla_##X(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,              \
-                             uint64_t first_path, uint64_t n_paths, REAL *payoffs,               \
-                             orc_result *out);                                                   \
+                             uint64_t first_path, uint64_t n_paths, int antithetic,              \
+                             REAL *payoffs, orc_result *out);                                    \
     void orc_dev_basket_##X(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,   \
                             const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,                \
-                            uint64_t first_path, uint64_t n_paths, REAL *payoffs,                \
-                            orc_result *out);                                                    \
+                            uint64_t first_path, uint64_t n_paths, int antithetic,               \
+                            REAL *payoffs, orc_result *out);                                     \
     void orc_dev_cva_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint, REAL lgd,          \
                          int n_grid, uint64_t seed, uint64_t first_path, uint64_t n_paths,       \
-                         REAL *values, orc_result *out);
+                         int antithetic, REAL *values, orc_result *out);
 
 ORC_DECL(f32, float)
 ORC_DECL(f64, double)

@@ -264,7 +264,7 @@ static void FN(dev_finish)(double sum, double sum2, uint64_t n, double discount,
  * Path p draws normal (p mod NPB) of Philox unit (p div NPB), block 0, domain VANILLA.
  * Per-path values in REAL, (sum, sum2) accumulated in fp64. */
 void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
-                         uint64_t first_path, uint64_t n_paths, REAL *payoffs, orc_result *out)
+                         uint64_t first_path, uint64_t n_paths, int antithetic, REAL *payoffs, orc_result *out)
 {
     const REAL drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)t);
     const REAL vol = (REAL)((double)v * sqrt((double)t));
@@ -280,6 +280,10 @@ void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
         }
         REAL value = s * EXP_R(drift + vol * z[p % ORC_NPB]) - k;
         REAL payoff = value > 0 ? value : 0;
+        if (antithetic) { /* sample = mean of the payoffs at z and -z */
+            REAL mirror = s * EXP_R(drift - vol * z[p % ORC_NPB]) - k;
+            payoff = (REAL)0.5 * (payoff + (mirror > 0 ? mirror : 0));
+        }
         if (payoffs)
             payoffs[i] = payoff;
         sum += (double)payoff;
@@ -296,7 +300,7 @@ void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
  * zero, which Chol guarantees (dp/MonteCarloHost.c:95). */
 void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
                         const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,
-                        uint64_t first_path, uint64_t n_paths, REAL *payoffs, orc_result *out)
+                        uint64_t first_path, uint64_t n_paths, int antithetic, REAL *payoffs, orc_result *out)
 {
     int nblk = (n + ORC_NPB - 1) / ORC_NPB;
     REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)(nblk * ORC_NPB));
@@ -306,18 +310,23 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
         uint64_t path = first_path + i;
         for (int b = 0; b < nblk; b++)
             FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
-        REAL basket = 0;
-        for (int a = 0; a < n; a++) {
-            REAL bt = 0;
-            for (int b = 0; b <= a; b++)
-                bt += p[a * n + b] * g[b];
-            bt += d[a];
-            REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
-            REAL sa = s[a] * EXP_R(mu + v[a] * bt * sqrt_t);
-            basket += sa * w[a];
+        REAL payoff = 0;
+        for (int sign = 1; sign >= (antithetic ? -1 : 1); sign -= 2) {
+            REAL basket = 0;
+            for (int a = 0; a < n; a++) {
+                REAL bt = 0;
+                for (int b = 0; b <= a; b++)
+                    bt += p[a * n + b] * ((REAL)sign * g[b]);
+                bt += d[a];
+                REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
+                REAL sa = s[a] * EXP_R(mu + v[a] * bt * sqrt_t);
+                basket += sa * w[a];
+            }
+            REAL value = basket - k;
+            payoff += value > 0 ? value : 0;
         }
-        REAL value = basket - k;
-        REAL payoff = value > 0 ? value : 0;
+        if (antithetic)
+            payoff *= (REAL)0.5;
         if (payoffs)
             payoffs[i] = payoff;
         sum += (double)payoff;
@@ -339,7 +348,7 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
  *   - step j uses normal (j-1): Philox unit = path, block = (j-1) div NPB, domain CVA;
  *   - result is LGD * sum_j dp_j ee_j, NOT discounted (dp/MonteCarloKernel.cu:259,466). */
 void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid,
-                     uint64_t seed, uint64_t first_path, uint64_t n_paths, REAL *values,
+                     uint64_t seed, uint64_t first_path, uint64_t n_paths, int antithetic, REAL *values,
                      orc_result *out)
 {
     const REAL dt = t0 / n_grid;
@@ -349,7 +358,7 @@ void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL
     REAL z[ORC_NPB];
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t path = first_path + i;
-        REAL spot = s0, ttm = t0, acc = 0;
+        REAL spot = s0, mirror = s0, ttm = t0, acc = 0;
         for (int j = 1; j <= n_grid; j++) {
             double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
             /* e^{-l a} - e^{-l b} = -e^{-l a} expm1(-l (b - a)) */
@@ -361,12 +370,19 @@ void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL
                 if (idx % ORC_NPB == 0)
                     FN(orc_dev_normals)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
                 spot = spot * EXP_R(step_drift + step_vol * z[idx % ORC_NPB]);
-                if (ttm == 0) {
-                    REAL iv = spot - k;
-                    ee = iv > 0 ? iv : 0;
-                } else {
-                    ee = FN(orc_bs_call)(spot, k, r, v, ttm);
+                mirror = mirror * EXP_R(step_drift - step_vol * z[idx % ORC_NPB]);
+                for (int leg = 0; leg < (antithetic ? 2 : 1); leg++) {
+                    REAL sx = leg ? mirror : spot, e1;
+                    if (ttm == 0) {
+                        REAL iv = sx - k;
+                        e1 = iv > 0 ? iv : 0;
+                    } else {
+                        e1 = FN(orc_bs_call)(sx, k, r, v, ttm);
+                    }
+                    ee += e1;
                 }
+                if (antithetic)
+                    ee *= (REAL)0.5;
             }
             acc += dpd * ee;
         }

@@ -80,10 +80,10 @@ def lib() -> C.CDLL:
                                          C.c_int, res]
         f("orc_host_cva").argtypes = [R] * 7 + [C.c_int, C.c_int, C.c_uint, res]
         f("orc_dev_normals").argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, RP]
-        f("orc_dev_vanilla").argtypes = [R] * 5 + [C.c_uint64, C.c_uint64, C.c_uint64, RP, res]
+        f("orc_dev_vanilla").argtypes = [R] * 5 + [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, RP, res]
         f("orc_dev_basket").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R, C.c_uint64,
-                                        C.c_uint64, C.c_uint64, RP, res]
-        f("orc_dev_cva").argtypes = [R] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, RP, res]
+                                        C.c_uint64, C.c_uint64, C.c_int, RP, res]
+        f("orc_dev_cva").argtypes = [R] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, RP, res]
         for nm in ("orc_host_vanilla", "orc_host_basket", "orc_host_cva", "orc_dev_normals",
                    "orc_dev_vanilla", "orc_dev_basket", "orc_dev_cva"):
             f(nm).restype = None
@@ -176,32 +176,32 @@ def dev_normals(X, seed, domain, unit, block):
     return out
 
 
-def dev_vanilla(X, opt, seed, first, n, want_paths=True):
+def dev_vanilla(X, opt, seed, first, n, want_paths=True, antithetic=False):
     out = np.zeros(n if want_paths else 0, dtype=NP[X])
     ptr = out.ctypes.data_as(C.POINTER(CT[X])) if want_paths else None
     r = OrcResult()
     getattr(lib(), f"orc_dev_vanilla_{X}")(opt["s"], opt["k"], opt["r"], opt["v"], opt["t"], seed,
-                                           first, n, ptr, C.byref(r))
+                                           first, n, int(antithetic), ptr, C.byref(r))
     return out, r.as_dict()
 
 
-def dev_basket(X, b, seed, first, n, want_paths=True):
+def dev_basket(X, b, seed, first, n, want_paths=True, antithetic=False):
     nn = len(b["s"])
     keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
     out = np.zeros(n if want_paths else 0, dtype=NP[X])
     ptr = out.ctypes.data_as(C.POINTER(CT[X])) if want_paths else None
     r = OrcResult()
     getattr(lib(), f"orc_dev_basket_{X}")(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], seed,
-                                          first, n, ptr, C.byref(r))
+                                          first, n, int(antithetic), ptr, C.byref(r))
     return out, r.as_dict()
 
 
-def dev_cva(X, c, seed, first, n, want_paths=True):
+def dev_cva(X, c, seed, first, n, want_paths=True, antithetic=False):
     out = np.zeros(n if want_paths else 0, dtype=NP[X])
     ptr = out.ctypes.data_as(C.POINTER(CT[X])) if want_paths else None
     r = OrcResult()
     getattr(lib(), f"orc_dev_cva_{X}")(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"],
-                                       c["lgd"], c["n_grid"], seed, first, n, ptr, C.byref(r))
+                                       c["lgd"], c["n_grid"], seed, first, n, int(antithetic), ptr, C.byref(r))
     return out, r.as_dict()
 
 

@@ -36,9 +36,9 @@ int main(void)
     printf("host cva %.6f\n", r.expected);
     /* oracle, engine stream (unaligned ranges, per-path output) */
     mc_real *buf = (mc_real *)malloc(sizeof(mc_real) * 1001);
-    ORC(orc_dev_vanilla)(100, 100, (mc_real)0.04879, (mc_real)0.2, 1, 99ull, 3, 1001, buf, &r);
-    ORC(orc_dev_basket)(N, s, v, &fac[0][0], d, w, 100, 1, (mc_real)0.05, 99ull, (1ull << 32) - 500, 1001, buf, &r);
-    ORC(orc_dev_cva)(100, 100, (mc_real)0.05, (mc_real)0.2, 1, (mc_real)0.03, (mc_real)0.6, 37, 99ull, 5, 301, buf, &r);
+    ORC(orc_dev_vanilla)(100, 100, (mc_real)0.04879, (mc_real)0.2, 1, 99ull, 3, 1001, 0, buf, &r);
+    ORC(orc_dev_basket)(N, s, v, &fac[0][0], d, w, 100, 1, (mc_real)0.05, 99ull, (1ull << 32) - 500, 1001, 1, buf, &r);
+    ORC(orc_dev_cva)(100, 100, (mc_real)0.05, (mc_real)0.2, 1, (mc_real)0.03, (mc_real)0.6, 37, 99ull, 5, 301, 1, buf, &r);
     printf("dev cva %.6f\n", r.expected);
     free(buf);
     /* product host path (OpenMP CPU twin + closed forms + printers) */

@@ -117,3 +117,23 @@ def test_drivers_build():
     for b in ("vanillaOpt", "basketOpt", "cvaOpt"):
         for X in ("f64", "f32"):
             assert os.path.exists(os.path.join(ROOT, "drivers", f"{b}_{X}"))
+
+
+def test_antithetic_cpu_twin_matches_oracle(po):
+    """MC_ANTITHETIC=1 switches the CPU twin to the antithetic estimator (as it does the legacy GPU symbols)."""
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
+            "from oracle import pyoracle as po\n"
+            "OD, MOD, OV, CVA = po.ref_types('f64', 3)\n"
+            "L = C.CDLL(%r); L.host_vanillaOpt.argtypes=[OD, C.c_int]; L.host_vanillaOpt.restype = OV\n"
+            "L.host_cvaEquityOption.argtypes=[C.POINTER(CVA), C.c_int]; L.host_cvaEquityOption.restype = OV\n"
+            "v = L.host_vanillaOpt(OD(100, 100, 0.04879, 0.2, 1), 100003)\n"
+            "c = CVA(0.03, 0.6, 0, OD(100, 100, 0.05, 0.2, 1), 25); w = L.host_cvaEquityOption(C.byref(c), 3001)\n"
+            "print(float(v.Expected).hex(), float(v.Confidence).hex(), float(w.Expected).hex(), float(w.Confidence).hex())\n"
+            % (ROOT, os.path.join(CSRC, "libmchost_f64.so")))
+    out = subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, MC_ANTITHETIC="1")).decode().split()
+    e, ci, ce, cci = (float.fromhex(x) for x in out)
+    _, o = po.dev_vanilla("f64", dict(VAN, r=0.04879), SEED, 0, 100003, want_paths=False, antithetic=True)
+    assert e == pytest.approx(o["expected"], rel=1e-12) and ci == pytest.approx(o["confidence"], rel=1e-12)
+    c = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6, n_grid=25)
+    _, o = po.dev_cva("f64", c, SEED, 0, 3001, want_paths=False, antithetic=True)
+    assert ce == pytest.approx(o["expected"], rel=1e-12) and cci == pytest.approx(o["confidence"], rel=1e-11)
