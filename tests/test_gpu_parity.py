@@ -434,3 +434,34 @@ def test_antithetic_estimator_matches_oracle_and_reduces_variance(mc, po, X):
         plain_cva = e.cva(cva, 10 ** 6, SEED, 0, X)
         assert abs(anti_cva.expected - cva_analytic(cva)) < 3.5 / 1.96 * anti_cva.confidence + 2e-6
         assert anti_cva.confidence < 0.5 * plain_cva.confidence
+
+
+def test_async_launches_are_graph_capturable(mc):
+    """The *_launch_* entry points do no allocation or synchronisation, so a caller may capture a batch
+    of pricing calls into a hipGraph (torch.cuda.CUDAGraph is only the capture plumbing here)."""
+    torch = pytest.importorskip("torch")
+    eng = mc.Engine(0)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        out = torch.zeros((6, 3), dtype=torch.float64, device="cuda")
+        prepared = [eng.prepared("vanilla", "f32", VAN)[0], eng.prepared("basket", "f64", basket_inputs(mc, 4, "f64")),
+                    eng.prepared("cva", "f64", dict(CVA0, n_grid=64))[0]]
+        calls = [("vanilla", "f32", prepared[0]), ("basket", "f64", prepared[1][0]), ("cva", "f64", prepared[2])]
+
+        def enqueue():
+            for i in range(6):
+                prod, X, struct = calls[i % 3]
+                eng.launch(prod, X, struct, SEED, i * 100003, 200001, out[i].data_ptr(), torch.cuda.current_stream().cuda_stream)
+        enqueue()
+        torch.cuda.synchronize()
+        eager = out.clone()
+        out.zero_()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            enqueue()
+        for _ in range(3):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert bool((out == eager).all())
+    eng.close()
