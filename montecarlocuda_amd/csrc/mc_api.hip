@@ -643,6 +643,9 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         }
         HIPCHK(hipEventRecord(c->table_copied, st));
         c->table_key = key;
+    } else if (hipEventQuery(c->table_copied) != hipSuccess) {
+        // cached table, but its upload may still be in flight on another stream: order this one behind it
+        HIPCHK(hipStreamWaitEvent(st, c->table_copied, 0));
     }
     args.steps = (const CvaStep<Real> *)c->d_table;
     std::vector<Segment> segs;
