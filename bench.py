@@ -139,9 +139,8 @@ def main():
     K, W = args.steps, args.warmup
     struct, keep = eng.prepared(prod, X, inputs)
     seed = mc.MC_DEFAULT_SEED
-    # An explicit side stream: torch's default stream has the NULL handle, which the C ABI reads as
-    # "use the context's own stream" -- the launches would then not be ordered with torch's copies and
-    # RCCL's waits, which key on torch's CURRENT stream.  Make a real stream current for everything.
+    # Explicit non-default streams, one per context; the first is made torch's CURRENT stream so that
+    # torch's copies and RCCL's waits are ordered behind the launches.
     streams = [torch.cuda.Stream(device=local) for _ in engines]
     stream = streams[0]
     torch.cuda.set_stream(stream)

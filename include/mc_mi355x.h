@@ -94,6 +94,8 @@ int mc_context_create(int device, int blocks, mc_context **out);
 /* Replaces dp/MonteCarloKernel.cu:344 MonteCarlo_closing. */
 void mc_context_destroy(mc_context *ctx);
 int mc_context_device(const mc_context *ctx);
+/* The non-blocking HIP stream the context owns (the synchronous *_run_* calls use it). */
+void *mc_context_stream(const mc_context *ctx);
 int mc_context_blocks(const mc_context *ctx);
 /* Name / CU count / clock of the context's device, for logs. */
 int mc_context_info(const mc_context *ctx, char *name, int name_len, int *compute_units, int *clock_mhz);
@@ -115,7 +117,8 @@ int mc_context_profile_read(mc_context *ctx, int *samples, double *total_ms);
 
 /* ---- asynchronous launches ------------------------------------------------------------
  * d_triple: DEVICE pointer to 3 doubles, overwritten with {sum, sum2, n}.
- * stream  : hipStream_t passed as void*; NULL = the context's own stream.
+ * stream  : hipStream_t passed as void*; NULL = the HIP null stream, as in any HIP API
+ *           (mc_context_stream(ctx) is the context's own non-blocking stream).
  * Replace the kernel launch + D2H + host block-sum of dp/MonteCarloKernel.cu:365-419
  * (vanilla :381, basket :394) and :433-465 (CVA :448). */
 int mc_vanilla_launch_f32(mc_context *ctx, const mc_option_f32 *opt, uint64_t seed,

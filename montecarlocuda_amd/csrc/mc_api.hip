@@ -68,6 +68,7 @@ struct mc_context {
     size_t table_bytes = 0;
     std::vector<char> table_key;  // inputs the cached table was built from
     hipEvent_t table_copied = nullptr;
+    hipStream_t table_stream = nullptr;  // stream the cached table was uploaded on
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool antithetic = false;      // estimator: plain (reference) or antithetic variates
     // sampled device timing of the simulation kernels (mc_context_profile)
@@ -179,6 +180,7 @@ extern "C" void mc_context_destroy(mc_context *c)
 }
 
 extern "C" int mc_context_device(const mc_context *c) { return c ? c->device : -1; }
+extern "C" void *mc_context_stream(const mc_context *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int mc_context_blocks(const mc_context *c) { return c ? c->blocks : 0; }
 extern "C" int mc_context_info(const mc_context *c, char *name, int name_len, int *cus, int *mhz)
 {
@@ -284,7 +286,8 @@ static int grid_for(const mc_context *c, uint32_t n_units)
     return (int)(need < (uint64_t)c->blocks ? (need ? need : 1) : c->blocks);
 }
 
-static hipStream_t pick_stream(mc_context *c, void *stream) { return stream ? (hipStream_t)stream : c->stream; }
+// NULL is the HIP null stream, as in every HIP API (the context's own stream: mc_context_stream)
+static hipStream_t pick_stream(mc_context *, void *stream) { return (hipStream_t)stream; }
 
 static int check_common(mc_context *c, const void *opt, uint64_t first, uint64_t n, const void *dst)
 {
@@ -642,9 +645,10 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
             HIPCHK(hipMemcpyAsync(c->d_table, c->h_table, bytes, hipMemcpyHostToDevice, st));
         }
         HIPCHK(hipEventRecord(c->table_copied, st));
+        c->table_stream = st;
         c->table_key = key;
-    } else if (hipEventQuery(c->table_copied) != hipSuccess) {
-        // cached table, but its upload may still be in flight on another stream: order this one behind it
+    } else if (st != c->table_stream) {
+        // cached table uploaded on another stream: order this stream behind that upload
         HIPCHK(hipStreamWaitEvent(st, c->table_copied, 0));
     }
     args.steps = (const CvaStep<Real> *)c->d_table;

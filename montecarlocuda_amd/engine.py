@@ -112,6 +112,7 @@ class Engine:
         check(lib().mc_context_create(device, blocks, C.byref(self._ctx)))
         self.device = device
         self.blocks = lib().mc_context_blocks(self._ctx)
+        self.stream = lib().mc_context_stream(self._ctx) or 0
 
     def close(self):
         if self._ctx:
@@ -169,7 +170,8 @@ class Engine:
 
     # ---- asynchronous launches (device triple, caller's stream) ------------------------
     def launch(self, prod, precision, struct, seed, first_path, n_paths, d_triple_ptr: int, stream: int = 0):
-        """Enqueue; d_triple_ptr = device address of 3 doubles, stream = hipStream_t handle (0 = context's)."""
+        """Enqueue; d_triple_ptr = device address of 3 doubles, stream = hipStream_t handle (0 = the HIP null
+        stream; ``self.stream`` is the context's own)."""
         check(getattr(lib(), f"mc_{prod}_launch_{precision}")(self._ctx, C.byref(struct), seed, first_path,
                                                                n_paths, C.c_void_p(d_triple_ptr),
                                                                C.c_void_p(stream)))
