@@ -1,0 +1,61 @@
+"""bench.py itself, on the GPU box: the JSON contract at N=1, and the multi-rank bookkeeping rehearsed
+with two ranks sharing the one GPU (gloo backend: triples reduced on the host; on an 8-GPU node the
+same code runs with RCCL).  Short runs -- this checks plumbing, not speed."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BS = 10.386270784322328
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+def _port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_contract_single_gpu():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "4", "--cpu-seconds", "0.5",
+                          "--fp64-steps", "5"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = _json_line(out.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 4 and d["unit"] == "paths/s" and d["dtype"] == "f32"
+    assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
+    assert d["paths_priced"] == 40 * 10 ** 8 and d["value"] > 1e11
+    assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and 0 < r["frac"] < 1
+    assert r["achieved"] == pytest.approx(15.5 * 1e8 / (r["avg_kernel_us"] * 1e-6) / 1e12, rel=1e-9)
+    c = d["cpu_baseline"]
+    assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 1e6
+    assert abs(d["fp64"]["price"] - BS) < 0.05
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_share_the_gpu(scaling):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling,
+           "--steps", "30", "--warmup", "3", "--cpu-seconds", "0", "--fp64-steps", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _json_line(out.stdout)
+    total = 30 * 10 ** 8 * (2 if scaling == "weak" else 1)
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["paths_priced"] == total
+    assert d["config"]["paths_per_gpu_per_step"] == (10 ** 8 if scaling == "weak" else 5 * 10 ** 7)
+    assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]      # every path counted exactly once across ranks
+    assert "cpu_baseline" not in d
