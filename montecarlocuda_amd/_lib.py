@@ -16,7 +16,8 @@ LEGACY = {"f64": os.path.join(CSRC, "libmcgpu_f64.so"), "f32": os.path.join(CSRC
 MC_OK = 0
 MC_DEFAULT_SEED = 0x4D435F4D49333535
 DOMAIN_VANILLA, DOMAIN_BASKET, DOMAIN_CVA = 1, 2, 3
-MAX_ASSETS = 16
+MAX_ASSETS = 16          # register-resident basket kernels
+MAX_ASSETS_GENERIC = 64  # LDS-staged generic kernel beyond that
 NPB = {"f32": 4, "f64": 2}
 CT = {"f32": C.c_float, "f64": C.c_double}
 

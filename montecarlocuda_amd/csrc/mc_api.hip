@@ -317,6 +317,36 @@ static int ensure_out(mc_context *c, size_t bytes)
 
 static constexpr uint64_t MAX_DUMP_PATHS = 1ull << 26;
 
+// The context's one per-call constant table (CVA per-date rows, or a generic basket's folded
+// constants): rebuilt and re-uploaded only when the inputs (the key) change.
+static int upload_table(mc_context *c, hipStream_t st, const std::vector<char> &key, const void *data, size_t bytes)
+{
+    if (key != c->table_key) {
+        if (bytes > c->table_bytes) {
+            HIPCHK(hipStreamSynchronize(st));
+            if (c->table_stream && c->table_stream != st) HIPCHK(hipStreamSynchronize(c->table_stream));
+            if (c->d_table) HIPCHK(hipFree(c->d_table));
+            if (c->h_table) HIPCHK(hipHostFree(c->h_table));
+            c->table_bytes = bytes < 4096 ? 4096 : bytes;
+            HIPCHK(hipMalloc(&c->d_table, c->table_bytes));
+            HIPCHK(hipHostMalloc(&c->h_table, c->table_bytes, hipHostMallocDefault));
+        } else {
+            HIPCHK(hipEventSynchronize(c->table_copied));  // previous upload has left the staging buffer
+        }
+        if (bytes) {
+            memcpy(c->h_table, data, bytes);
+            HIPCHK(hipMemcpyAsync(c->d_table, c->h_table, bytes, hipMemcpyHostToDevice, st));
+        }
+        HIPCHK(hipEventRecord(c->table_copied, st));
+        c->table_stream = st;
+        c->table_key = key;
+    } else if (st != c->table_stream) {
+        // cached table uploaded on another stream: order this stream behind that upload
+        HIPCHK(hipStreamWaitEvent(st, c->table_copied, 0));
+    }
+    return MC_OK;
+}
+
 // ---------------------------------------------------------------------------------------
 // vanilla
 // ---------------------------------------------------------------------------------------
@@ -524,12 +554,56 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     return MC_OK;
 }
 
+// Baskets beyond the compiled sizes: fold the constants exactly like basket_launch_n (no power-of-two
+// rescale: the generic kernel takes the plain max), park them in the context's table buffer and run
+// the LDS-staged kernel.
+template <class Real>
+static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
+                             const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot)
+{
+    const int n = o.n, n_tri = n * (n + 1) / 2;
+    const double sc = exp_scale<Real>();
+    const double sqrt_t = std::sqrt((double)o.t);
+    std::vector<Real> host((size_t)n_tri + 2 * n);
+    for (int a = 0; a < n; ++a) {
+        const double va = (double)o.v[a];
+        for (int b = 0; b <= a; ++b)
+            host[(size_t)a * (a + 1) / 2 + b] = (Real)(va * sqrt_t * (double)o.p[a * n + b] * sc);
+        host[(size_t)n_tri + a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
+        host[(size_t)n_tri + n + a] = (Real)((double)o.w[a] * (double)o.s[a]);
+    }
+    const size_t bytes = host.size() * sizeof(Real);
+    std::vector<char> key(bytes + 2);
+    memcpy(key.data(), host.data(), bytes);
+    key[bytes] = (char)sizeof(Real);
+    key[bytes + 1] = 'B';
+    if (int rc = upload_table(c, st, key, host.data(), bytes)) return rc;
+    BasketDyn<Real> k;
+    k.consts = (const Real *)c->d_table;
+    k.n = n;
+    k.strike = o.k;
+    constexpr int NPB = npb<Real>::value;
+    const size_t lds = (size_t)((n + NPB - 1) / NPB * NPB) * GROUP * sizeof(Real);
+    const auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
+    HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    uint64_t done = 0;
+    for (const Segment &s : segs) {
+        const Work w = make_work(seed, s, 0, 0);
+        const int g = grid_for(c, s.count);
+        hipLaunchKernelGGL(kernel, dim3(g), dim3(GROUP), lds, st, k, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+        slot += g;
+        done += s.count;
+    }
+    (void)prof;
+    return MC_OK;
+}
+
 template <class Real>
 static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o, uint64_t seed, uint64_t first,
                           uint64_t n, double *d_triple, hipStream_t st, Real *out)
 {
-    if (o->n < 1 || o->n > MC_MAX_ASSETS)
-        return fail(MC_ERR_UNSUPPORTED, "basket: n=%d outside the compiled range 1..%d", o->n, MC_MAX_ASSETS);
+    if (o->n < 1 || o->n > MC_MAX_ASSETS_GENERIC)
+        return fail(MC_ERR_UNSUPPORTED, "basket: n=%d outside the supported range 1..%d", o->n, MC_MAX_ASSETS_GENERIC);
     if (!o->s || !o->v || !o->p || !o->d || !o->w)
         return fail(MC_ERR_INVALID, "basket: NULL array");
     if (!(o->t >= 0) || !std::isfinite((double)o->r) || !std::isfinite((double)o->k))
@@ -545,6 +619,9 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
         MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
 #undef MC_CASE
+    default:
+        rc = basket_launch_dyn<Real>(c, prof, *o, seed, segs, st, out, slot);
+        break;
     }
     if (rc) return rc;
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale, scale * scale, (double)n, d_triple);
@@ -629,28 +706,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     static thread_local std::vector<CvaStep<Real>> tab;
     if (int rc = build_cva_table<Real>(*v, tab, args)) return rc;
     const size_t bytes = tab.size() * sizeof(CvaStep<Real>);
-    if (key != c->table_key) {
-        if (bytes > c->table_bytes) {
-            HIPCHK(hipStreamSynchronize(st));
-            if (c->d_table) HIPCHK(hipFree(c->d_table));
-            if (c->h_table) HIPCHK(hipHostFree(c->h_table));
-            c->table_bytes = bytes < 4096 ? 4096 : bytes;
-            HIPCHK(hipMalloc(&c->d_table, c->table_bytes));
-            HIPCHK(hipHostMalloc(&c->h_table, c->table_bytes, hipHostMallocDefault));
-        } else {
-            HIPCHK(hipEventSynchronize(c->table_copied));  // previous upload has left the staging buffer
-        }
-        if (bytes) {
-            memcpy(c->h_table, tab.data(), bytes);
-            HIPCHK(hipMemcpyAsync(c->d_table, c->h_table, bytes, hipMemcpyHostToDevice, st));
-        }
-        HIPCHK(hipEventRecord(c->table_copied, st));
-        c->table_stream = st;
-        c->table_key = key;
-    } else if (st != c->table_stream) {
-        // cached table uploaded on another stream: order this stream behind that upload
-        HIPCHK(hipStreamWaitEvent(st, c->table_copied, 0));
-    }
+    if (int rc = upload_table(c, st, key, tab.data(), bytes)) return rc;
     args.steps = (const CvaStep<Real> *)c->d_table;
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;

@@ -393,6 +393,64 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
     store_partial(partials, acc_s, acc_q);
 }
 
+// ---- generic basket: runtime asset count beyond the compiled sizes (17 .. MC_MAX_ASSETS_GENERIC) ----
+// The reference's N is any compile-time constant (MonteCarlo.h:16); sizes without a register-resident
+// specialisation run here.  A lane's normals live in its own column of a dynamic-LDS array
+// g[asset][lane] (consecutive lanes, consecutive addresses: conflict-free, and nobody else touches
+// the column, so no barrier); the folded constants m | base | coef sit in one device buffer and are
+// read with a wave-uniform index (scalar loads).  A fallback: correctness and the same stream /
+// estimator definitions as the specialised kernels, not their speed.
+template <class Real>
+struct BasketDyn {
+    const Real *consts;  // m packed lower-triangular rows (n(n+1)/2), then base[n], then coef[n]
+    int n;
+    Real strike;
+};
+
+template <class Real, bool ANTI>
+__global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real> o, const Work w,
+                                                           double2 *__restrict__ partials, Real *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
+    constexpr int NPB = npb<Real>::value;
+    const int n = o.n, nblk = (n + NPB - 1) / NPB, n_tri = n * (n + 1) / 2;
+    const Real *__restrict__ m = o.consts, *__restrict__ base = o.consts + n_tri, *__restrict__ coef = base + n;
+    const uint32_t stride = gridDim.x * GROUP;
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
+        for (int b = 0; b < nblk; ++b) {
+            Real z[NPB];
+            block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
+#pragma unroll
+            for (int j = 0; j < NPB; ++j)
+                g[(b * NPB + j) * GROUP] = z[j];
+        }
+        Real basket = 0, mirror = 0;
+        int idx = 0;
+        for (int a = 0; a < n; ++a) {
+            Real x = base[a];
+            for (int b = 0; b <= a; ++b)
+                x = fma_r(m[idx++], g[b * GROUP], x);
+            basket = fma_r(coef[a], exp_model(x), basket);
+            if (ANTI)
+                mirror = fma_r(coef[a], exp_model(fma_r((Real)-1, x, 2 * base[a])), mirror);
+        }
+        const Real v = basket - o.strike;
+        Real p = v > 0 ? v : 0;
+        if (ANTI) {
+            const Real vm = mirror - o.strike;
+            p = (Real)0.5 * (p + (vm > 0 ? vm : 0));
+        }
+        acc_s += (double)p;
+        acc_q = __builtin_fma((double)p, (double)p, acc_q);
+        if (out)
+            out[i] = p;
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
 // =========================================================================================
 // CVA of one call.  Reference device loop, dp/MonteCarloKernel.cu:241-262 (spot advanced
 // first, exposure = Black-Scholes value at the NEW spot and residual maturity :125-129, with

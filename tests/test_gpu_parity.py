@@ -323,8 +323,8 @@ def test_invalid_arguments_are_errors_not_crashes(mc, eng):
         eng.vanilla(dict(VAN, s=-1.0), 10)
     with pytest.raises(mc.McError):
         eng.cva(dict(CVA0, n_grid=0), 10)
-    n = 17
-    with pytest.raises(mc.McError, match="1..16"):
+    n = 65
+    with pytest.raises(mc.McError, match="1..64"):
         eng.basket(dict(s=[1.0] * n, v=[.1] * n, p=np.eye(n).tolist(), d=[0.0] * n, w=[1 / n] * n, k=1.0, t=1.0, r=0.0), 10)
     with pytest.raises(mc.McError):
         mc.Engine(99)
@@ -465,3 +465,34 @@ def test_async_launches_are_graph_capturable(mc):
             torch.cuda.synchronize()
             assert bool((out == eager).all())
     eng.close()
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("n_assets", [17, 24, 33, 64])
+def test_generic_basket_beyond_compiled_sizes(mc, eng, po, X, n_assets):
+    """n > 16 runs the LDS-staged generic kernel (the reference's N is any compile-time constant):
+    same stream, same estimator, same tolerances as the specialised kernels; also antithetic."""
+    b = basket_inputs(mc, n_assets, X, rho=0.3)
+    n, first = 3001, (1 << 32) - 1500          # straddles the 2^32 unit boundary: two segments
+    got = f64(eng.basket_paths(b, n, SEED, first, X))
+    want, o = po.dev_basket(X, b, SEED, first, n)
+    assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * 100.0 * 4
+    e = eng.basket(b, n, SEED, first, X)
+    assert e.sum == pytest.approx(o["sum"], rel=2 * TOL[X]["rel"]) and e.confidence == pytest.approx(o["confidence"], rel=4 * TOL[X]["rel"])
+    with mc.Engine(0) as anti:
+        anti.set_antithetic(True)
+        got = f64(anti.basket_paths(b, 1001, SEED, 3, X))
+        want, _ = po.dev_basket(X, b, SEED, 3, 1001, antithetic=True)
+        assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * 100.0 * 4
+
+
+def test_generic_basket_alternates_with_cva_on_one_context(eng, mc, po):
+    """The generic basket's constants and the CVA date table share the context's table buffer: calls of
+    both kinds interleaved must each see their own data."""
+    b = basket_inputs(mc, 20, "f64", rho=0.3)
+    c = dict(CVA0, n_grid=64)
+    _, ob = po.dev_basket("f64", b, SEED, 0, 2001)
+    _, oc = po.dev_cva("f64", c, SEED, 0, 2001)
+    for _ in range(3):
+        assert eng.basket(b, 2001, SEED, 0, "f64").sum == pytest.approx(ob["sum"], rel=1e-12)
+        assert eng.cva(c, 2001, SEED, 0, "f64").sum == pytest.approx(oc["sum"], rel=1e-12)
