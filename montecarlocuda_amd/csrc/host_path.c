@@ -153,6 +153,9 @@ static uint64_t seed_from_env(void)
 /* MC_ANTITHETIC=1: the antithetic-variates estimator of the GPU engine (mc_context_set_antithetic):
  * the sample of a path is the mean of its value at z and at -z.  Read once per call. */
 static int g_antithetic;
+/* MC_CONTROL_VARIATE=1 (host_basketOpt only): the geometric-basket control variate of the GPU engine
+ * (mc_context_set_control_variate); the closed-form mean is added back in host_basketOpt. */
+static int g_control;
 
 /* ---- chunked, thread-count-independent accumulation ------------------------------------------ */
 #define CHUNK 65536ll
@@ -167,6 +170,7 @@ static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, doubl
     double *part = (double *)malloc(sizeof(double) * 2 * (size_t)n_chunks);
     const uint64_t seed = seed_from_env();
     g_antithetic = getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC"));
+    g_control = getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE"));
     const char *cap = getenv("MC_HOST_THREADS");
     (void)cap;
 #ifdef _OPENMP
@@ -221,23 +225,31 @@ static void basket_chunk(const void *ctx, uint64_t seed, long long first, long l
     const mc_real sqrt_t = (mc_real)sqrt((double)o->t);
     enum { NBLK = (N + NPB - 1) / NPB };
     mc_real g[NBLK * NPB];
-    double s = 0, s2 = 0;
+    double s = 0, s2 = 0, wsum = 0;
+    for (int a = 0; a < N; ++a)
+        wsum += (double)o->w[a];
     for (long long i = 0; i < count; ++i) {
         for (int b = 0; b < NBLK; ++b)
             block_normals(seed, MC_DOMAIN_BASKET, (uint64_t)(first + i), (uint32_t)b, g + b * NPB);
         mc_real payoff = 0;
         for (int sign = 1; sign >= (g_antithetic ? -1 : 1); sign -= 2) {
-            mc_real basket = 0;
+            mc_real basket = 0, lg = (mc_real)log(wsum);
             for (int a = 0; a < N; ++a) {
                 mc_real bt = 0;
                 for (int b = 0; b <= a; ++b)
                     bt += o->p[a][b] * ((mc_real)sign * g[b]);
                 bt += o->d[a];
                 const mc_real mu = (mc_real)(((double)o->r - 0.5 * (double)o->v[a] * (double)o->v[a]) * (double)o->t);
-                basket += o->s[a] * R_EXP(mu + o->v[a] * bt * sqrt_t) * o->w[a];
+                const mc_real x = mu + o->v[a] * bt * sqrt_t;
+                basket += o->s[a] * R_EXP(x) * o->w[a];
+                lg += (mc_real)((double)o->w[a] / wsum) * (R_LOG(o->s[a]) + x);
             }
             const mc_real v = basket - o->k;
             payoff += v > 0 ? v : 0;
+            if (g_control) {
+                const mc_real gv = R_EXP(lg) - o->k;
+                payoff -= gv > 0 ? gv : 0;
+            }
         }
         if (g_antithetic)
             payoff *= (mc_real)0.5;
@@ -295,7 +307,23 @@ OptionValue host_vanillaOpt(OptionData option, int path)
 
 OptionValue host_basketOpt(MultiOptionData *option, int path)
 {
-    return simulate(basket_chunk, option, path, exp(-(double)option->r * (double)option->t));
+    const double disc = exp(-(double)option->r * (double)option->t);
+    OptionValue v = simulate(basket_chunk, option, path, disc);
+    if (g_control) { /* simulated: payoff - control; add the control's closed-form mean back */
+        double mean = 0;
+#ifdef MC_SINGLE_PRECISION
+        const mc_basket_f32 b = {N, option->s, option->v, &option->p[0][0], option->d, option->w, option->k, option->t, option->r};
+        if (mc_basket_control_mean_f32(&b, &mean) != MC_OK) {
+#else
+        const mc_basket_f64 b = {N, option->s, option->v, &option->p[0][0], option->d, option->w, option->k, option->t, option->r};
+        if (mc_basket_control_mean_f64(&b, &mean) != MC_OK) {
+#endif
+            fprintf(stderr, "Error in host_basketOpt: %s\n", mc_last_error());
+            exit(1);
+        }
+        v.Expected = (mc_real)((double)v.Expected + disc * mean);
+    }
+    return v;
 }
 
 OptionValue host_cvaEquityOption(CVA *cva, int path)

@@ -18,7 +18,8 @@
  * numThreads is accepted and ignored (it only shaped the reference's reduction, :163);
  * nothing is printed on success (set MC_VERBOSE=1 for one line per call).
  * Environment: MC_DEVICE (default 0), MC_SEED (default MC_DEFAULT_SEED), MC_VERBOSE,
- * MC_ANTITHETIC=1 (antithetic-variates estimator instead of the reference's plain one).
+ * MC_ANTITHETIC=1 (antithetic-variates estimator instead of the reference's plain one),
+ * MC_CONTROL_VARIATE=1 (dev_basketOpt only: geometric-basket control variate).
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -61,6 +62,8 @@ static mc_context *context(void)
             die("creating the device context");
         if (getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC")))
             mc_context_set_antithetic(g_ctx, 1);
+        if (getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE")))
+            mc_context_set_control_variate(g_ctx, 1);
         atexit(drop_context);
     }
     return g_ctx;

@@ -71,6 +71,7 @@ struct mc_context {
     hipStream_t table_stream = nullptr;  // stream the cached table was uploaded on
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool antithetic = false;      // estimator: plain (reference) or antithetic variates
+    bool control = false;         // baskets: geometric-basket control variate
     // sampled device timing of the simulation kernels (mc_context_profile)
     int profile_every = 0;
     uint64_t launches = 0;
@@ -199,6 +200,60 @@ extern "C" int mc_context_set_antithetic(mc_context *c, int on)
         return fail(MC_ERR_INVALID, "NULL context");
     c->antithetic = on != 0;
     return MC_OK;
+}
+
+extern "C" int mc_context_set_control_variate(mc_context *c, int on)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    c->control = on != 0;
+    return MC_OK;
+}
+
+// E[max(G - K, 0)] of the geometric-basket control, closed form in fp64 (see mc_mi355x.h)
+template <class B>
+static int control_mean(const B &o, double *mean)
+{
+    if (!mean || o.n < 1 || o.n > MC_MAX_ASSETS_GENERIC || !o.s || !o.v || !o.p || !o.d || !o.w)
+        return fail(MC_ERR_INVALID, "control variate: bad basket");
+    const int n = o.n;
+    double W = 0;
+    for (int a = 0; a < n; ++a) {
+        if (!((double)o.w[a] > 0) || !((double)o.s[a] > 0))
+            return fail(MC_ERR_INVALID, "control variate: needs w[a] > 0 and s[a] > 0 for every asset");
+        W += (double)o.w[a];
+    }
+    if (!((double)o.k > 0))
+        return fail(MC_ERR_INVALID, "control variate: needs k > 0");
+    const double sqrt_t = std::sqrt((double)o.t);
+    double m = std::log(W), var = 0;
+    for (int a = 0; a < n; ++a) {
+        const double va = (double)o.v[a];
+        m += (double)o.w[a] / W * (std::log((double)o.s[a]) + ((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]);
+    }
+    for (int b = 0; b < n; ++b) {
+        double cb = 0;
+        for (int a = b; a < n; ++a)
+            cb += (double)o.w[a] / W * (double)o.v[a] * sqrt_t * (double)o.p[a * n + b];
+        var += cb * cb;
+    }
+    const double sd = std::sqrt(var);
+    if (sd == 0) {
+        const double g = std::exp(m) - (double)o.k;
+        *mean = g > 0 ? g : 0;
+        return MC_OK;
+    }
+    const double d1 = (m - std::log((double)o.k) + var) / sd, d2 = d1 - sd;
+    *mean = std::exp(m + 0.5 * var) * 0.5 * std::erfc(-d1 / std::sqrt(2.0)) - (double)o.k * 0.5 * std::erfc(-d2 / std::sqrt(2.0));
+    return MC_OK;
+}
+extern "C" int mc_basket_control_mean_f32(const mc_basket_f32 *o, double *mean)
+{
+    return o ? control_mean(*o, mean) : fail(MC_ERR_INVALID, "NULL basket");
+}
+extern "C" int mc_basket_control_mean_f64(const mc_basket_f64 *o, double *mean)
+{
+    return o ? control_mean(*o, mean) : fail(MC_ERR_INVALID, "NULL basket");
 }
 
 extern "C" int mc_context_profile(mc_context *c, int every)
@@ -539,8 +594,25 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
             k.m[a * (a + 1) / 2 + b] = (Real)m[a][b];
         k.base[a] = (Real)base[a];
         k.coef[a] = (Real)(coef[a] / scale);
+        k.wg[a] = 0;
     }
     k.strike = (Real)((double)o.k / scale);
+    k.cg = 0;
+    k.cv = 0;
+    if (c->control) {
+        double cv_mean;
+        if (int rc = control_mean(o, &cv_mean)) return rc;  // validates w > 0, s > 0, k > 0
+        double W = 0, cg = 0;
+        for (int a = 0; a < NA; ++a)
+            W += (double)o.w[a];
+        for (int a = 0; a < NA; ++a) {
+            k.wg[a] = (Real)((double)o.w[a] / W);
+            cg += (double)o.w[a] / W * std::log((double)o.s[a]);
+        }
+        // ln G in the kernel's exponent units (log2 in f32), minus the power-of-two rescale
+        k.cg = (Real)((cg + std::log(W)) * sc - (is_f32 ? std::log2(scale) : 0.0));
+        k.cv = 1;
+    }
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
@@ -564,13 +636,26 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     const int n = o.n, n_tri = n * (n + 1) / 2;
     const double sc = exp_scale<Real>();
     const double sqrt_t = std::sqrt((double)o.t);
-    std::vector<Real> host((size_t)n_tri + 2 * n);
+    std::vector<Real> host((size_t)n_tri + 3 * n);
     for (int a = 0; a < n; ++a) {
         const double va = (double)o.v[a];
         for (int b = 0; b <= a; ++b)
             host[(size_t)a * (a + 1) / 2 + b] = (Real)(va * sqrt_t * (double)o.p[a * n + b] * sc);
         host[(size_t)n_tri + a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
         host[(size_t)n_tri + n + a] = (Real)((double)o.w[a] * (double)o.s[a]);
+        host[(size_t)n_tri + 2 * n + a] = 0;
+    }
+    double cg_dyn = 0;
+    if (c->control) {
+        double cv_mean, W = 0;
+        if (int rc = control_mean(o, &cv_mean)) return rc;
+        for (int a = 0; a < n; ++a)
+            W += (double)o.w[a];
+        for (int a = 0; a < n; ++a) {
+            host[(size_t)n_tri + 2 * n + a] = (Real)((double)o.w[a] / W);
+            cg_dyn += (double)o.w[a] / W * std::log((double)o.s[a]);
+        }
+        cg_dyn = (cg_dyn + std::log(W)) * sc;
     }
     const size_t bytes = host.size() * sizeof(Real);
     std::vector<char> key(bytes + 2);
@@ -582,6 +667,8 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     k.consts = (const Real *)c->d_table;
     k.n = n;
     k.strike = o.k;
+    k.cg = (Real)cg_dyn;
+    k.cv = c->control ? 1 : 0;
     constexpr int NPB = npb<Real>::value;
     const size_t lds = (size_t)((n + NPB - 1) / NPB * NPB) * GROUP * sizeof(Real);
     const auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
@@ -847,9 +934,17 @@ static int dump_sync(mc_context *c, uint64_t n, Real *h_out, Enq enqueue)
                                      uint64_t n, mc_result *out)                                             \
     {                                                                                                        \
         if (int rc = check_common(c, o, first, n, out)) return rc;                                           \
-        return run_sync(c, n, std::exp(-(double)o->r * (double)o->t), out, [&](hipStream_t st, double *t) {  \
-            return basket_enqueue<Real>(c, o, seed, first, n, t, st, nullptr);                               \
-        });                                                                                                  \
+        const double disc = std::exp(-(double)o->r * (double)o->t);                                          \
+        if (int rc = run_sync(c, n, disc, out, [&](hipStream_t st, double *t) {                              \
+                return basket_enqueue<Real>(c, o, seed, first, n, t, st, nullptr);                           \
+            }))                                                                                              \
+            return rc;                                                                                       \
+        if (c->control) { /* the simulated quantity was payoff - control: add the control's closed-form mean */ \
+            double cv_mean;                                                                                  \
+            if (int rc = control_mean(*o, &cv_mean)) return rc;                                              \
+            out->expected += disc * cv_mean;                                                                 \
+        }                                                                                                    \
+        return MC_OK;                                                                                        \
     }                                                                                                        \
     extern "C" int mc_cva_run_##X(mc_context *c, const mc_cva_##X *o, uint64_t seed, uint64_t first,         \
                                   uint64_t n, mc_result *out)                                                \

@@ -236,6 +236,13 @@ struct BasketArgs {
     Real base[NA];
     Real coef[NA];
     Real strike;
+    // geometric-basket control variate (off in the reference's plain estimator):
+    // ln G = cg + sum_a wg_a x_a in the kernel's exponent units, x_a = asset a's exponent.  When
+    // cv != 0 the per-path value is payoff(arithmetic) - payoff(geometric); the closed-form mean of
+    // the latter (mc_basket_control_mean_*) is added back on the host.
+    Real wg[NA];
+    Real cg;
+    int cv;
 };
 
 __device__ __forceinline__ float exp_model(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -255,7 +262,7 @@ __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const
         for (int j = 0; j < NPB; ++j)
             g[b * NPB + j] = z[j];
     }
-    Real basket = 0, mirror = 0;
+    Real basket = 0, mirror = 0, lg = o.cg, lgm = o.cg;
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         Real x = o.base[a];
@@ -263,14 +270,27 @@ __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const
         for (int b = 0; b <= a; ++b)
             x = fma_r(o.m[a * (a + 1) / 2 + b], g[b], x);
         basket = fma_r(o.coef[a], exp_model(x), basket);
-        if (ANTI)  // exponent of the mirrored path: base - m g = 2 base - x
-            mirror = fma_r(o.coef[a], exp_model(fma_r((Real)-1, x, 2 * o.base[a])), mirror);
+        lg = fma_r(o.wg[a], x, lg);
+        if (ANTI) {  // exponent of the mirrored path: base - m g = 2 base - x
+            const Real xm = fma_r((Real)-1, x, 2 * o.base[a]);
+            mirror = fma_r(o.coef[a], exp_model(xm), mirror);
+            lgm = fma_r(o.wg[a], xm, lgm);
+        }
     }
     const Real v = basket - o.strike;
     Real pay = v > 0 ? v : 0;
+    if (o.cv) {  // wave-uniform
+        const Real gv = exp_model(lg) - o.strike;
+        pay -= gv > 0 ? gv : 0;
+    }
     if (ANTI) {
         const Real vm = mirror - o.strike;
-        pay = (Real)0.5 * (pay + (vm > 0 ? vm : 0));
+        Real pm = vm > 0 ? vm : 0;
+        if (o.cv) {
+            const Real gm = exp_model(lgm) - o.strike;
+            pm -= gm > 0 ? gm : 0;
+        }
+        pay = (Real)0.5 * (pay + pm);
     }
     return pay;
 }
@@ -327,7 +347,7 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, co
         g[4 * b + 2] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
         g[4 * b + 3] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
     }
-    f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f};
+    f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f}, lg = bcast(o.cg), lgm = bcast(o.cg);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
         f2 x = bcast(o.base[a]);
@@ -335,14 +355,22 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, co
         for (int b = 0; b <= a; ++b)
             x = pk_fma(bcast(o.m[a * (a + 1) / 2 + b]), g[b], x);
         basket = pk_fma(bcast(o.coef[a]), (f2){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}, basket);
+        lg = pk_fma(bcast(o.wg[a]), x, lg);
         if (ANTI) {  // mirrored path: base - m g = 2 base - x
             const f2 xm = pk_fma(bcast(-1.0f), x, bcast(2.0f * o.base[a]));
             mirror = pk_fma(bcast(o.coef[a]), (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
+            lgm = pk_fma(bcast(o.wg[a]), xm, lgm);
         }
     }
+    // the geometric mean never exceeds the arithmetic one, so the same 2^-k scale keeps it in [0,1]
     f2 pay = {clamp01(basket.x - o.strike), clamp01(basket.y - o.strike)};
-    if (ANTI)  // sum of the two payoffs; the 1/2 rides on the finishing kernel's scale
+    if (o.cv)  // wave-uniform
+        pay -= (f2){clamp01(__builtin_amdgcn_exp2f(lg.x) - o.strike), clamp01(__builtin_amdgcn_exp2f(lg.y) - o.strike)};
+    if (ANTI) {  // sum of the two values; the 1/2 rides on the finishing kernel's scale
         pay += (f2){clamp01(mirror.x - o.strike), clamp01(mirror.y - o.strike)};
+        if (o.cv)
+            pay -= (f2){clamp01(__builtin_amdgcn_exp2f(lgm.x) - o.strike), clamp01(__builtin_amdgcn_exp2f(lgm.y) - o.strike)};
+    }
     return pay;
 }
 
@@ -402,9 +430,11 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
 // estimator definitions as the specialised kernels, not their speed.
 template <class Real>
 struct BasketDyn {
-    const Real *consts;  // m packed lower-triangular rows (n(n+1)/2), then base[n], then coef[n]
+    const Real *consts;  // m packed lower-triangular rows (n(n+1)/2), then base[n], coef[n], wg[n]
     int n;
     Real strike;
+    Real cg;  // control variate constant (see BasketArgs)
+    int cv;
 };
 
 template <class Real, bool ANTI>
@@ -415,7 +445,8 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
     Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
     constexpr int NPB = npb<Real>::value;
     const int n = o.n, nblk = (n + NPB - 1) / NPB, n_tri = n * (n + 1) / 2;
-    const Real *__restrict__ m = o.consts, *__restrict__ base = o.consts + n_tri, *__restrict__ coef = base + n;
+    const Real *__restrict__ m = o.consts, *__restrict__ base = o.consts + n_tri, *__restrict__ coef = base + n,
+                            *__restrict__ wg = coef + n;
     const uint32_t stride = gridDim.x * GROUP;
     double acc_s = 0.0, acc_q = 0.0;
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
@@ -426,21 +457,34 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
             for (int j = 0; j < NPB; ++j)
                 g[(b * NPB + j) * GROUP] = z[j];
         }
-        Real basket = 0, mirror = 0;
+        Real basket = 0, mirror = 0, lg = o.cg, lgm = o.cg;
         int idx = 0;
         for (int a = 0; a < n; ++a) {
             Real x = base[a];
             for (int b = 0; b <= a; ++b)
                 x = fma_r(m[idx++], g[b * GROUP], x);
             basket = fma_r(coef[a], exp_model(x), basket);
-            if (ANTI)
-                mirror = fma_r(coef[a], exp_model(fma_r((Real)-1, x, 2 * base[a])), mirror);
+            lg = fma_r(wg[a], x, lg);
+            if (ANTI) {
+                const Real xm = fma_r((Real)-1, x, 2 * base[a]);
+                mirror = fma_r(coef[a], exp_model(xm), mirror);
+                lgm = fma_r(wg[a], xm, lgm);
+            }
         }
         const Real v = basket - o.strike;
         Real p = v > 0 ? v : 0;
+        if (o.cv) {
+            const Real gv = exp_model(lg) - o.strike;
+            p -= gv > 0 ? gv : 0;
+        }
         if (ANTI) {
             const Real vm = mirror - o.strike;
-            p = (Real)0.5 * (p + (vm > 0 ? vm : 0));
+            Real pm = vm > 0 ? vm : 0;
+            if (o.cv) {
+                const Real gm = exp_model(lgm) - o.strike;
+                pm -= gm > 0 ? gm : 0;
+            }
+            p = (Real)0.5 * (p + pm);
         }
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);

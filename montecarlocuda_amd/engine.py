@@ -142,6 +142,10 @@ class Engine:
         """Plain Monte Carlo (the reference's estimator) or antithetic variates (pair means)."""
         check(lib().mc_context_set_antithetic(self._ctx, 1 if on else 0))
 
+    def set_control_variate(self, on: bool):
+        """Baskets: simulate payoff(arithmetic) - payoff(geometric) and add the geometric closed form back."""
+        check(lib().mc_context_set_control_variate(self._ctx, 1 if on else 0))
+
     def profile(self, every: int):
         """Sample the simulation kernel's device time on every `every`-th launch (0 = off)."""
         check(lib().mc_context_profile(self._ctx, every))
@@ -220,6 +224,14 @@ def shard_range(total, rank, world):
     first, count = C.c_uint64(), C.c_uint64()
     lib().mc_shard_range(total, rank, world, C.byref(first), C.byref(count))
     return first.value, count.value
+
+
+def basket_control_mean(b, precision="f64"):
+    """Closed-form E[max(G - K, 0)] of the geometric-basket control (undiscounted, fp64)."""
+    h = _BasketHolder(precision, b)
+    m = C.c_double()
+    check(getattr(lib(), f"mc_basket_control_mean_{precision}")(C.byref(h.struct), C.byref(m)))
+    return m.value
 
 
 def chol(c, precision="f64"):

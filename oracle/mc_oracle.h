@@ -78,8 +78,10 @@ void orc_closing(double sum, double sum2, long long n, double discount,
                              REAL *payoffs, orc_result *out);                                    \
     void orc_dev_basket_##X(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,   \
                             const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,                \
-                            uint64_t first_path, uint64_t n_paths, int antithetic,               \
+                            uint64_t first_path, uint64_t n_paths, int mode,                     \
                             REAL *payoffs, orc_result *out);                                     \
+    double orc_basket_control_mean_##X(int n, const REAL *s, const REAL *v, const REAL *p,       \
+                                       const REAL *d, const REAL *w, REAL k, REAL t, REAL r);    \
     void orc_dev_cva_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint, REAL lgd,          \
                          int n_grid, uint64_t seed, uint64_t first_path, uint64_t n_paths,       \
                          int antithetic, REAL *values, orc_result *out);

@@ -298,13 +298,52 @@ void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
  * g[b*NPB .. b*NPB+NPB-1]; domain BASKET.  The product multiplies only the lower triangle
  * (structural zeros of the factor skipped) -- identical values whenever the upper triangle is
  * zero, which Chol guarantees (dp/MonteCarloHost.c:95). */
+/* Closed-form mean of the geometric-basket control (not in the reference):
+ *   G = W prod_a S_a(T)^(w_a / W),  W = sum_a w_a > 0,  is lognormal: ln G ~ N(m, sd^2) with
+ *   m = ln W + sum_a wh_a (ln S_a + (r - v_a^2/2) T + v_a sqrt(T) d_a),  wh = w / W,
+ *   sd^2 = sum_b (sum_{a>=b} wh_a v_a sqrt(T) L_ab)^2,
+ *   E[max(G - K, 0)] = e^{m + sd^2/2} Phi(d1) - K Phi(d2),  d1 = (m - ln K + sd^2)/sd, d2 = d1 - sd.
+ * Evaluated in fp64 whatever the simulation precision. */
+double FN(orc_basket_control_mean)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                                   const REAL *w, REAL k, REAL t, REAL r)
+{
+    double W = 0;
+    for (int a = 0; a < n; a++)
+        W += (double)w[a];
+    const double sqrt_t = sqrt((double)t);
+    double m = log(W), var = 0;
+    for (int a = 0; a < n; a++)
+        m += (double)w[a] / W * (log((double)s[a]) + ((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t +
+                                 (double)v[a] * sqrt_t * (double)d[a]);
+    for (int b = 0; b < n; b++) {
+        double c = 0;
+        for (int a = b; a < n; a++)
+            c += (double)w[a] / W * (double)v[a] * sqrt_t * (double)p[a * n + b];
+        var += c * c;
+    }
+    const double sd = sqrt(var);
+    if (sd == 0) {
+        double g = exp(m) - (double)k;
+        return g > 0 ? g : 0;
+    }
+    const double d1 = (m - log((double)k) + var) / sd, d2 = d1 - sd;
+    return exp(m + 0.5 * var) * 0.5 * erfc(-d1 / sqrt(2.0)) - (double)k * 0.5 * erfc(-d2 / sqrt(2.0));
+}
+
+/* `mode` bit 0: antithetic variates; bit 1: geometric-basket control variate (the per-path value is
+ * then payoff(arithmetic) - payoff(geometric), and the closed-form mean above is added back to the
+ * expectation). */
 void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
                         const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,
-                        uint64_t first_path, uint64_t n_paths, int antithetic, REAL *payoffs, orc_result *out)
+                        uint64_t first_path, uint64_t n_paths, int mode, REAL *payoffs, orc_result *out)
 {
+    const int antithetic = mode & 1, control = (mode >> 1) & 1;
     int nblk = (n + ORC_NPB - 1) / ORC_NPB;
     REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)(nblk * ORC_NPB));
     const REAL sqrt_t = (REAL)sqrt((double)t);
+    double wsum = 0;
+    for (int a = 0; a < n; a++)
+        wsum += (double)w[a];
     double sum = 0, sum2 = 0;
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t path = first_path + i;
@@ -312,7 +351,7 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
             FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
         REAL payoff = 0;
         for (int sign = 1; sign >= (antithetic ? -1 : 1); sign -= 2) {
-            REAL basket = 0;
+            REAL basket = 0, lg = (REAL)log(wsum);
             for (int a = 0; a < n; a++) {
                 REAL bt = 0;
                 for (int b = 0; b <= a; b++)
@@ -321,9 +360,14 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
                 REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
                 REAL sa = s[a] * EXP_R(mu + v[a] * bt * sqrt_t);
                 basket += sa * w[a];
+                lg += (REAL)((double)w[a] / wsum) * (LOG_R(s[a]) + (mu + v[a] * bt * sqrt_t));
             }
             REAL value = basket - k;
             payoff += value > 0 ? value : 0;
+            if (control) {
+                REAL gv = EXP_R(lg) - k;
+                payoff -= gv > 0 ? gv : 0;
+            }
         }
         if (antithetic)
             payoff *= (REAL)0.5;
@@ -333,7 +377,10 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
         sum2 += (double)payoff * (double)payoff;
     }
     free(g);
-    FN(dev_finish)(sum, sum2, n_paths, exp(-(double)r * (double)t), out);
+    const double disc = exp(-(double)r * (double)t);
+    FN(dev_finish)(sum, sum2, n_paths, disc, out);
+    if (control && out)
+        out->expected += disc * FN(orc_basket_control_mean)(n, s, v, p, d, w, k, t, r);
 }
 
 /* CVA, DEVICE ordering dp/MonteCarloKernel.cu:241-262: at step j the spot is advanced FIRST

@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
         f("orc_dev_basket").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R, C.c_uint64,
                                         C.c_uint64, C.c_uint64, C.c_int, RP, res]
         f("orc_dev_cva").argtypes = [R] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, RP, res]
+        f("orc_basket_control_mean").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R]
+        f("orc_basket_control_mean").restype = C.c_double
         for nm in ("orc_host_vanilla", "orc_host_basket", "orc_host_cva", "orc_dev_normals",
                    "orc_dev_vanilla", "orc_dev_basket", "orc_dev_cva"):
             f(nm).restype = None
@@ -185,15 +187,20 @@ def dev_vanilla(X, opt, seed, first, n, want_paths=True, antithetic=False):
     return out, r.as_dict()
 
 
-def dev_basket(X, b, seed, first, n, want_paths=True, antithetic=False):
+def dev_basket(X, b, seed, first, n, want_paths=True, antithetic=False, control=False):
     nn = len(b["s"])
     keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
     out = np.zeros(n if want_paths else 0, dtype=NP[X])
     ptr = out.ctypes.data_as(C.POINTER(CT[X])) if want_paths else None
     r = OrcResult()
     getattr(lib(), f"orc_dev_basket_{X}")(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], seed,
-                                          first, n, int(antithetic), ptr, C.byref(r))
+                                          first, n, int(antithetic) | (int(control) << 1), ptr, C.byref(r))
     return out, r.as_dict()
+
+
+def basket_control_mean(X, b):
+    keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
+    return getattr(lib(), f"orc_basket_control_mean_{X}")(len(b["s"]), *[p for _, p in keep], b["k"], b["t"], b["r"])
 
 
 def dev_cva(X, c, seed, first, n, want_paths=True, antithetic=False):

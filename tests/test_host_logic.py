@@ -50,3 +50,21 @@ def test_chol_flags_indefinite_input(mc):
     assert bad > 0
     _, bad = mc.chol(np.full((4, 4), 0.5) + 0.5 * np.eye(4))
     assert bad == 0
+
+
+def test_basket_control_mean_matches_oracle_and_simulation(mc, po):
+    """Closed-form mean of the geometric-basket control: engine helper == oracle (fp64 formula), and it
+    equals the simulated mean of the geometric payoff (difference of the oracle's two estimators)."""
+    for X in ("f64", "f32"):
+        for n in (1, 3, 4, 16):
+            corr = np.full((n, n), 0.4) + 0.6 * np.eye(n)
+            L = po.chol(X, corr)
+            b = dict(s=[90.0 + 3 * i for i in range(n)], v=[0.15 + 0.02 * i for i in range(n)], p=L.tolist(),
+                     d=[0.01 * (i % 3 - 1) for i in range(n)], w=[1.0 + 0.1 * i for i in range(n)], k=100.0 * n, t=1.5, r=0.03)
+            assert mc.basket_control_mean(b, X) == pytest.approx(po.basket_control_mean(X, b), rel=1e-13)
+        _, plain = po.dev_basket("f64", b, 5, 0, 200000, want_paths=False)
+        _, ctrl = po.dev_basket("f64", b, 5, 0, 200000, want_paths=False, control=True)
+        assert ctrl["confidence"] < 0.15 * plain["confidence"]
+        assert abs(ctrl["expected"] - plain["expected"]) < 3.5 / 1.96 * plain["confidence"]
+    with pytest.raises(mc.McError, match=r"w\[a\] > 0"):
+        mc.basket_control_mean(dict(b, w=[1.0] * 15 + [-0.5]))
