@@ -116,9 +116,9 @@ __device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w,
     block_normals(c0, w.unit_hi, 0u, 1u, w.seed_lo, w.seed_hi, z);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        p[j] = fmax(o.spot * exp(o.drift + o.vol * z[j]) - o.strike, 0.0);
+        p[j] = fmax(o.spot * exp_f64(o.drift + o.vol * z[j]) - o.strike, 0.0);
         if (ANTI)
-            p[j] = 0.5 * (p[j] + fmax(o.spot * exp(o.drift - o.vol * z[j]) - o.strike, 0.0));
+            p[j] = 0.5 * (p[j] + fmax(o.spot * exp_f64(o.drift - o.vol * z[j]) - o.strike, 0.0));
     }
 }
 
@@ -246,7 +246,7 @@ struct BasketArgs {
 };
 
 __device__ __forceinline__ float exp_model(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ double exp_model(double x) { return exp(x); }
+__device__ __forceinline__ double exp_model(double x) { return exp_f64(x); }
 
 template <class Real, int NA, bool ANTI>
 __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const Work &w, uint32_t c0)
@@ -557,9 +557,9 @@ __device__ __forceinline__ double hastings_poly(double k)
 
 __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const CvaStep<double> &st)
 {
-    const double spot = exp(ln_spot);
+    const double spot = exp_f64(ln_spot);
     const double d1 = __builtin_fma(W, st.g, st.e1), d2 = __builtin_fma(W, st.g, st.e2);
-    const double A = 0.39894228040143267793994605993438 * exp(__builtin_fma(-0.5 * d1, d1, ln_spot));
+    const double A = 0.39894228040143267793994605993438 * exp_f64(__builtin_fma(-0.5 * d1, d1, ln_spot));
     const double t1 = A * hastings_poly(recip_pos(__builtin_fma(0.2316419, fabs(d1), 1.0)));
     const double t2 = A * hastings_poly(recip_pos(__builtin_fma(0.2316419, fabs(d2), 1.0)));
     const double a = d1 > 0 ? spot - t1 : t1;

@@ -13,12 +13,60 @@
 //   sqrt_pos(x)        ~9                 v_rsq_f64 + two coupled Newton steps (ocml's core, no rescaling)
 //   sincos_turns(u)    ~36                quadrant from rint(4u), Taylor to y^15 / y^16 on |y| <= 1/2
 //   recip_pos(d)       ~5                 v_rcp_f64 + two Newton steps
-// exp() stays ocml's: it is already 23 instructions of straight Horner.
+//   exp_f64(x)         ~19                n = rint(x log2 e), two-step reduction, Taylor to r^13, v_ldexp_f64
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mc {
+
+// Build switches for in-process A/B runs (tools/ab_f64.py builds one .so per combination and times them
+// interleaved on one device).  Measured on MI355X, medians, default build = 1.00:
+//                     vanilla f64   basket n=4 / n=16 f64   CVA 256 dates f64
+//   default                1.00          1.00 / 1.00              1.00
+//   MC_AB_OCML_EXP         1.04          1.04 / 1.03              1.04      (ocml exp: ~10 extra v_mov_b64)
+//   MC_AB_CONST_COEF       1.00          1.19 / 1.03              1.11      (coefficients in constant memory:
+//                                                              scalar reloads in the loop cost more than VGPRs)
+//   both                   1.02          1.20 / 1.07              1.13      (profiles/r01_ab_f64_math.log)
+#ifdef MC_AB_CONST_COEF
+#define MC_COEF_STORAGE __constant__
+#else
+#define MC_COEF_STORAGE static constexpr
+#endif
+MC_COEF_STORAGE double LOG_LG[7] = {6.666666666666735130e-01, 3.999999999940941908e-01, 2.857142874366239149e-01,
+                                 2.222219843214978396e-01, 1.818357216161805012e-01, 1.531383769920937332e-01,
+                                 1.479819860511658591e-01};
+MC_COEF_STORAGE double SIN_Q[8] = {1.5707963267948966,     -0.6459640975062463,    0.07969262624616705,   -0.004681754135318688,
+                                0.00016044118478735983, -3.598843235212085e-06, 5.692172921967927e-08, -6.688035109811468e-10};
+MC_COEF_STORAGE double COS_Q[8] = {-1.2337005501361697,     0.25366950790104803,   -0.02086348076335296,   0.0009192602748394266,
+                                -2.5202042373060607e-05, 4.710874778818172e-07, -6.386603083791852e-09, 6.565963114979473e-11};
+
+// e^x for finite x (underflows to 0 through v_ldexp_f64; these kernels never overflow it):
+// x = n ln2 + r, |r| <= ln2/2, Taylor to r^13: 19 instructions, max error 0.86 ulp.
+#ifndef MC_AB_OCML_EXP
+__device__ __forceinline__ double exp_f64(double x)
+{
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+    double p = __builtin_fma(r, 1.6059043836821613e-10, 2.08767569878681e-09);
+    p = __builtin_fma(r, p, 2.505210838544172e-08);
+    p = __builtin_fma(r, p, 2.755731922398589e-07);
+    p = __builtin_fma(r, p, 2.7557319223985893e-06);
+    p = __builtin_fma(r, p, 2.48015873015873e-05);
+    p = __builtin_fma(r, p, 0.0001984126984126984);
+    p = __builtin_fma(r, p, 0.001388888888888889);
+    p = __builtin_fma(r, p, 0.008333333333333333);
+    p = __builtin_fma(r, p, 0.041666666666666664);
+    p = __builtin_fma(r, p, 0.16666666666666666);
+    p = __builtin_fma(r, p, 0.5);
+    p = __builtin_fma(r, p, 1.0);
+    p = __builtin_fma(r, p, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)n);
+}
+#else
+__device__ __forceinline__ double exp_f64(double x) { return exp(x); }
+#endif
 
 __device__ __forceinline__ double recip_pos(double d)
 {
@@ -44,11 +92,8 @@ __device__ __forceinline__ double log_unit(double x)
     double s = f * r;
     s = __builtin_fma(__builtin_fma(-s, d, f), r, s);
     const double z = s * s, w = z * z;
-    const double t1 = w * __builtin_fma(w, __builtin_fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01),
-                                        3.999999999940941908e-01);
-    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
-                                                         2.857142874366239149e-01),
-                                        6.666666666666735130e-01);
+    const double t1 = w * __builtin_fma(w, __builtin_fma(w, LOG_LG[5], LOG_LG[3]), LOG_LG[1]);
+    const double t2 = z * __builtin_fma(w, __builtin_fma(w, __builtin_fma(w, LOG_LG[6], LOG_LG[4]), LOG_LG[2]), LOG_LG[0]);
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
@@ -80,21 +125,15 @@ __device__ __forceinline__ void sincos_turns(double u, double &sin_out, double &
     const double q = __builtin_rint(t);
     const double y = t - q;
     const double z = y * y;
-    double ps = __builtin_fma(z, -6.688035109811468e-10, 5.692172921967927e-08);
-    ps = __builtin_fma(z, ps, -3.598843235212085e-06);
-    ps = __builtin_fma(z, ps, 0.00016044118478735983);
-    ps = __builtin_fma(z, ps, -0.004681754135318688);
-    ps = __builtin_fma(z, ps, 0.07969262624616705);
-    ps = __builtin_fma(z, ps, -0.6459640975062463);
-    ps = __builtin_fma(z, ps, 1.5707963267948966);
+    double ps = __builtin_fma(z, SIN_Q[7], SIN_Q[6]);
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+        ps = __builtin_fma(z, ps, SIN_Q[i]);
     const double sy = y * ps;
-    double pc = __builtin_fma(z, 6.565963114979473e-11, -6.386603083791852e-09);
-    pc = __builtin_fma(z, pc, 4.710874778818172e-07);
-    pc = __builtin_fma(z, pc, -2.5202042373060607e-05);
-    pc = __builtin_fma(z, pc, 0.0009192602748394266);
-    pc = __builtin_fma(z, pc, -0.02086348076335296);
-    pc = __builtin_fma(z, pc, 0.25366950790104803);
-    pc = __builtin_fma(z, pc, -1.2337005501361697);
+    double pc = __builtin_fma(z, COS_Q[7], COS_Q[6]);
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+        pc = __builtin_fma(z, pc, COS_Q[i]);
     const double cy = __builtin_fma(z, pc, 1.0);
     // angle = (pi/2)(q + y):  q mod 4 = 0: (sy, cy)  1: (cy, -sy)  2: (-sy, -cy)  3: (-cy, sy)
     const int qi = (int)q;
