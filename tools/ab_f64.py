@@ -10,7 +10,10 @@ from montecarlocuda_amd import _lib, engine
 import bench
 
 variants = sorted(glob.glob(os.path.join(ROOT, "tools", "ab_*.so")))
-work = {"vanilla_f64": 4 * 10 ** 8, "basket16_f64": 3 * 10 ** 7, "cva256_f64": 10 ** 6, "basket4_f64": 10 ** 8}
+work = {"vanilla_f64": 4 * 10 ** 8, "basket16_f64": 3 * 10 ** 7, "cva256_f64": 10 ** 6, "basket4_f64": 10 ** 8,
+        "vanilla_f32": 2 * 10 ** 9, "basket4_f32": 5 * 10 ** 8, "cva256_f32": 4 * 10 ** 6}
+if len(sys.argv) > 1:
+    work = {k: v for k, v in work.items() if k in sys.argv[1:]}
 W = bench.workloads(mc)
 W["basket4_f64"] = ("basket", "f64", lambda: bench.basket_inputs(mc, 4, "f64"), 0, 0, "")
 engines = {}
