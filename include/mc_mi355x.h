@@ -162,6 +162,16 @@ int mc_cva_run_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
 int mc_cva_run_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
                    uint64_t first_path, uint64_t n_paths, mc_result *out);
 
+/* ---- pathwise Greeks of the vanilla call (the reference prices only) -------------
+ * One pass, the pricing kernels' stream and path indexing: price, delta = dV/dS and vega = dV/dsigma
+ * as discounted means of  I (S_T - K),  I S_T / S,  I S_T (sqrt(T) z - sigma T),  I = [S_T > K],
+ * each with its own 95 % half-width.  Plain estimator only. */
+typedef struct { mc_result price, delta, vega; } mc_vanilla_greeks;
+int mc_vanilla_greeks_run_f32(mc_context *ctx, const mc_option_f32 *opt, uint64_t seed,
+                              uint64_t first_path, uint64_t n_paths, mc_vanilla_greeks *out);
+int mc_vanilla_greeks_run_f64(mc_context *ctx, const mc_option_f64 *opt, uint64_t seed,
+                              uint64_t first_path, uint64_t n_paths, mc_vanilla_greeks *out);
+
 /* ---- per-path values, for parity tests ---------------------------------------------------
  * h_out: HOST pointer to n_paths values (undiscounted payoffs / per-path CVA).  Same kernels
  * as above with a store of every value added; n_paths <= 2^26. */

@@ -60,6 +60,10 @@ class Result(C.Structure):
                 ("n", C.c_uint64), ("kernel_ms", C.c_float)]
 
 
+class Greeks(C.Structure):
+    _fields_ = [("price", Result), ("delta", Result), ("vega", Result)]
+
+
 OPTION = {"f32": OptionF32, "f64": OptionF64}
 BASKET = {"f32": BasketF32, "f64": BasketF64}
 CVA = {"f32": CvaF32, "f64": CvaF64}
@@ -71,6 +75,7 @@ for _x in ("f32", "f64"):
     for _p in ("vanilla", "basket", "cva"):
         EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]
     EXPORTS.append(f"mc_normals_{_x}")
+    EXPORTS.append(f"mc_vanilla_greeks_run_{_x}")
 
 
 def _declare(L: C.CDLL) -> C.CDLL:
@@ -106,6 +111,7 @@ def _declare(L: C.CDLL) -> C.CDLL:
             getattr(L, f"mc_{prod}_run_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, C.POINTER(Result)]
             getattr(L, f"mc_{prod}_paths_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, RP]
         getattr(L, f"mc_normals_{X}").argtypes = [ctx, u64, C.c_uint32, u64, u64, C.c_uint32, RP]
+        getattr(L, f"mc_vanilla_greeks_run_{X}").argtypes = [ctx, C.POINTER(OPTION[X]), u64, u64, u64, C.POINTER(Greeks)]
     return L
 
 

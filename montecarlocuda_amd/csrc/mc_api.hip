@@ -60,6 +60,7 @@ struct mc_context {
     hipStream_t stream = nullptr;
     double2 *partials = nullptr;  // MAX_SEGMENTS * blocks + 2 (vanilla edge launches)
     double *d_triple = nullptr;   // result slot of the synchronous runs
+    double *d_triple9 = nullptr;  // three result slots (price, delta, vega), allocated on first use
     double *h_triple = nullptr;   // pinned
     void *d_out = nullptr;        // per-path dump buffer (tests), grown on demand
     size_t d_out_bytes = 0;
@@ -167,6 +168,7 @@ extern "C" void mc_context_destroy(mc_context *c)
         (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->partials);
     (void)hipFree(c->d_triple);
+    (void)hipFree(c->d_triple9);
     (void)hipHostFree(c->h_triple);
     (void)hipFree(c->d_out);
     (void)hipFree(c->d_table);
@@ -524,6 +526,85 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale1, scale2, (double)n, d_triple);
     HIPCHK(hipGetLastError());
     return MC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// vanilla with pathwise Greeks (price, delta, vega)
+// ---------------------------------------------------------------------------------------
+static void greeks_prepare(const mc_option_f32 &o, GreeksF32 &k)
+{
+    const double log2e = 1.4426950408889634074;
+    k.drift2 = (float)((((double)o.r - 0.5 * (double)o.v * (double)o.v) * (double)o.t) * log2e);
+    k.vol2 = (float)((double)o.v * std::sqrt((double)o.t) * log2e);
+    k.spot = o.s, k.strike = o.k;
+    k.sqrt_t = (float)std::sqrt((double)o.t);
+    k.sigma_t = (float)((double)o.v * (double)o.t);
+}
+static void greeks_prepare(const mc_option_f64 &o, GreeksF64 &k)
+{
+    k.drift = (o.r - 0.5 * o.v * o.v) * o.t;
+    k.vol = o.v * std::sqrt(o.t);
+    k.spot = o.s, k.strike = o.k;
+    k.sqrt_t = std::sqrt(o.t);
+    k.sigma_t = o.v * o.t;
+}
+
+template <class Real, class In, class Opt>
+static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first, uint64_t n, mc_vanilla_greeks *out)
+{
+    if (int rc = check_common(c, o, first, n, out)) return rc;
+    if (!finite_pos(o->s) || !finite_pos(o->k) || !(o->v >= 0) || !(o->t >= 0) || !std::isfinite((double)o->r))
+        return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
+    if (c->antithetic)
+        return fail(MC_ERR_UNSUPPORTED, "greeks: only the plain estimator is implemented");
+    constexpr uint64_t NPB = npb<Real>::value;
+    HIPCHK(hipSetDevice(c->device));
+    Opt k;
+    greeks_prepare(*o, k);
+    const uint64_t end = first + n, u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
+    std::vector<Segment> segs;
+    if (int rc = plan_segments(u0, u1 - u0, segs)) return rc;
+    if (segs.size() > 2)   // three pair-planes share the partial buffer
+        return fail(MC_ERR_INVALID, "greeks: path range too large for one call; split it");
+    const int plane = 2 * c->blocks + 2;   // pairs reserved per quantity
+    if (!c->d_triple9)
+        HIPCHK(hipMalloc(&c->d_triple9, 9 * sizeof(double)));
+    hipStream_t st = c->stream;
+    HIPCHK(hipEventRecord(c->ev0, st));
+    int slot = 0;
+    for (const Segment &s : segs) {
+        const Work w = make_work(seed, s, first, end);
+        const int g = grid_for(c, s.count);
+        vanilla_greeks_kernel<Opt, Real><<<g, GROUP, 0, st>>>(k, w, c->partials + slot, plane);
+        slot += g;
+    }
+    for (int q = 0; q < 3; ++q)
+        finish_kernel<<<1, GROUP, 0, st>>>(c->partials + (size_t)q * plane, slot, 1.0, 1.0, (double)n, c->d_triple9 + 3 * q);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, st));
+    double h[9];
+    HIPCHK(hipMemcpyAsync(h, c->d_triple9, sizeof h, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    const double disc = std::exp(-(double)o->r * (double)o->t);
+    mc_result *r[3] = {&out->price, &out->delta, &out->vega};
+    for (int q = 0; q < 3; ++q) {
+        r[q]->sum = h[3 * q], r[q]->sum2 = h[3 * q + 1], r[q]->n = (uint64_t)h[3 * q + 2], r[q]->kernel_ms = ms;
+        mc_closing(r[q]->sum, r[q]->sum2, r[q]->n, disc, &r[q]->expected, &r[q]->confidence);
+    }
+    return MC_OK;
+}
+
+extern "C" int mc_vanilla_greeks_run_f32(mc_context *c, const mc_option_f32 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                         mc_vanilla_greeks *out)
+{
+    return greeks_run<float, mc_option_f32, GreeksF32>(c, o, seed, first, n, out);
+}
+extern "C" int mc_vanilla_greeks_run_f64(mc_context *c, const mc_option_f64 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                         mc_vanilla_greeks *out)
+{
+    return greeks_run<double, mc_option_f64, GreeksF64>(c, o, seed, first, n, out);
 }
 
 // ---------------------------------------------------------------------------------------

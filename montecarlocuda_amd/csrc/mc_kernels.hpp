@@ -222,6 +222,52 @@ __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Opt o, cons
 }
 
 // =========================================================================================
+// Vanilla call with pathwise Greeks (the reference prices only).  Per path, on the same
+// normal as the pricing kernels:  S_T = S exp(drift + vol z),  I = [S_T > K],
+//     payoff = I (S_T - K),   d payoff / dS = I S_T / S,   d payoff / d sigma = I S_T (sqrt(T) z - sigma T)
+// Three (sum, sum2) pairs per workgroup: partials[q * pair_stride + block], q = price, delta, vega.
+// Always honours the path window (no separate hot variant: a secondary kernel).
+// =========================================================================================
+struct GreeksF32 { float drift2, vol2, spot, strike, sqrt_t, sigma_t; };   // exponent in log2 units
+struct GreeksF64 { double drift, vol, spot, strike, sqrt_t, sigma_t; };
+
+__device__ __forceinline__ float greeks_spot(const GreeksF32 &o, float z) { return o.spot * __builtin_amdgcn_exp2f(__builtin_fmaf(o.vol2, z, o.drift2)); }
+__device__ __forceinline__ double greeks_spot(const GreeksF64 &o, double z) { return o.spot * exp_f64(__builtin_fma(o.vol, z, o.drift)); }
+
+template <class Opt, class Real>
+__global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Opt o, const Work w, double2 *__restrict__ partials,
+                                                               int pair_stride)
+{
+    constexpr int NPB = npb<Real>::value;
+    const uint32_t stride = gridDim.x * GROUP;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
+        Real z[NPB];
+        block_normals(w.unit_lo + i, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi, z);
+        const uint64_t unit = ((uint64_t)w.unit_hi << 32) | (uint32_t)(w.unit_lo + i);
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) {
+            const uint64_t path = unit * NPB + j;
+            if (path >= w.first_path && path < w.end_path) {
+                const Real st = greeks_spot(o, z[j]);
+                const bool itm = st > o.strike;
+                const double pay = itm ? (double)(st - o.strike) : 0.0;
+                const double dl = itm ? (double)(st / o.spot) : 0.0;
+                const double vg = itm ? (double)(st * (o.sqrt_t * z[j] - o.sigma_t)) : 0.0;
+                acc[0] += pay, acc[1] = __builtin_fma(pay, pay, acc[1]);
+                acc[2] += dl, acc[3] = __builtin_fma(dl, dl, acc[3]);
+                acc[4] += vg, acc[5] = __builtin_fma(vg, vg, acc[5]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        group_sum2(acc[2 * q], acc[2 * q + 1]);
+        store_partial(partials + (size_t)q * pair_stride, acc[2 * q], acc[2 * q + 1]);
+    }
+}
+
+// =========================================================================================
 // Basket call.  Reference device formulas, dp/MonteCarloKernel.cu:74-101:
 //     bt = L g + d;  s_a = S_a exp((r - v_a^2/2) T + v_a sqrt(T) bt_a);
 //     payoff = max(sum_a w_a s_a - K, 0)

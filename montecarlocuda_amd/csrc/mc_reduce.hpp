@@ -68,6 +68,7 @@ __device__ __forceinline__ void group_sum2(double &s, double &q)
         s = ts;
         q = tq;
     }
+    __syncthreads();  // the LDS slots may be reused by a following call (kernels that reduce several pairs)
 }
 
 // Per-workgroup partial: one coalescable 16-byte store.

@@ -165,6 +165,13 @@ class Engine:
     def vanilla(self, opt, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:
         return self._run("vanilla", precision, _as_option(precision, opt), seed, first_path, n_paths)
 
+    def vanilla_greeks(self, opt, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
+        """(price, delta, vega) Estimates from one pass (pathwise derivatives)."""
+        g = _lib.Greeks()
+        check(getattr(lib(), f"mc_vanilla_greeks_run_{precision}")(self._ctx, C.byref(_as_option(precision, opt)), seed,
+                                                                    first_path, n_paths, C.byref(g)))
+        return _estimate(g.price), _estimate(g.delta), _estimate(g.vega)
+
     def basket(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:
         h = _BasketHolder(precision, b)
         return self._run("basket", precision, h.struct, seed, first_path, n_paths)

@@ -76,6 +76,8 @@ void orc_closing(double sum, double sum2, long long n, double discount,
     void orc_dev_vanilla_##X(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,              \
                              uint64_t first_path, uint64_t n_paths, int antithetic,              \
                              REAL *payoffs, orc_result *out);                                    \
+    void orc_dev_vanilla_greeks_##X(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,       \
+                                    uint64_t first_path, uint64_t n_paths, orc_result *out3);    \
     void orc_dev_basket_##X(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,   \
                             const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,                \
                             uint64_t first_path, uint64_t n_paths, int mode,                     \

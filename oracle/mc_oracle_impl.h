@@ -298,6 +298,35 @@ void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
  * g[b*NPB .. b*NPB+NPB-1]; domain BASKET.  The product multiplies only the lower triangle
  * (structural zeros of the factor skipped) -- identical values whenever the upper triangle is
  * zero, which Chol guarantees (dp/MonteCarloHost.c:95). */
+/* Pathwise Greeks of the vanilla call on the product stream (not in the reference):
+ * per path  S_T = S exp(drift + vol z),  I = [S_T > K]:  payoff I (S_T - K),  delta I S_T / S,
+ * vega I S_T (sqrt(T) z - sigma T).  out[0..2] = price, delta, vega (each discounted). */
+void FN(orc_dev_vanilla_greeks)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed, uint64_t first_path,
+                                uint64_t n_paths, orc_result *out)
+{
+    const REAL drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)t);
+    const REAL vol = (REAL)((double)v * sqrt((double)t));
+    const REAL sqrt_t = (REAL)sqrt((double)t), sigma_t = (REAL)((double)v * (double)t);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    REAL z[ORC_NPB];
+    uint64_t have = (uint64_t)-1;
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t p = first_path + i, unit = p / ORC_NPB;
+        if (unit != have) {
+            FN(orc_dev_normals)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
+            have = unit;
+        }
+        REAL zz = z[p % ORC_NPB];
+        REAL st = s * EXP_R(drift + vol * zz);
+        int itm = st > k;
+        double pay = itm ? (double)(st - k) : 0.0, dl = itm ? (double)(st / s) : 0.0;
+        double vg = itm ? (double)(st * (sqrt_t * zz - sigma_t)) : 0.0;
+        acc[0] += pay, acc[1] += pay * pay, acc[2] += dl, acc[3] += dl * dl, acc[4] += vg, acc[5] += vg * vg;
+    }
+    for (int q = 0; q < 3; q++)
+        FN(dev_finish)(acc[2 * q], acc[2 * q + 1], n_paths, exp(-(double)r * (double)t), out + q);
+}
+
 /* Closed-form mean of the geometric-basket control (not in the reference):
  *   G = W prod_a S_a(T)^(w_a / W),  W = sum_a w_a > 0,  is lognormal: ln G ~ N(m, sd^2) with
  *   m = ln W + sum_a wh_a (ln S_a + (r - v_a^2/2) T + v_a sqrt(T) d_a),  wh = w / W,

@@ -84,6 +84,8 @@ def lib() -> C.CDLL:
         f("orc_dev_basket").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R, C.c_uint64,
                                         C.c_uint64, C.c_uint64, C.c_int, RP, res]
         f("orc_dev_cva").argtypes = [R] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, RP, res]
+        f("orc_dev_vanilla_greeks").argtypes = [R] * 5 + [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcResult * 3)]
+        f("orc_dev_vanilla_greeks").restype = None
         f("orc_basket_control_mean").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R]
         f("orc_basket_control_mean").restype = C.c_double
         for nm in ("orc_host_vanilla", "orc_host_basket", "orc_host_cva", "orc_dev_normals",
@@ -196,6 +198,13 @@ def dev_basket(X, b, seed, first, n, want_paths=True, antithetic=False, control=
     getattr(lib(), f"orc_dev_basket_{X}")(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], seed,
                                           first, n, int(antithetic) | (int(control) << 1), ptr, C.byref(r))
     return out, r.as_dict()
+
+
+def dev_vanilla_greeks(X, opt, seed, first, n):
+    """(price, delta, vega) result dicts of the pathwise-Greeks twin."""
+    r = (OrcResult * 3)()
+    getattr(lib(), f"orc_dev_vanilla_greeks_{X}")(opt["s"], opt["k"], opt["r"], opt["v"], opt["t"], seed, first, n, C.byref(r))
+    return [x.as_dict() for x in r]
 
 
 def basket_control_mean(X, b):

@@ -547,3 +547,24 @@ def test_legacy_env_switches_estimators(mc, po):
     assert abs(both[0] - both[3]) < 2e-6 and abs(both[1] - both[4]) < 2e-6        # CPU twin == GPU
     assert both[4] < 0.6 * plain[4]    # tighter CI (only ~2x here: the reference data anti-correlate the assets)
     assert abs(both[3] - plain[3]) < 3.5 / 1.96 * plain[4]                       # same price
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_vanilla_pathwise_greeks(eng, po, X):
+    """Price, delta and vega in one pass: sums against the oracle twin on the same counters
+    (unaligned range), the price leg equal to the pricing kernel's, and all three within their CI of the
+    closed forms  N(d1)  and  S sqrt(T) phi(d1)  at 1e8 paths."""
+    n, first = 50003, 7
+    gp, gd, gv = eng.vanilla_greeks(VAN, n, SEED, first, X)
+    op, od, ov = po.dev_vanilla_greeks(X, VAN, SEED, first, n)
+    rel = 4 * TOL[X]["rel"]
+    for g, o in ((gp, op), (gd, od), (gv, ov)):
+        assert g.n == n and g.sum == pytest.approx(o["sum"], rel=rel) and g.sum2 == pytest.approx(o["sum2"], rel=rel)
+        assert g.expected == pytest.approx(o["expected"], rel=rel) and g.confidence == pytest.approx(o["confidence"], rel=rel)
+    assert gp.sum == pytest.approx(eng.vanilla(VAN, n, SEED, first, X).sum, rel=rel)
+    big = eng.vanilla_greeks(VAN, 10 ** 8, SEED, 0, X)
+    s, k, r, v, t = (VAN[c] for c in "skrvt")
+    d1 = (math.log(s / k) + (r + 0.5 * v * v) * t) / (v * math.sqrt(t))
+    exact = (BS_EXACT, 0.5 * math.erfc(-d1 / math.sqrt(2)), s * math.sqrt(t) * math.exp(-0.5 * d1 * d1) / math.sqrt(2 * math.pi))
+    for g, want in zip(big, exact):
+        assert abs(g.expected - want) < 3.5 / 1.96 * g.confidence, (g.expected, want)
