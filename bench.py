@@ -92,6 +92,31 @@ def cpu_baseline(prod, X, inputs, seconds):
             "host_cores_available": os.cpu_count()}
 
 
+def cpu_all_cores(seconds=2.0):
+    """The product's own CPU twin (libmchost: OpenMP, same Philox stream and estimator as the GPU) on all
+    host cores: the fair many-core figure next to the single-threaded reference."""
+    import ctypes as C
+    path = os.path.join(ROOT, "montecarlocuda_amd", "csrc", "libmchost_f32.so")
+    if not os.path.exists(path):
+        return None
+
+    class OptionData(C.Structure):
+        _fields_ = [(k, C.c_float) for k in "skrvt"]
+
+    class OptionValue(C.Structure):
+        _fields_ = [("Expected", C.c_float), ("Confidence", C.c_float)]
+    L = C.CDLL(path)
+    L.host_vanillaOpt.argtypes = [OptionData, C.c_int]
+    L.host_vanillaOpt.restype = OptionValue
+    o = OptionData(*[VAN[k] for k in "skrvt"])
+    n = 50_000_000
+    t0 = time.perf_counter(); L.host_vanillaOpt(o, n); dt = time.perf_counter() - t0
+    n = int(min(2 ** 31 - 1, max(n, n * seconds / max(dt, 1e-3))))
+    t0 = time.perf_counter(); v = L.host_vanillaOpt(o, n); dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "paths/s", "cores": os.cpu_count(), "kind": "libmchost_f32 (OpenMP CPU twin of the engine)",
+            "sample": f"{n} paths in {dt:.2f} s", "price": float(v.Expected)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -291,6 +316,10 @@ def main():
             out["fp64"] = fp64_side
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds)
+            if prod == "vanilla" and X == "f32":
+                extra = cpu_all_cores()
+                if extra:
+                    out["cpu_all_cores"] = extra
         print(json.dumps(out), flush=True)
     if grouped:
         barrier()
