@@ -89,7 +89,7 @@ def cpu_baseline(prod, X, inputs, seconds):
     return {"value": n * per_unit / dt, "unit": unit, "cores": 1, "kind": "reference" if use_ref else "port",
             "sample": f"{n} paths of the same workload in {dt:.1f} s, single thread (the reference is single-threaded: "
                       f"MonteCarloHost.c:185-229), gcc -O2 -ffp-contract=off",
-            "host_cores_available": os.cpu_count()}
+            "host_cores_available": len(os.sched_getaffinity(0))}
 
 
 def cpu_all_cores(seconds=2.0):
@@ -113,7 +113,7 @@ def cpu_all_cores(seconds=2.0):
     t0 = time.perf_counter(); L.host_vanillaOpt(o, n); dt = time.perf_counter() - t0
     n = int(min(2 ** 31 - 1, max(n, n * seconds / max(dt, 1e-3))))
     t0 = time.perf_counter(); v = L.host_vanillaOpt(o, n); dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "paths/s", "cores": os.cpu_count(), "kind": "libmchost_f32 (OpenMP CPU twin of the engine)",
+    return {"value": n / dt, "unit": "paths/s", "cores": len(os.sched_getaffinity(0)), "kind": "libmchost_f32 (OpenMP CPU twin of the engine)",
             "sample": f"{n} paths in {dt:.2f} s", "price": float(v.Expected)}
 
 
