@@ -58,6 +58,7 @@ def workloads(mc):
         "vanilla_f32": ("vanilla", "f32", VAN, 10 ** 8, 15.5, "European vanilla call, 1 asset, 1e8 paths, fp32 (BASELINE configs[1])"),
         "vanilla_f64": ("vanilla", "f64", VAN, 10 ** 8, 15.5, "European vanilla call, 1 asset, 1e8 paths, fp64"),
         "basket4_f32": ("basket", "f32", lambda: basket_inputs(mc, 4, "f32"), 10 ** 8, f_basket(4), "Basket call, 4 correlated assets, 1e8 paths, fp32 (BASELINE configs[2])"),
+        "basket16_f32": ("basket", "f32", lambda: basket_inputs(mc, 16, "f32"), 125 * 10 ** 6, f_basket(16), "Basket call, 16 correlated assets, 1e9/8 paths per GPU, fp32"),
         "basket16_f64": ("basket", "f64", lambda: basket_inputs(mc, 16, "f64"), 125 * 10 ** 6, f_basket(16), "Basket call, 16 correlated assets, 1e9/8 paths per GPU, fp64 (BASELINE configs[3])"),
         "cva256_f64": ("cva", "f64", CVA, 1250000, 60.0 * 256 + 5, "CVA on vanilla call, 256 dates x 1e7/8 paths per GPU, fp64 (BASELINE configs[4])"),
         "cva256_f32": ("cva", "f32", CVA, 1250000, 60.0 * 256 + 5, "CVA on vanilla call, 256 dates x 1e7/8 paths per GPU, fp32"),

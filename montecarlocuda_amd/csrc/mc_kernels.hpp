@@ -291,11 +291,79 @@ struct BasketArgs {
     int cv;
 };
 
+// Where a basket kernel reads its folded constants from.  Small baskets keep them in SGPRs straight from
+// the kernel arguments; larger ones do not fit the scalar register file (hipcc then "spills" SGPRs into
+// VGPR lanes and pays a v_readlane_b32 -- a full VALU issue slot -- per use: 272 of 870 instructions per
+// trip at n=16 f32), so they are staged once per workgroup into LDS and read back as broadcast
+// ds_reads, which do not occupy the VALU.
+#ifdef MC_AB_BASKET_SGPR   // A/B switch (tools/ab_f64.py): never stage in LDS
+template <class Real, int NA> constexpr bool basket_consts_in_lds() { return false; }
+#else
+template <class Real, int NA> constexpr bool basket_consts_in_lds() { return sizeof(Real) == 4 ? NA > 5 : NA > 3; }
+#endif
+// Whether the LDS reads are additionally pinned every few rows (ConstsLds::fence).  In-process A/B on
+// MI355X (tools/ab_basket.py, profiles/r01_ab_basket_lds.log), kernel time LDS vs SGPR constants:
+//   f32  n=6 -1 %, n=8 -11 %, n=10 -15 % (no fence);  n=12 -15 %, n=16 -20 % (fence every 4 rows; -6 % / -5 % without)
+//   f64  n=4 -4 %, n=8 -11 %, n=12 -4 %, n=16 +-0 (no fence; any fence costs f64 3-9 %: its rows are long enough)
+// Returns the fence period in rows (0 = never).
+#ifdef MC_AB_FENCE_PERIOD
+template <class Real, int NA> constexpr int basket_fence_rows() { return MC_AB_FENCE_PERIOD; }
+#else
+template <class Real, int NA> constexpr int basket_fence_rows() { return sizeof(Real) == 4 && NA >= 11 ? 4 : 0; }
+#endif
+
+template <class Real, int NA>
+struct ConstsArg {  // kernel arguments (SGPRs)
+    const BasketArgs<Real, NA> &o;
+    __device__ __forceinline__ Real m(int i) const { return o.m[i]; }
+    __device__ __forceinline__ Real base(int a) const { return o.base[a]; }
+    __device__ __forceinline__ Real coef(int a) const { return o.coef[a]; }
+    __device__ __forceinline__ Real wg(int a) const { return o.wg[a]; }
+    template <class T> __device__ __forceinline__ void fence(int, T) {}
+};
+template <class Real, int NA>
+struct ConstsLds {  // staged copy: m | base | coef | wg
+    static constexpr int NM = NA * (NA + 1) / 2, COUNT = NM + 3 * NA;
+    const Real *p;
+    int off = 0;  // always 0, but opaque to the compiler (see fence)
+    __device__ __forceinline__ Real m(int i) const { return p[off + i]; }
+    __device__ __forceinline__ Real base(int a) const { return p[off + NM + a]; }
+    __device__ __forceinline__ Real coef(int a) const { return p[off + NM + NA + a]; }
+    __device__ __forceinline__ Real wg(int a) const { return p[off + NM + 2 * NA + a]; }
+    // The staged constants never change, so left alone hipcc hoists every ds_read out of the path loop
+    // (or to the top of a trip) and pins ~140 values in VGPRs -- 168 VGPRs and scratch at n=16.  Tying
+    // the read offset to the value computed just before (a row's exponent) keeps each row's reads next to
+    // the row that uses them.
+    template <class T> __device__ __forceinline__ void fence(int row, T dep)
+    {
+        constexpr int PERIOD = basket_fence_rows<Real, NA>();
+        if (PERIOD > 0 && row % (PERIOD > 0 ? PERIOD : 1) == 0)  // row is a compile-time constant after unrolling
+            asm volatile("" : "+v"(off) : "v"(dep));
+    }
+    // Thread 0 writes every constant with a compile-time index (SGPR -> v_mov -> ds_write): a per-thread
+    // index into the kernel-argument struct would make hipcc copy the whole struct to scratch first.
+    __device__ __forceinline__ static void stage(Real *lds, const BasketArgs<Real, NA> &o)
+    {
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < NM; ++i)
+                lds[i] = o.m[i];
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                lds[NM + a] = o.base[a];
+                lds[NM + NA + a] = o.coef[a];
+                lds[NM + 2 * NA + a] = o.wg[a];
+            }
+        }
+        __syncthreads();
+    }
+};
+
 __device__ __forceinline__ float exp_model(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ double exp_model(double x) { return exp_f64(x); }
 
-template <class Real, int NA, bool ANTI>
-__device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const Work &w, uint32_t c0)
+template <class Real, int NA, bool ANTI, class Consts>
+__device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, Consts k, const Work &w, uint32_t c0)
 {
     constexpr int NPB = npb<Real>::value;
     constexpr int NBLK = (NA + NPB - 1) / NPB;
@@ -309,18 +377,23 @@ __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, const
             g[b * NPB + j] = z[j];
     }
     Real basket = 0, mirror = 0, lg = o.cg, lgm = o.cg;
+    k.fence(0, g[0]);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        Real x = o.base[a];
+        const Real base = k.base(a), coef = k.coef(a);
+        Real x = base;
 #pragma unroll
         for (int b = 0; b <= a; ++b)
-            x = fma_r(o.m[a * (a + 1) / 2 + b], g[b], x);
-        basket = fma_r(o.coef[a], exp_model(x), basket);
-        lg = fma_r(o.wg[a], x, lg);
+            x = fma_r(k.m(a * (a + 1) / 2 + b), g[b], x);
+        basket = fma_r(coef, exp_model(x), basket);
+        if (o.cv)
+            lg = fma_r(k.wg(a), x, lg);
+        k.fence(a + 1, x);
         if (ANTI) {  // exponent of the mirrored path: base - m g = 2 base - x
-            const Real xm = fma_r((Real)-1, x, 2 * o.base[a]);
-            mirror = fma_r(o.coef[a], exp_model(xm), mirror);
-            lgm = fma_r(o.wg[a], xm, lgm);
+            const Real xm = fma_r((Real)-1, x, 2 * base);
+            mirror = fma_r(coef, exp_model(xm), mirror);
+            if (o.cv)
+                lgm = fma_r(k.wg(a), xm, lgm);
         }
     }
     const Real v = basket - o.strike;
@@ -349,8 +422,16 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
+    constexpr bool IN_LDS = basket_consts_in_lds<Real, NA>();
+    __shared__ Real lds_consts[IN_LDS ? ConstsLds<Real, NA>::COUNT : 1];
+    if (IN_LDS)
+        ConstsLds<Real, NA>::stage(lds_consts, o);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
-        const Real p = basket_path<Real, NA, ANTI>(o, w, w.unit_lo + i);
+        Real p;
+        if constexpr (IN_LDS)
+            p = basket_path<Real, NA, ANTI>(o, ConstsLds<Real, NA>{lds_consts}, w, w.unit_lo + i);
+        else
+            p = basket_path<Real, NA, ANTI>(o, ConstsArg<Real, NA>{o}, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests
@@ -369,8 +450,8 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 bcast(float x) { return (f2){x, x}; }
 
-template <int NA, bool ANTI>
-__device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, const Work &w, uint32_t cA, uint32_t cB)
+template <int NA, bool ANTI, class Consts>
+__device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, Consts k, const Work &w, uint32_t cA, uint32_t cB)
 {
     constexpr int NBLK = (NA + 3) / 4;
     f2 g[NBLK * 4];
@@ -394,18 +475,23 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, co
         g[4 * b + 3] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
     }
     f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f}, lg = bcast(o.cg), lgm = bcast(o.cg);
+    k.fence(0, g[0].x);
 #pragma unroll
     for (int a = 0; a < NA; ++a) {
-        f2 x = bcast(o.base[a]);
+        const float base = k.base(a), coef = k.coef(a);
+        f2 x = bcast(base);
 #pragma unroll
         for (int b = 0; b <= a; ++b)
-            x = pk_fma(bcast(o.m[a * (a + 1) / 2 + b]), g[b], x);
-        basket = pk_fma(bcast(o.coef[a]), (f2){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}, basket);
-        lg = pk_fma(bcast(o.wg[a]), x, lg);
+            x = pk_fma(bcast(k.m(a * (a + 1) / 2 + b)), g[b], x);
+        basket = pk_fma(bcast(coef), (f2){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}, basket);
+        if (o.cv)
+            lg = pk_fma(bcast(k.wg(a)), x, lg);
+        k.fence(a + 1, x.x);
         if (ANTI) {  // mirrored path: base - m g = 2 base - x
-            const f2 xm = pk_fma(bcast(-1.0f), x, bcast(2.0f * o.base[a]));
-            mirror = pk_fma(bcast(o.coef[a]), (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
-            lgm = pk_fma(bcast(o.wg[a]), xm, lgm);
+            const f2 xm = pk_fma(bcast(-1.0f), x, bcast(2.0f * base));
+            mirror = pk_fma(bcast(coef), (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
+            if (o.cv)
+                lgm = pk_fma(bcast(k.wg(a)), xm, lgm);
         }
     }
     // the geometric mean never exceeds the arithmetic one, so the same 2^-k scale keeps it in [0,1]
@@ -432,9 +518,19 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
     const uint32_t full_trips = w.n_units / (2 * stride);  // trips in which every lane has both units
     double acc_s = 0.0, acc_q = 0.0;
     f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
+    constexpr bool IN_LDS = basket_consts_in_lds<float, NA>();
+    __shared__ float lds_consts[IN_LDS ? ConstsLds<float, NA>::COUNT : 1];
+    if (IN_LDS)
+        ConstsLds<float, NA>::stage(lds_consts, o);
+    const auto pair = [&](uint32_t cA, uint32_t cB) __attribute__((always_inline)) {
+        if constexpr (IN_LDS)
+            return basket_pair_f32<NA, ANTI>(o, ConstsLds<float, NA>{lds_consts}, w, cA, cB);
+        else
+            return basket_pair_f32<NA, ANTI>(o, ConstsArg<float, NA>{o}, w, cA, cB);
+    };
     uint32_t i = gtid;
     for (uint32_t trip = 0; trip < full_trips; ++trip, i += 2 * stride) {
-        const f2 p = basket_pair_f32<NA, ANTI>(o, w, w.unit_lo + i, w.unit_lo + i + stride);
+        const f2 p = pair(w.unit_lo + i, w.unit_lo + i + stride);
         s2 += p;
         q2 = pk_fma(p, p, q2);
         if (out) {  // wave-uniform: per-path dump for the parity tests
@@ -450,7 +546,7 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
     }
     if (i < w.n_units) {  // the partial last trip: unit i, and unit i + stride where it exists
         const bool has_b = i + stride < w.n_units;
-        f2 p = basket_pair_f32<NA, ANTI>(o, w, w.unit_lo + i, w.unit_lo + (has_b ? i + stride : i));
+        f2 p = pair(w.unit_lo + i, w.unit_lo + (has_b ? i + stride : i));
         if (!has_b)
             p.y = 0.0f;
         s2 += p;

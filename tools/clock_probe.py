@@ -13,7 +13,7 @@ import bench  # noqa: E402
 import montecarlocuda_amd as mc  # noqa: E402
 
 which = sys.argv[1:] or ["vanilla_f32", "vanilla_f64", "basket4_f32", "basket16_f64", "cva256_f64", "cva256_f32"]
-SIZES = {"vanilla_f32": 2 * 10 ** 10, "vanilla_f64": 4 * 10 ** 9, "basket4_f32": 5 * 10 ** 9, "basket16_f64": 3 * 10 ** 8,
+SIZES = {"vanilla_f32": 2 * 10 ** 10, "vanilla_f64": 4 * 10 ** 9, "basket4_f32": 5 * 10 ** 9, "basket16_f64": 3 * 10 ** 8, "basket16_f32": 10 ** 9,
          "cva256_f64": 10 ** 7, "cva256_f32": 4 * 10 ** 7}
 eng = mc.Engine(0)
 W = bench.workloads(mc)
