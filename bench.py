@@ -137,6 +137,9 @@ def main():
                     help="nccl = RCCL over xGMI (default). gloo = rehearsal of the multi-rank logic on a box with fewer "
                          "GPUs than ranks: ranks share GPUs (LOCAL_RANK mod device count), triples are reduced on the host")
     ap.add_argument("--fp64-steps", type=int, default=100, help="steps of the fp64 side measurement (0 = skip)")
+    ap.add_argument("--exclusive-launches", type=int, default=50,
+                    help="after the timed region, this many launches one at a time on one stream, each timed on the device: "
+                         "the kernel's duration without a neighbour (roofline.exclusive); 0 = skip")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
@@ -237,6 +240,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # The dominant kernel alone on the device (outside the timed region): with 2 streams the timed launches
+    # overlap their neighbours, which stretches every per-kernel duration.
+    exclusive = None
+    if args.exclusive_launches > 0:
+        n_ex = min(args.exclusive_launches, 512)
+        solo = torch.zeros((n_ex, 3), dtype=torch.float64, device="cuda")
+        eng.profile(1)
+        for i in range(n_ex):
+            eng.launch(prod, X, structs[0][0], seed, (W + K + i) * step_total + shard_first, shard_count, solo[i].data_ptr(),
+                       streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        ex_samples, ex_ms = eng.profile_read()
+        eng.profile(0)
+        if ex_samples:
+            exclusive = (ex_samples, ex_ms / ex_samples * 1e-3)
+
     # BASELINE.json's metric names both precisions: the same step in fp64, measured after (and
     # outside) the headline region, reported as a side figure.
     fp64_side = None
@@ -311,6 +330,13 @@ def main():
                                  "beside the next launch's head), so per-kernel durations exceed the step period"
                                  if len(engines) > 1 else "one launch at a time"},
         }
+        if exclusive:
+            ex_n, ex_s = exclusive
+            ex_ach = flop_per_path * shard_count / ex_s / 1e12
+            out["roofline"]["exclusive"] = {
+                "avg_kernel_us": ex_s * 1e6, "launches": ex_n, "achieved": ex_ach, "frac": ex_ach / PEAK_TFLOPS[X],
+                "kernel_paths_per_s": shard_count / ex_s,
+                "note": "the same kernel, one launch at a time on one stream after the timed region"}
         if prod == "vanilla":
             out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
         if fp64_side:

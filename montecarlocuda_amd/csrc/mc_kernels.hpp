@@ -170,6 +170,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, 
 template <class Opt, class Real, bool ANTI>
 __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work w, double2 *__restrict__ partials)
 {
+    stage_tables<Real>();
     constexpr int NPB = npb<Real>::value;
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Opt o, cons
                                                                double2 *__restrict__ partials,
                                                                Real *__restrict__ out, Real out_scale)
 {
+    stage_tables<Real>();
     constexpr int NPB = npb<Real>::value;
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
@@ -238,6 +240,7 @@ template <class Opt, class Real>
 __global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Opt o, const Work w, double2 *__restrict__ partials,
                                                                int pair_stride)
 {
+    stage_tables<Real>();
     constexpr int NPB = npb<Real>::value;
     const uint32_t stride = gridDim.x * GROUP;
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -299,12 +302,21 @@ struct BasketArgs {
 #ifdef MC_AB_BASKET_SGPR   // A/B switch (tools/ab_f64.py): never stage in LDS
 template <class Real, int NA> constexpr bool basket_consts_in_lds() { return false; }
 #else
-template <class Real, int NA> constexpr bool basket_consts_in_lds() { return sizeof(Real) == 4 ? NA > 5 : NA > 3; }
+#ifndef MC_AB_F64_LDS_MAX
+#define MC_AB_F64_LDS_MAX 9
+#endif
+template <class Real, int NA> constexpr bool basket_consts_in_lds()
+{
+    return sizeof(Real) == 4 ? NA > 5 : (NA > 3 && NA <= MC_AB_F64_LDS_MAX);
+}
 #endif
 // Whether the LDS reads are additionally pinned every few rows (ConstsLds::fence).  In-process A/B on
 // MI355X (tools/ab_basket.py, profiles/r01_ab_basket_lds.log), kernel time LDS vs SGPR constants:
 //   f32  n=6 -1 %, n=8 -11 %, n=10 -15 % (no fence);  n=12 -15 %, n=16 -20 % (fence every 4 rows; -6 % / -5 % without)
-//   f64  n=4 -4 %, n=8 -11 %, n=12 -4 %, n=16 +-0 (no fence; any fence costs f64 3-9 %: its rows are long enough)
+//   f64  n=4 -7 %, n=7 -10 %, n=8 -12 %, n=9 -11 %, n=10 +1 %, n=12 +2 %, n=16 +6 % (no fence; a fence costs f64
+//        3-9 %).  From n=10 hipcc keeps the staged constants in > 256 registers: one wave per SIMD, every LDS
+//        latency exposed; asking for more waves (amdgpu_waves_per_eu) turns that into scratch spills, so those
+//        sizes stay on the SGPR path.
 // Returns the fence period in rows (0 = never).
 #ifdef MC_AB_FENCE_PERIOD
 template <class Real, int NA> constexpr int basket_fence_rows() { return MC_AB_FENCE_PERIOD; }
@@ -419,6 +431,7 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA
                                                        double2 *__restrict__ partials,
                                                        Real *__restrict__ out)
 {
+    stage_tables<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
@@ -583,6 +596,7 @@ template <class Real, bool ANTI>
 __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real> o, const Work w,
                                                            double2 *__restrict__ partials, Real *__restrict__ out)
 {
+    stage_tables<Real>();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
     constexpr int NPB = npb<Real>::value;
@@ -702,8 +716,10 @@ __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const Cv
     const double spot = exp_f64(ln_spot);
     const double d1 = __builtin_fma(W, st.g, st.e1), d2 = __builtin_fma(W, st.g, st.e2);
     const double A = 0.39894228040143267793994605993438 * exp_f64(__builtin_fma(-0.5 * d1, d1, ln_spot));
-    const double t1 = A * hastings_poly(recip_pos(__builtin_fma(0.2316419, fabs(d1), 1.0)));
-    const double t2 = A * hastings_poly(recip_pos(__builtin_fma(0.2316419, fabs(d2), 1.0)));
+    double k1, k2;
+    recip2_pos(__builtin_fma(0.2316419, fabs(d1), 1.0), __builtin_fma(0.2316419, fabs(d2), 1.0), k1, k2);
+    const double t1 = A * hastings_poly(k1);
+    const double t2 = A * hastings_poly(k2);
     const double a = d1 > 0 ? spot - t1 : t1;
     const double b = d2 > 0 ? st.disc - t2 : t2;
     return a - b;
@@ -750,6 +766,7 @@ template <class Real, bool ANTI>
 __global__ __launch_bounds__(GROUP) void cva_kernel(const CvaArgs<Real> o, const Work w,
                                                     double2 *__restrict__ partials, Real *__restrict__ out)
 {
+    stage_tables<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
@@ -771,6 +788,7 @@ template <class Real>
 __global__ __launch_bounds__(GROUP) void normals_kernel(const Work w, uint32_t block, uint32_t domain,
                                                         Real *__restrict__ out)
 {
+    stage_tables<Real>();
     constexpr int NPB = npb<Real>::value;
     const uint32_t stride = gridDim.x * GROUP;
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {

@@ -14,6 +14,16 @@
 //   sincos_turns(u)    ~36                quadrant from rint(4u), Taylor to y^15 / y^16 on |y| <= 1/2
 //   recip_pos(d)       ~5                 v_rcp_f64 + two Newton steps
 //   exp_f64(x)         ~19                n = rint(x log2 e), two-step reduction, Taylor to r^13, v_ldexp_f64
+//                      ~15 + ds_read      (default) 64-entry table of 2^(j/64), Taylor to r^5
+//
+// The two functions inside Box-Muller additionally have table-driven forms (the default), which trade
+// polynomial length for one 16-byte LDS read each -- LDS reads do not occupy the VALU:
+//   neg2log_unit_tab(u) ~16 + ds_read     128-entry table over the reduced mantissa: -2 ln m = t_i + S(m c2_i + 2),
+//                                         S a 7-term series on |r'| <= 2^-7            (replaces log_unit + a multiply)
+//   sincos_turns_tab    ~21 + ds_read     256-entry table of (sin, cos) at the slot centres, angle-addition with
+//                                         3-term series on |b| <= 2 pi / 512            (replaces sincos_turns)
+// tools/check_f64_tables.c (host twin, vs 80-bit libm over 4e7 inputs): -2 ln u within 2.8e-16 relative,
+// sin/cos within 1.1e-16 absolute, the normal within 1.8e-15 absolute -- the same as the polynomial forms.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,9 +51,43 @@ MC_COEF_STORAGE double SIN_Q[8] = {1.5707963267948966,     -0.6459640975062463, 
 MC_COEF_STORAGE double COS_Q[8] = {-1.2337005501361697,     0.25366950790104803,   -0.02086348076335296,   0.0009192602748394266,
                                 -2.5202042373060607e-05, 4.710874778818172e-07, -6.386603083791852e-09, 6.565963114979473e-11};
 
+// ---- lookup tables (LDS) --------------------------------------------------------------------------
+struct alignas(16) F64Pair { double x, y; };
+// rows 0..127: {c2_i, t_i} of the log table; rows 128..383: {sin, cos} at the centre of angle slot i;
+// rows 384..415: 2^(j/64), j = 0..63, two per row
+// (tools/gen_f64_tables.py; 60-digit arithmetic, rounded once)
+__device__ const F64Pair F64_TABLES_ROM[416] = {
+#include "mc_tables_f64.inc"
+};
+__shared__ F64Pair f64_tables[416];  // 6.5 KB of LDS per workgroup, filled by stage_f64_tables()
+
+// Every fp64 kernel calls this first (all threads; ends in a barrier).
+__device__ __forceinline__ void stage_f64_tables()
+{
+    for (int i = threadIdx.x; i < 416; i += blockDim.x)
+        f64_tables[i] = F64_TABLES_ROM[i];
+    __syncthreads();
+}
+
 // e^x for finite x (underflows to 0 through v_ldexp_f64; these kernels never overflow it):
 // x = n ln2 + r, |r| <= ln2/2, Taylor to r^13: 19 instructions, max error 0.86 ulp.
-#ifndef MC_AB_OCML_EXP
+#if !defined(MC_AB_OCML_EXP) && !defined(MC_AB_EXP_POLY) && !defined(MC_AB_NO_TABLES)
+// Table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128;  e^x = 2^e * T_j * (1 + r + r^2/2 + ... + r^5/120).
+// 15 instructions + one 8-byte LDS read; max error 1.03 ulp (tools/check_f64_tables.c).
+__device__ __forceinline__ double exp_f64(double x)
+{
+    const double n = __builtin_rint(x * 92.332482616893656877);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01 / 64, x);
+    r = __builtin_fma(n, -1.90821492927058770002e-10 / 64, r);
+    const int ni = (int)n;
+    const double T = reinterpret_cast<const double *>(f64_tables + 384)[ni & 63];
+    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
+    p = __builtin_fma(r, p, 1.0 / 6);
+    p = __builtin_fma(r, p, 0.5);
+    p = __builtin_fma(r, p, 1.0);
+    return __builtin_amdgcn_ldexp(__builtin_fma(T, r * p, T), ni >> 6);
+}
+#elif !defined(MC_AB_OCML_EXP)
 __device__ __forceinline__ double exp_f64(double x)
 {
     const double n = __builtin_rint(x * 1.4426950408889634074);
@@ -75,6 +119,20 @@ __device__ __forceinline__ double recip_pos(double d)
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-d, r, 1.0);
     return __builtin_fma(r, e, r);
+}
+
+// 1/a and 1/b from ONE v_rcp_f64 (a 16-cycle instruction): r = 1/(a b), 1/a = r b, 1/b = r a.
+// For operands whose product stays far from over/underflow (CVA: both in [1, 3]).
+__device__ __forceinline__ void recip2_pos(double a, double b, double &ra, double &rb)
+{
+#ifdef MC_AB_TWO_RCP
+    ra = recip_pos(a);
+    rb = recip_pos(b);
+#else
+    const double r = recip_pos(a * b);
+    ra = r * b;
+    rb = r * a;
+#endif
 }
 
 // natural log of a positive normal double
@@ -112,9 +170,54 @@ __device__ __forceinline__ double sqrt_pos(double x)
     g = __builtin_fma(g, r, g);
     h = __builtin_fma(h, r, h);
     double d = __builtin_fma(-g, g, x);
+#ifdef MC_AB_SQRT_LONG   // ocml's second residual step (correct rounding); the first already gives < 1 ulp
     g = __builtin_fma(d, h, g);
     d = __builtin_fma(-g, g, x);
+#endif
     return __builtin_fma(d, h, g);
+}
+
+// ---- table-driven forms of the Box-Muller pieces -------------------------------------------------
+// -2 ln(u) for a positive normal double.
+// u = 2^k m, m in [sqrt(1/2), sqrt(2)) as in log_unit; slot i = top 7 bits of the shifted mantissa;
+// r' = m c2_i + 2 = -2 (m c_i - 1), |r'| <= 2^-7;  -2 ln m = t_i + r' + r'^2/4 + r'^3/12 + ... + r'^7/448.
+// The slot that contains m = 1 has c = 1, t = 0, so u -> 1 keeps its relative accuracy.
+__device__ __forceinline__ double neg2log_unit_tab(double u)
+{
+    const int h = __double2hiint(u) - 0x3fe6a09e;
+    const int k = h >> 20;
+    const double m = __hiloint2double(__double2hiint(u) - (k << 20), __double2loint(u));
+    const F64Pair e = f64_tables[(h >> 13) & 0x7f];
+    const double r = __builtin_fma(m, e.x, 2.0);
+    double p = __builtin_fma(r, 1.0 / 448, 1.0 / 192);
+    p = __builtin_fma(r, p, 1.0 / 80);
+    p = __builtin_fma(r, p, 1.0 / 32);
+    p = __builtin_fma(r, p, 1.0 / 12);
+    p = __builtin_fma(r, p, 0.25);
+    const double small = __builtin_fma(r * r, p, r);
+    const double big = __builtin_fma((double)k, -1.3862943611198906188, e.y);
+    return big + small;
+}
+
+// (sin, cos) of 2 pi u for the 52-bit uniform u = (J + 1/2) 2^-52 given by its Philox words (J = hi:lo >> 12).
+// Slot i = top 8 bits of J with centre a_i = 2 pi (i + 1/2)/256; b = 2 pi u - a_i, |b| <= 2 pi/512, is formed
+// exactly up to one rounding from the low 44 bits; then sin(a+b), cos(a+b) by angle addition.
+__device__ __forceinline__ void sincos_turns_tab(uint32_t lo, uint32_t hi, double &sin_out, double &cos_out)
+{
+    const F64Pair e = f64_tables[128 + (hi >> 24)];
+    const uint32_t mant_lo = __builtin_amdgcn_alignbit(hi, lo, 12);
+    const uint32_t mant_hi = ((hi >> 12) & 0xfffu) | 0x3ff00000u;
+    const double y = __hiloint2double((int)mant_hi, (int)mant_lo) - (1.0 + 0x1p-9);   // (J mod 2^44) 2^-52 - 2^-9
+    const double b = __builtin_fma(y, 6.283185307179586477, 6.283185307179586477 * 0x1p-53);
+    const double z = b * b;
+    double ps = __builtin_fma(z, -1.0 / 5040, 1.0 / 120);
+    ps = __builtin_fma(z, ps, -1.0 / 6);
+    const double sb = __builtin_fma(z * b, ps, b);       // sin b
+    double pc = __builtin_fma(z, -1.0 / 720, 1.0 / 24);
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cm = z * pc;                            // cos b - 1
+    sin_out = e.x + __builtin_fma(e.x, cm, e.y * sb);
+    cos_out = e.y + __builtin_fma(e.y, cm, -(e.x * sb));
 }
 
 // (sin, cos) of 2*pi*u for u in [0, 1]: quadrant q = rint(4u), y = 4u - q in [-1/2, 1/2]

@@ -88,6 +88,8 @@ __device__ __forceinline__ double u01_f64(uint32_t lo, uint32_t hi)
     return __hiloint2double((int)mant_hi, (int)mant_lo) + (-1.0 + 0x1p-53);
 }
 
+// Kernels that draw fp64 normals call stage_tables<double>() first (LDS tables of mc_math_f64.hpp).
+#ifdef MC_AB_NO_TABLES   // A/B switch (tools/ab_f64.py): polynomial-only log and sincos
 __device__ __forceinline__ void box_muller_f64(const u32x4 r, double &z_cos, double &z_sin)
 {
     const double ua = u01_f64(r.x, r.y);
@@ -98,6 +100,22 @@ __device__ __forceinline__ void box_muller_f64(const u32x4 r, double &z_cos, dou
     z_cos = radius * c;
     z_sin = radius * s;
 }
+template <class Real> __device__ __forceinline__ void stage_tables() {}
+#else
+__device__ __forceinline__ void box_muller_f64(const u32x4 r, double &z_cos, double &z_sin)
+{
+    const double radius = sqrt_pos(neg2log_unit_tab(u01_f64(r.x, r.y)));
+    double s, c;
+    sincos_turns_tab(r.z, r.w, s, c);  // angle 2*pi*u01_f64(r.z, r.w)
+    z_cos = radius * c;
+    z_sin = radius * s;
+}
+template <class Real> __device__ __forceinline__ void stage_tables()
+{
+    if constexpr (sizeof(Real) == 8)
+        stage_f64_tables();
+}
+#endif
 
 template <class Real> struct npb;           // normals per Philox block
 template <> struct npb<float> { static constexpr int value = 4; };

@@ -5,6 +5,14 @@ import sys
 
 import pytest
 
+# This image carries two ROCm runtimes with the same sonames (/opt/rocm and the copy bundled in torch/lib).
+# Whichever libamdhip64 is loaded first serves the whole process; torch only finds the device through its
+# own copy, so tests that use torch next to libmc_mi355x.so need torch loaded first.
+try:
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -41,6 +41,8 @@ def test_bench_contract_single_gpu():
     r = d["roofline"]
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and 0 < r["frac"] < 1
     assert r["achieved"] == pytest.approx(15.5 * 1e8 / (r["avg_kernel_us"] * 1e-6) / 1e12, rel=1e-9)
+    ex = r["exclusive"]      # the kernel alone on the device: no slower than when it shares the device
+    assert ex["launches"] == 50 and 0 < ex["avg_kernel_us"] <= r["avg_kernel_us"] * 1.05 and 0 < ex["frac"] < 1
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 1e6
     assert abs(d["fp64"]["price"] - BS) < 0.05
@@ -59,3 +61,19 @@ def test_bench_two_ranks_share_the_gpu(scaling):
     assert d["config"]["paths_per_gpu_per_step"] == (10 ** 8 if scaling == "weak" else 5 * 10 ** 7)
     assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]      # every path counted exactly once across ranks
     assert "cpu_baseline" not in d
+
+
+def test_bench_rccl_plumbing_world_of_one():
+    """The exact launch line the driver uses for N > 1 (torch.distributed.run + RCCL), with one rank:
+    process-group creation on the device, bucketed asynchronous all-reduces of the triple rows, the
+    device barrier and the MAX over ranks all run through RCCL."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "5",
+           "--cpu-seconds", "0", "--fp64-steps", "4"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = _json_line(out.stdout)
+    assert d["n_gpus"] == 1 and d["paths_priced"] == 60 * 10 ** 8
+    assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]
+    assert d["value"] > 1e11
