@@ -20,4 +20,6 @@ run write WRITE_SIZE &&
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_TRANS_F32 SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY &&
 run sq2 SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_LDS &&
 run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+# LDS behaviour of the table lookups (fp64 kernels); counter names vary between ASICs, so this pass may fail alone
+run lds SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT || true
 find "$OUT" -name "*counter_collection.csv" | head

@@ -51,6 +51,9 @@ for k in sorted(acc):
     if "SQ_ACTIVE_INST_VALU" in avg and "SQ_BUSY_CYCLES" in avg:
         lines.append(f"    -> SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = {avg['SQ_ACTIVE_INST_VALU']/avg['SQ_WAVE_CYCLES']:.3f}"
                      f"; SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES = {avg['SQ_ACTIVE_INST_ANY']/avg['SQ_WAVE_CYCLES']:.3f}")
+    if "SQ_LDS_BANK_CONFLICT" in avg and "SQ_ACTIVE_INST_LDS" in avg and avg["SQ_ACTIVE_INST_LDS"]:
+        lines.append(f"    -> LDS: bank-conflict cycles / active LDS cycles = {avg['SQ_LDS_BANK_CONFLICT']/avg['SQ_ACTIVE_INST_LDS']:.3f}"
+                     + (f"; active LDS cycles / SQ busy cycles = {avg['SQ_ACTIVE_INST_LDS']/avg['SQ_BUSY_CYCLES']:.3f}" if "SQ_BUSY_CYCLES" in avg else ""))
 text = "\n".join(lines)
 print(text)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
