@@ -337,6 +337,20 @@ def main():
                 "avg_kernel_us": ex_s * 1e6, "launches": ex_n, "achieved": ex_ach, "frac": ex_ach / PEAK_TFLOPS[X],
                 "kernel_paths_per_s": shard_count / ex_s,
                 "note": "the same kernel, one launch at a time on one stream after the timed region"}
+        if (prod, X) == ("vanilla", "f32"):
+            # SURVEY 8d's second fraction: the issue-slot ceiling of this kernel's instruction mix.  Per wave-trip
+            # (4 paths per lane) the ISA has 56 full-rate VALU instructions (4.1-4.2 cycles each next to multiplies,
+            # tools/ubench) and 12 transcendentals (8.1-8.3 cycles); with the lower ends 326.8 cycles; 1024 SIMDs x
+            # 64 lanes at the clock tools/clock_probe.py measures inside this kernel (2.39 GHz).
+            cycles, clock = 56 * 4.1 + 12 * 8.1, 2.39e9
+            ceiling = 1024 * 64 * 4 / cycles * clock
+            best = max(out["roofline"]["kernel_paths_per_s"] or 0, (exclusive and shard_count / exclusive[1]) or 0, value / world)
+            out["roofline"]["issue_model"] = {
+                "cycles_per_wave_trip": cycles, "paths_per_wave_trip": 256, "clock_hz": clock,
+                "ceiling_paths_per_s": ceiling, "achieved_paths_per_s": best, "frac": best / ceiling,
+                "note": "ceiling of the instruction mix actually issued (Philox is integer work and transcendentals are "
+                        "half-rate, so the flop fraction above cannot approach 1); achieved = best of the per-GPU whole-job "
+                        "rate and the two per-kernel rates"}
         if prod == "vanilla":
             out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
         if fp64_side:
