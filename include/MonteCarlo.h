@@ -100,6 +100,12 @@ OptionValue host_cvaEquityOption(CVA *cva, int path);
 void Chol(mc_real c[N][N], mc_real a[N][N]);
 void printOption(OptionData o);
 void printMultiOpt(MultiOptionData *o);
+/* helpers the reference's host file leaves visible (MonteCarloHost.c:20,31,67,111; basketOpt.cu:21 declares
+ * randMinMax): row-major matrices, randMinMax draws from libc's rand() */
+void printVect(mc_real *vect, int c);
+void printMat(mc_real *mat, int r, int c);
+void prodMat(mc_real *first, mc_real *second, mc_real *result, int f_rows, int f_cols, int s_cols);
+mc_real randMinMax(mc_real min, mc_real max);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,41 @@ void Chol(mc_real c[N][N], mc_real a[N][N])
 #endif
 }
 
+/* ---- small helpers the reference's host file also exports (MonteCarloHost.c:20,31,67,111) -----
+ * Not used by the estimators here; kept so that a driver declaring them (basketOpt.cu:21 declares
+ * randMinMax) links against this library unchanged. */
+static void print_rows(const mc_real *a, int rows, int cols)
+{
+    for (int i = 0; i < rows; ++i) {
+        printf("\n!\t");
+        for (int j = 0; j < cols; ++j)
+            printf("\t%f\t", (double)a[(size_t)i * cols + j]);
+        printf("\t!");
+    }
+    printf("\n\n");
+}
+void printVect(mc_real *vect, int c) { print_rows(vect, 1, c); }
+void printMat(mc_real *mat, int r, int c) { print_rows(mat, r, c); }
+
+/* result (f_rows x s_cols) = first (f_rows x f_cols) * second (f_cols x s_cols), row-major, accumulated in mc_real */
+void prodMat(mc_real *first, mc_real *second, mc_real *result, int f_rows, int f_cols, int s_cols)
+{
+    for (int i = 0; i < f_rows; ++i)
+        for (int j = 0; j < s_cols; ++j) {
+            mc_real acc = 0;
+            for (int k = 0; k < f_cols; ++k)
+                acc += first[(size_t)i * f_cols + k] * second[(size_t)k * s_cols + j];
+            result[(size_t)i * s_cols + j] = acc;
+        }
+}
+
+/* uniform in [min, max] from libc's rand(), the reference's convention x = rand()/RAND_MAX */
+mc_real randMinMax(mc_real min, mc_real max)
+{
+    const mc_real x = (mc_real)rand() / (mc_real)RAND_MAX;
+    return max * x + ((mc_real)1 - x) * min;
+}
+
 /* ---- printers (same content as MonteCarloHost.c:42-65, own wording) ------------------------ */
 void printOption(OptionData o)
 {

@@ -137,3 +137,21 @@ def test_antithetic_cpu_twin_matches_oracle(po):
     c = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6, n_grid=25)
     _, o = po.dev_cva("f64", c, SEED, 0, 3001, want_paths=False, antithetic=True)
     assert ce == pytest.approx(o["expected"], rel=1e-12) and cci == pytest.approx(o["confidence"], rel=1e-11)
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_small_host_helpers(po, X):
+    """prodMat / randMinMax, which the reference's host file also exports (MonteCarloHost.c:67,111)."""
+    L, R = load(po, X)[0], (C.c_double if X == "f64" else C.c_float)
+    a = np.arange(6, dtype=R).reshape(2, 3) + 1
+    b = (np.arange(12, dtype=R).reshape(3, 4) - 5) / 3
+    out = np.zeros((2, 4), dtype=R)
+    ptr = lambda m: m.ctypes.data_as(C.POINTER(R))   # noqa: E731
+    L.prodMat.argtypes = [C.POINTER(R)] * 3 + [C.c_int] * 3
+    L.prodMat.restype = None
+    L.prodMat(ptr(a), ptr(b), ptr(out), 2, 3, 4)
+    np.testing.assert_allclose(out, a.astype(np.float64) @ b.astype(np.float64), rtol=1e-6 if X == "f32" else 1e-14)
+    L.randMinMax.argtypes = [R, R]
+    L.randMinMax.restype = R
+    draws = [L.randMinMax(-2.0, 3.0) for _ in range(200)]
+    assert all(-2.0 <= d <= 3.0 for d in draws) and len(set(draws)) > 150
