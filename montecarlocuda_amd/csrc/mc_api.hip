@@ -714,17 +714,27 @@ template <class Real>
 static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
                              const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot)
 {
-    const int n = o.n, n_tri = n * (n + 1) / 2;
+    // layout of BasketDyn::consts: 4 x 4 tiles of the folded lower-triangular matrix, block-row by block-row
+    // (tile (A, c4) = 16 reals, index 4 j + r = m[4A + r][4 c4 + j], zero outside the triangle / beyond n),
+    // then base, coef, wg padded with zeros to 4 nb entries
+    const int n = o.n, nb = (n + 3) / 4, np = 4 * nb;
+    const size_t n_tiles = (size_t)8 * nb * (nb + 1);
     const double sc = exp_scale<Real>();
     const double sqrt_t = std::sqrt((double)o.t);
-    std::vector<Real> host((size_t)n_tri + 3 * n);
+    std::vector<Real> host(n_tiles + 3 * (size_t)np, (Real)0);
+    size_t t = 0;
+    for (int A = 0; A < nb; ++A)
+        for (int c4 = 0; c4 <= A; ++c4, t += 16)
+            for (int j = 0; j < 4; ++j)
+                for (int r = 0; r < 4; ++r) {
+                    const int a = 4 * A + r, b = 4 * c4 + j;
+                    if (a < n && b <= a)
+                        host[t + 4 * j + r] = (Real)((double)o.v[a] * sqrt_t * (double)o.p[a * n + b] * sc);
+                }
     for (int a = 0; a < n; ++a) {
         const double va = (double)o.v[a];
-        for (int b = 0; b <= a; ++b)
-            host[(size_t)a * (a + 1) / 2 + b] = (Real)(va * sqrt_t * (double)o.p[a * n + b] * sc);
-        host[(size_t)n_tri + a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
-        host[(size_t)n_tri + n + a] = (Real)((double)o.w[a] * (double)o.s[a]);
-        host[(size_t)n_tri + 2 * n + a] = 0;
+        host[n_tiles + a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
+        host[n_tiles + np + a] = (Real)((double)o.w[a] * (double)o.s[a]);
     }
     double cg_dyn = 0;
     if (c->control) {
@@ -733,7 +743,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
         for (int a = 0; a < n; ++a)
             W += (double)o.w[a];
         for (int a = 0; a < n; ++a) {
-            host[(size_t)n_tri + 2 * n + a] = (Real)((double)o.w[a] / W);
+            host[n_tiles + 2 * np + a] = (Real)((double)o.w[a] / W);
             cg_dyn += (double)o.w[a] / W * std::log((double)o.s[a]);
         }
         cg_dyn = (cg_dyn + std::log(W)) * sc;
@@ -750,8 +760,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     k.strike = o.k;
     k.cg = (Real)cg_dyn;
     k.cv = c->control ? 1 : 0;
-    constexpr int NPB = npb<Real>::value;
-    const size_t lds = (size_t)((n + NPB - 1) / NPB * NPB) * GROUP * sizeof(Real);
+    const size_t lds = (size_t)np * GROUP * sizeof(Real);
     const auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
     HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t done = 0;
@@ -764,6 +773,19 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     }
     (void)prof;
     return MC_OK;
+}
+
+// Largest basket that takes its register-resident kernel; larger ones run the generic tiled kernel.
+// MC_BASKET_STATIC_MAX_F32 / _F64 (read once) lower the limits for experiments and tests.
+template <class Real>
+static int basket_static_max()
+{
+    static const int limit = [] {
+        const char *e = getenv(sizeof(Real) == 4 ? "MC_BASKET_STATIC_MAX_F32" : "MC_BASKET_STATIC_MAX_F64");
+        const int v = e ? atoi(e) : MC_MAX_ASSETS;
+        return v < 0 ? 0 : (v > MC_MAX_ASSETS ? MC_MAX_ASSETS : v);
+    }();
+    return limit;
 }
 
 template <class Real>
@@ -782,7 +804,7 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
     int slot = 0, rc = MC_OK;
     double scale = 1.0;
     ProfileScope prof(c);
-    switch (o->n) {
+    switch (o->n <= basket_static_max<Real>() ? o->n : 0) {
 #define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, slot, scale); break;
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
         MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)

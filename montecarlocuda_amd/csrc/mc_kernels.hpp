@@ -580,12 +580,14 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
 // The reference's N is any compile-time constant (MonteCarlo.h:16); sizes without a register-resident
 // specialisation run here.  A lane's normals live in its own column of a dynamic-LDS array
 // g[asset][lane] (consecutive lanes, consecutive addresses: conflict-free, and nobody else touches
-// the column, so no barrier); the folded constants m | base | coef sit in one device buffer and are
-// read with a wave-uniform index (scalar loads).  A fallback: correctness and the same stream /
-// estimator definitions as the specialised kernels, not their speed.
+// the column, so no barrier).  The triangular mat-vec is blocked 4 rows x 4 columns: one ds_read of
+// g[b] feeds four rows' fmas (LDS traffic / 4), and the host lays the folded matrix out block-row by
+// block-row, 4 row-values per column, zero-padded to whole blocks, so that each 4 x 4 tile is 16
+// consecutive reals behind ONE wave-uniform (scalar) load.  Padded rows have coef = 0, padded columns
+// multiply real normals by 0.  Same stream and estimator definitions as the specialised kernels.
 template <class Real>
 struct BasketDyn {
-    const Real *consts;  // m packed lower-triangular rows (n(n+1)/2), then base[n], coef[n], wg[n]
+    const Real *consts;  // tiles (8 nb (nb + 1) reals, nb = ceil(n / 4)), then base[4 nb], coef[4 nb], wg[4 nb]
     int n;
     Real strike;
     Real cg;  // control variate constant (see BasketArgs)
@@ -600,9 +602,11 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
     constexpr int NPB = npb<Real>::value;
-    const int n = o.n, nblk = (n + NPB - 1) / NPB, n_tri = n * (n + 1) / 2;
-    const Real *__restrict__ m = o.consts, *__restrict__ base = o.consts + n_tri, *__restrict__ coef = base + n,
-                            *__restrict__ wg = coef + n;
+    const int nb = (o.n + 3) >> 2, np = nb * 4, nblk = np / NPB;
+    // constant address space: wave-uniform reads become scalar loads (s_load_dwordx16 per tile) whatever the
+    // compiler can or cannot prove about the kernel's global stores
+    typedef const __attribute__((address_space(4))) Real *cptr;
+    const cptr tiles = (cptr)o.consts, base = tiles + 8 * nb * (nb + 1), coef = base + np, wg = coef + np;
     const uint32_t stride = gridDim.x * GROUP;
     double acc_s = 0.0, acc_q = 0.0;
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
@@ -614,17 +618,31 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
                 g[(b * NPB + j) * GROUP] = z[j];
         }
         Real basket = 0, mirror = 0, lg = o.cg, lgm = o.cg;
-        int idx = 0;
-        for (int a = 0; a < n; ++a) {
-            Real x = base[a];
-            for (int b = 0; b <= a; ++b)
-                x = fma_r(m[idx++], g[b * GROUP], x);
-            basket = fma_r(coef[a], exp_model(x), basket);
-            lg = fma_r(wg[a], x, lg);
-            if (ANTI) {
-                const Real xm = fma_r((Real)-1, x, 2 * base[a]);
-                mirror = fma_r(coef[a], exp_model(xm), mirror);
-                lgm = fma_r(wg[a], xm, lgm);
+        cptr tile = tiles;
+        for (int A = 0; A < nb; ++A) {
+            Real x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[r] = base[4 * A + r];
+            for (int c4 = 0; c4 <= A; ++c4, tile += 16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const Real gb = g[(4 * c4 + j) * GROUP];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        x[r] = fma_r(tile[4 * j + r], gb, x[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const Real cf = coef[4 * A + r], wr = wg[4 * A + r];
+                basket = fma_r(cf, exp_model(x[r]), basket);
+                lg = fma_r(wr, x[r], lg);
+                if (ANTI) {
+                    const Real xm = fma_r((Real)-1, x[r], 2 * base[4 * A + r]);
+                    mirror = fma_r(cf, exp_model(xm), mirror);
+                    lgm = fma_r(wr, xm, lgm);
+                }
             }
         }
         const Real v = basket - o.strike;

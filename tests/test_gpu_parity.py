@@ -12,8 +12,8 @@ real-number formulas on the same uniforms; they differ only in rounding:
            normal        |dz|  <= 2e-6
            payoff        |dp|  <= 2e-6 * spot      (2e-4 at S=100)
            CVA per path  |dv|  <= 2e-5, sums/estimates rel <= 3e-6
-  f64  device uses ocml double log/exp/sincospi (<= 1-2 ulp), the oracle glibc (< 1 ulp).
-       Measured: normals 1.7e-15, payoffs 1.1e-13 abs, CVA 6e-15, sums 5e-15 rel.  Stated bounds:
+  f64  device uses its own log / sincos / exp / sqrt (mc_math_f64.hpp, <= 1-2 ulp), the oracle glibc (< 1 ulp).
+       Measured: normals 2.9e-15, payoffs 1.1e-13 abs, CVA 6e-15, sums 5e-15 rel.  Stated bounds:
            normal <= 2e-14, payoff <= 1e-14 * spot (1e-12 at S=100), CVA <= 1e-13,
            sums/estimates rel <= 1e-12
 Integer work (Philox words -> uniforms) is exact on both sides; any mismatch there would show
@@ -25,6 +25,8 @@ import os
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -484,6 +486,30 @@ def test_generic_basket_beyond_compiled_sizes(mc, eng, po, X, n_assets):
         got = f64(anti.basket_paths(b, 1001, SEED, 3, X))
         want, _ = po.dev_basket(X, b, SEED, 3, 1001, antithetic=True)
         assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * 100.0 * 4
+
+
+@pytest.mark.parametrize("n_assets", [3, 8, 13, 16])
+def test_generic_kernel_reproduces_the_specialised_kernels_bitwise_in_f64(mc, eng, n_assets):
+    """The tiled generic kernel and the register-resident kernels run the same fma chains in the same order
+    (zero padding adds exact zeros), so their fp64 per-path payoffs are identical bits.  The generic kernel is
+    forced for n <= 16 through MC_BASKET_STATIC_MAX_F64 (read once per process: hence the child process)."""
+    import subprocess
+    import sys
+    import tempfile
+    b = basket_inputs(mc, n_assets, "f64", rho=0.4)
+    want = eng.basket_paths(b, 5000, SEED, 77, "f64")
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "import montecarlocuda_amd as mc\n"
+            "b = json.load(open(sys.argv[1]))\n"
+            "with mc.Engine(0) as e:\n"
+            "    np.save(sys.argv[2], e.basket_paths(b, 5000, %d, 77, 'f64'))\n" % (ROOT, SEED))
+    with tempfile.TemporaryDirectory() as d:
+        import json
+        json.dump(b, open(os.path.join(d, "b.json"), "w"))
+        subprocess.run([sys.executable, "-c", code, os.path.join(d, "b.json"), os.path.join(d, "out.npy")], check=True,
+                       env=dict(os.environ, MC_BASKET_STATIC_MAX_F64="0"), timeout=300)
+        got = np.load(os.path.join(d, "out.npy"))
+    assert got.dtype == np.float64 and np.array_equal(got, want)
 
 
 def test_generic_basket_alternates_with_cva_on_one_context(eng, mc, po):
