@@ -104,15 +104,20 @@ struct ProfileScope {
 };
 
 template <class... KArgs, class... Args>
-static void launch_sim(ProfileScope &prof, void (*kernel)(KArgs...), int grid, hipStream_t st, Args... args)
+static void launch_sim_lds(ProfileScope &prof, void (*kernel)(KArgs...), int grid, size_t dynamic_lds, hipStream_t st, Args... args)
 {
     if (prof.slot >= 0 && !prof.used) {
         prof.used = true;
-        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(GROUP), 0, st, prof.c->prof_start[prof.slot],
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(GROUP), dynamic_lds, st, prof.c->prof_start[prof.slot],
                               prof.c->prof_stop[prof.slot], 0, args...);
     } else {
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(GROUP), 0, st, args...);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(GROUP), dynamic_lds, st, args...);
     }
+}
+template <class... KArgs, class... Args>
+static void launch_sim(ProfileScope &prof, void (*kernel)(KArgs...), int grid, hipStream_t st, Args... args)
+{
+    launch_sim_lds(prof, kernel, grid, 0, st, args...);
 }
 
 extern "C" int mc_device_count(void)
@@ -707,6 +712,32 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     return MC_OK;
 }
 
+// Which kernel family prices a basket of n assets (in-process A/B on MI355X: tools/generic_basket_speed.py):
+//   n <= basket_static_max      constants as kernel arguments / LDS-staged (basket_kernel, basket_f32_kernel)
+//   fp64, 9 <= n <= 16          constants as scalar-loaded tiles, normals in registers (basket_tiled_kernel):
+//                               +14...+20 % over the kernel-argument form at n >= 10, +3 % at 9, -1 % at <= 8
+//   otherwise (n up to 64)      generic tiled kernel, normals in LDS (basket_dyn_kernel)
+// MC_BASKET_STATIC_MAX_F32 / _F64 and MC_BASKET_TILED_MIN_F64 (read once per process) move the limits for
+// experiments and for the tests that compare the families bit for bit.
+static int env_int(const char *name, int fallback, int lo, int hi)
+{
+    const char *e = getenv(name);
+    const int v = e ? atoi(e) : fallback;
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+template <class Real>
+static int basket_static_max()
+{
+    static const int limit = sizeof(Real) == 4 ? env_int("MC_BASKET_STATIC_MAX_F32", MC_MAX_ASSETS, 0, MC_MAX_ASSETS)
+                                               : env_int("MC_BASKET_STATIC_MAX_F64", 8, 0, MC_MAX_ASSETS);
+    return limit;
+}
+static int basket_tiled_min()
+{
+    static const int limit = env_int("MC_BASKET_TILED_MIN_F64", 9, 9, 1000);
+    return limit;
+}
+
 // Baskets beyond the compiled sizes: fold the constants exactly like basket_launch_n (no power-of-two
 // rescale: the generic kernel takes the plain max), park them in the context's table buffer and run
 // the LDS-staged kernel.
@@ -760,32 +791,27 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     k.strike = o.k;
     k.cg = (Real)cg_dyn;
     k.cv = c->control ? 1 : 0;
-    const size_t lds = (size_t)np * GROUP * sizeof(Real);
-    const auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
-    HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    size_t lds = (size_t)np * GROUP * sizeof(Real);
+    auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
+    if (sizeof(Real) == 8 && n >= basket_tiled_min() && n <= 16) {  // fp64: normals in registers, no dynamic LDS
+        lds = 0;
+        switch (n) {
+#define MC_CASE(NA) case NA: kernel = c->antithetic ? basket_tiled_kernel<Real, NA, true> : basket_tiled_kernel<Real, NA, false>; break;
+            MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
+#undef MC_CASE
+        }
+    }
+    if (lds)
+        HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
-        hipLaunchKernelGGL(kernel, dim3(g), dim3(GROUP), lds, st, k, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+        launch_sim_lds(prof, kernel, g, lds, st, k, w, c->partials + slot, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;
     }
-    (void)prof;
     return MC_OK;
-}
-
-// Largest basket that takes its register-resident kernel; larger ones run the generic tiled kernel.
-// MC_BASKET_STATIC_MAX_F32 / _F64 (read once) lower the limits for experiments and tests.
-template <class Real>
-static int basket_static_max()
-{
-    static const int limit = [] {
-        const char *e = getenv(sizeof(Real) == 4 ? "MC_BASKET_STATIC_MAX_F32" : "MC_BASKET_STATIC_MAX_F64");
-        const int v = e ? atoi(e) : MC_MAX_ASSETS;
-        return v < 0 ? 0 : (v > MC_MAX_ASSETS ? MC_MAX_ASSETS : v);
-    }();
-    return limit;
 }
 
 template <class Real>

@@ -669,6 +669,115 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
     store_partial(partials, acc_s, acc_q);
 }
 
+// ---- tiled basket with register-resident normals: the larger fp64 sizes -----------------------
+// Same constant buffer and tile layout as the generic kernel, but the asset count is bounded at compile
+// time, the normals stay in registers and everything is unrolled (padding rows, columns and the zeros
+// above the diagonal are skipped at compile time).  The folded matrix never sits in
+// registers across a trip: each half tile (4 rows x 2 columns = 8 reals) is one scalar load from constant
+// memory issued one half tile ahead of its use, so the constants cost no VALU slot (the SGPR path pays a
+// v_readlane_b32 per use once they no longer fit: 329 of 1457 instructions at n=16) and no LDS latency.
+// What keeps hipcc from hoisting these loop-invariant loads out of the path loop (and spilling them again)
+// is an offset it cannot see through: an empty volatile asm that redefines `off` (always 0) and is tied
+// to the value computed just before, which also fixes where in the trip each load is issued.
+template <class Real, int NA, bool ANTI>
+__global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const BasketDyn<Real> o, const Work w,
+                                                             double2 *__restrict__ partials, Real *__restrict__ out)
+{
+    stage_tables<Real>();
+    constexpr int NB = (NA + 3) / 4, NP = 4 * NB, NPB = npb<Real>::value, NBLK = (NA + NPB - 1) / NPB;
+    constexpr int NH = NB * (NB + 1);  // half tiles in the buffer
+    typedef const __attribute__((address_space(4))) Real *cptr;
+    const cptr tiles = (cptr)o.consts, base = tiles + 8 * NH, coef = base + NP, wg = coef + NP;
+    const uint32_t stride = gridDim.x * GROUP;
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
+        Real g[NBLK * NPB];
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) {
+            Real z[NPB];
+            block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
+#pragma unroll
+            for (int j = 0; j < NPB; ++j)
+                g[b * NPB + j] = z[j];
+        }
+        Real basket = 0, mirror = 0, lg = o.cg, lgm = o.cg;
+        Real tl[2][8];
+        int off = 0;
+        asm volatile("" : "+s"(off) : "v"(g[0]));
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            tl[0][k] = tiles[off + k];
+        int slot = 0;  // which of the two register tiles holds the half tile in use (compile-time after unrolling)
+#pragma unroll
+        for (int A = 0; A < NB; ++A) {
+            constexpr int ROWS_LAST = NA - 4 * (NB - 1);
+            const int rows = A == NB - 1 ? ROWS_LAST : 4;   // rows of this block row that exist
+            const int halves = (4 * A + rows + 1) / 2;      // half tiles that hold a column <= the last row's diagonal
+            Real x[4], cf[4], wr[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < rows) {
+                    x[r] = base[off + 4 * A + r];
+                    cf[r] = coef[off + 4 * A + r];
+                    wr[r] = wg[off + 4 * A + r];
+                }
+#pragma unroll
+            for (int c2 = 0; c2 < 2 * (A + 1); ++c2) {
+                if (c2 >= halves)
+                    continue;
+                // the half tile used next: the following one of this block row, or the first of the next block row
+                const int h = A * (A + 1) + c2;
+                const int h_next = c2 + 1 < halves ? h + 1 : (A + 1 < NB ? (A + 1) * (A + 2) : -1);
+                if (h_next >= 0) {  // issued now, used after this half tile's fmas
+                    asm volatile("" : "+s"(off) : "v"(x[0]));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k)
+                        tl[slot ^ 1][k] = tiles[off + 8 * h_next + k];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < rows && 2 * c2 + j <= 4 * A + r)   // inside the lower triangle
+                            x[r] = fma_r(tl[slot][4 * j + r], g[2 * c2 + j], x[r]);
+                slot ^= 1;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < rows) {
+                    basket = fma_r(cf[r], exp_model(x[r]), basket);
+                    lg = fma_r(wr[r], x[r], lg);
+                    if (ANTI) {
+                        const Real xm = fma_r((Real)-1, x[r], 2 * base[off + 4 * A + r]);
+                        mirror = fma_r(cf[r], exp_model(xm), mirror);
+                        lgm = fma_r(wr[r], xm, lgm);
+                    }
+                }
+        }
+        const Real v = basket - o.strike;
+        Real p = v > 0 ? v : 0;
+        if (o.cv) {
+            const Real gv = exp_model(lg) - o.strike;
+            p -= gv > 0 ? gv : 0;
+        }
+        if (ANTI) {
+            const Real vm = mirror - o.strike;
+            Real pm = vm > 0 ? vm : 0;
+            if (o.cv) {
+                const Real gm = exp_model(lgm) - o.strike;
+                pm -= gm > 0 ? gm : 0;
+            }
+            p = (Real)0.5 * (p + pm);
+        }
+        acc_s += (double)p;
+        acc_q = __builtin_fma((double)p, (double)p, acc_q);
+        if (out)
+            out[i] = p;
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
 // =========================================================================================
 // CVA of one call.  Reference device loop, dp/MonteCarloKernel.cu:241-262 (spot advanced
 // first, exposure = Black-Scholes value at the NEW spot and residual maturity :125-129, with

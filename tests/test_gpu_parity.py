@@ -488,28 +488,34 @@ def test_generic_basket_beyond_compiled_sizes(mc, eng, po, X, n_assets):
         assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * 100.0 * 4
 
 
-@pytest.mark.parametrize("n_assets", [3, 8, 13, 16])
-def test_generic_kernel_reproduces_the_specialised_kernels_bitwise_in_f64(mc, eng, n_assets):
-    """The tiled generic kernel and the register-resident kernels run the same fma chains in the same order
-    (zero padding adds exact zeros), so their fp64 per-path payoffs are identical bits.  The generic kernel is
-    forced for n <= 16 through MC_BASKET_STATIC_MAX_F64 (read once per process: hence the child process)."""
+@pytest.mark.parametrize("n_assets", [3, 8, 9, 13, 16])
+def test_basket_kernel_families_agree_bitwise_in_f64(mc, eng, n_assets):
+    """The three fp64 basket kernels -- constants as kernel arguments / LDS (basket_kernel), scalar-loaded tiles
+    with normals in registers (basket_tiled_kernel, the default for 9..16 assets), generic tiled with normals in
+    LDS (basket_dyn_kernel) -- run the same fma chains in the same order (padding adds exact zeros), so their
+    per-path payoffs are identical bits.  The families are selected through MC_BASKET_STATIC_MAX_F64 /
+    MC_BASKET_TILED_MIN_F64, which are read once per process: hence the child processes."""
+    import json
     import subprocess
     import sys
     import tempfile
     b = basket_inputs(mc, n_assets, "f64", rho=0.4)
-    want = eng.basket_paths(b, 5000, SEED, 77, "f64")
+    default = eng.basket_paths(b, 5000, SEED, 77, "f64")
     code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
             "import montecarlocuda_amd as mc\n"
             "b = json.load(open(sys.argv[1]))\n"
             "with mc.Engine(0) as e:\n"
             "    np.save(sys.argv[2], e.basket_paths(b, 5000, %d, 77, 'f64'))\n" % (ROOT, SEED))
+    families = {"arguments": dict(MC_BASKET_STATIC_MAX_F64="16"),
+                "tiled": dict(MC_BASKET_STATIC_MAX_F64="8", MC_BASKET_TILED_MIN_F64="9"),
+                "generic": dict(MC_BASKET_STATIC_MAX_F64="0", MC_BASKET_TILED_MIN_F64="1000")}
     with tempfile.TemporaryDirectory() as d:
-        import json
         json.dump(b, open(os.path.join(d, "b.json"), "w"))
-        subprocess.run([sys.executable, "-c", code, os.path.join(d, "b.json"), os.path.join(d, "out.npy")], check=True,
-                       env=dict(os.environ, MC_BASKET_STATIC_MAX_F64="0"), timeout=300)
-        got = np.load(os.path.join(d, "out.npy"))
-    assert got.dtype == np.float64 and np.array_equal(got, want)
+        for name, env in families.items():
+            subprocess.run([sys.executable, "-c", code, os.path.join(d, "b.json"), os.path.join(d, name + ".npy")], check=True,
+                           env=dict(os.environ, **env), timeout=300)
+            got = np.load(os.path.join(d, name + ".npy"))
+            assert got.dtype == np.float64 and np.array_equal(got, default), name
 
 
 def test_generic_basket_alternates_with_cva_on_one_context(eng, mc, po):

@@ -7,7 +7,7 @@ import torch  # noqa: F401  (first, see tests/conftest.py)
 import montecarlocuda_amd as mc
 import bench
 e = mc.Engine(0)
-for X in ("f32", "f64"):
+for X in [x for x in ("f32", "f64") if x in os.environ.get("PRECISIONS", "f32 f64")]:
     for n in [int(a) for a in sys.argv[1:]] or (16, 17, 20, 24, 32, 48, 64):
         inputs = bench.basket_inputs(mc, n, X)
         paths = int((4e9 if X == "f32" else 1.2e9) / (n * n / 8 + 4 * n))
