@@ -65,6 +65,18 @@ def workloads(mc):
     }
 
 
+def kernel_name(prod, X, inputs):
+    """The simulation kernel a workload runs (montecarlocuda_amd/csrc/mc_api.hip picks it)."""
+    if prod == "vanilla":
+        return "mc::vanilla_f32_kernel" if X == "f32" else "mc::vanilla_kernel<f64>"
+    if prod == "basket":
+        n = len(inputs["s"])
+        if X == "f32":
+            return f"mc::basket_f32_kernel<{n}>" if n <= 16 else "mc::basket_dyn_kernel<f32>"
+        return f"mc::basket_kernel<f64, {n}>" if n <= 8 else (f"mc::basket_tiled_kernel<f64, {n}>" if n <= 16 else "mc::basket_dyn_kernel<f64>")
+    return f"mc::cva_kernel<{X}>"
+
+
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md; fp64 vector = half)
 
 
@@ -322,7 +334,7 @@ def main():
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
             "roofline": {"bound": "valu", "achieved": ach, "peak": PEAK_TFLOPS[X], "unit": "TFLOP/s",
                          "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,
-                         "kernel": "mc::vanilla_f32_kernel" if (prod, X) == ("vanilla", "f32") else f"mc::{prod}_kernel<{X}>", "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
+                         "kernel": kernel_name(prod, X, inputs), "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
                          "kernel_samples": samples, "flop_per_path": flop_per_path,
                          "kernel_paths_per_s": shard_count / kernel_s if kernel_s else None,
                          "concurrent_launches": len(engines), "step_period_us": elapsed / K * 1e6,
