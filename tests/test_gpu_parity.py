@@ -161,7 +161,7 @@ def test_vanilla_shards_add_up_and_geometry_does_not_matter(mc, eng, X):
 
 # ---- basket -------------------------------------------------------------------------------
 @pytest.mark.parametrize("X", ["f32", "f64"])
-@pytest.mark.parametrize("n_assets", [1, 2, 3, 4, 5, 7, 8, 13, 16])
+@pytest.mark.parametrize("n_assets", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 16])
 def test_basket_per_path_and_sums(mc, eng, po, X, n_assets):
     b = basket_inputs(mc, n_assets, X)
     n = 6000
@@ -411,7 +411,7 @@ def test_antithetic_estimator_matches_oracle_and_reduces_variance(mc, po, X):
         assert est.n == n and est.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"])
         assert est.confidence == pytest.approx(o["confidence"], rel=4 * TOL[X]["rel"])
         # baskets (f32 goes through the packed two-path kernel)
-        for n_assets in (1, 3, 4, 16):
+        for n_assets in (1, 3, 4, 11, 16):
             b = basket_inputs(mc, n_assets, X)
             got = f64(e.basket_paths(b, 4001, SEED, 7, X))
             want, o = po.dev_basket(X, b, SEED, 7, 4001, antithetic=True)
@@ -537,7 +537,7 @@ def test_basket_control_variate_matches_oracle_and_reduces_variance(mc, po, X):
     mean added back by mc_basket_run_*, and the variance actually falling by two orders of magnitude."""
     with mc.Engine(0) as e, mc.Engine(0) as plain:
         e.set_control_variate(True)
-        for n_assets in (1, 3, 4, 16, 20):
+        for n_assets in (1, 3, 4, 11, 14, 16, 20):
             b = basket_inputs(mc, n_assets, X, rho=0.5)
             b["w"] = [(1.0 + 0.2 * (i % 3)) / n_assets for i in range(n_assets)]      # unequal weights, sum != 1
             for anti in (False, True):
