@@ -145,10 +145,11 @@ def main():
                     help="independent (context, HIP stream) pairs the steps rotate over; >1 lets consecutive pricing "
                          "calls overlap each other's launch gaps and finishing kernels")
     ap.add_argument("--profile-every", type=int, default=8)
+    ap.add_argument("--blocks", type=int, default=0, help="workgroups per launch (0 = the engine's default, 8 per CU)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default). gloo = rehearsal of the multi-rank logic on a box with fewer "
                          "GPUs than ranks: ranks share GPUs (LOCAL_RANK mod device count), triples are reduced on the host")
-    ap.add_argument("--fp64-steps", type=int, default=100, help="steps of the fp64 side measurement (0 = skip)")
+    ap.add_argument("--fp64-steps", type=int, default=300, help="steps of the fp64 side measurement (0 = skip)")
     ap.add_argument("--exclusive-launches", type=int, default=50,
                     help="after the timed region, this many launches one at a time on one stream, each timed on the device: "
                          "the kernel's duration without a neighbour (roofline.exclusive); 0 = skip")
@@ -170,7 +171,7 @@ def main():
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     grouped = dist.is_initialized()   # one process per GPU under torch.distributed.run (RCCL), also for N=1
-    engines = [mc.Engine(local) for _ in range(max(1, args.streams))]
+    engines = [mc.Engine(local, args.blocks) for _ in range(max(1, args.streams))]
     eng = engines[0]
     prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
     if callable(inputs):
