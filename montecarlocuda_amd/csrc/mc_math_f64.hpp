@@ -5,12 +5,12 @@
 // ocml routines pay for double-double intermediates and for arguments these kernels never see
 // (measured VALU instructions: log 98, sincospi 70, sqrt 22, 1/x 12).  The versions below assume
 // what the generator guarantees -- a uniform strictly inside (0,1), a positive finite radicand --
-// and stay within 1 ulp of the correctly rounded result (checked against glibc through the
-// oracle's normals: tests/test_gpu_parity.py, bound 2e-14 absolute on |z| < 8.3):
+// and stay within 1-2 ulp of the correctly rounded result (checked against glibc through the
+// oracle's normals: tests/test_gpu_parity.py, bound 2e-14 absolute on |z| < 8.3; measured 2.9e-15):
 //
 //   log_unit(u)        ~36 instructions   fdlibm's e_log scheme: u = 2^k (1+f), s = f/(2+f),
 //                                         7-term minimax in s^2 (max error 0.8 ulp)
-//   sqrt_pos(x)        ~9                 v_rsq_f64 + two coupled Newton steps (ocml's core, no rescaling)
+//   sqrt_pos(x)        ~7                 v_rsq_f64 + one coupled Newton step + one residual step (no rescaling)
 //   sincos_turns(u)    ~36                quadrant from rint(4u), Taylor to y^15 / y^16 on |y| <= 1/2
 //   recip_pos(d)       ~5                 v_rcp_f64 + two Newton steps
 //   exp_f64(x)         ~19                n = rint(x log2 e), two-step reduction, Taylor to r^13, v_ldexp_f64
