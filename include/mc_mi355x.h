@@ -16,8 +16,8 @@
  *   - *_run_* are the synchronous forms: launch, wait, close the estimator on the host;
  *   - *_paths_* return per-path values for a (small) path range: used by the parity tests.
  *
- * Random numbers: Philox4x32-10, key = 64-bit seed, counter = {unit_lo, unit_hi, block,
- * domain}.  A path's normals depend only on (seed, global path index), never on the launch
+ * Random numbers: Philox4x32-10, key = 64-bit seed, counter = {unit_hi, unit_lo, block,
+ * domain} (unit = 64-bit index of a path or of a Philox block of vanilla paths).  A path's normals depend only on (seed, global path index), never on the launch
  * geometry or on how a range is split over GPUs.  Layout per product: DESIGN.md "RNG".
  *
  * Precision suffix: _f32 simulates in float (sums are still accumulated in double),

@@ -161,7 +161,7 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
 static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, mc_real z[NPB])
 {
     uint32_t x[4];
-    philox4x32_10((uint32_t)unit, (uint32_t)(unit >> 32), block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);
+    philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);  /* counter = {unit_hi, unit_lo, block, domain} */
 #ifdef MC_SINGLE_PRECISION
     for (int h = 0; h < 2; ++h) {
         const float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f), ub = fmaf((float)x[2 * h + 1], 0x1p-32f, 0x1p-33f);

@@ -73,7 +73,7 @@ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f),
 template <bool ANTI>
 __device__ __forceinline__ void vanilla_unit_pk(const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)
 {
-    const u32x4 r = philox4x32_10(c0, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi);
+    const u32x4 r = philox_unit(c0, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi);
     const f2 scale = {0x1p-32f, 0x1p-32f}, half = {0x1p-33f, 0x1p-33f};
     const f2 ua = __builtin_elementwise_fma((f2){(float)r.x, (float)r.z}, scale, half);  // radius uniforms
     const f2 ub = __builtin_elementwise_fma((f2){(float)r.y, (float)r.w}, scale, half);  // angle uniforms
@@ -471,8 +471,8 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, Co
     const f2 scale = bcast(0x1p-32f), half = bcast(0x1p-33f), neg2ln2 = bcast(NEG_2LN2_F32);
 #pragma unroll
     for (int b = 0; b < NBLK; ++b) {
-        const u32x4 ra = philox4x32_10(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
-        const u32x4 rb = philox4x32_10(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
+        const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
+        const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
         // Box-Muller pair X = words (x, y), pair Z = words (z, w); halves = {path A, path B}
         const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
         const f2 ax = pk_fma((f2){(float)ra.y, (float)rb.y}, scale, half);

@@ -218,13 +218,13 @@ void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REA
 /* ===================================================================================== */
 
 /* One Philox block -> NPB normals (NPB = 4 in f32, 2 in f64) by two-branch Box-Muller.
- *   counter = { unit_lo, unit_hi, block, domain },  key = { seed_lo, seed_hi }
+ *   counter = { unit_hi, unit_lo, block, domain },  key = { seed_lo, seed_hi }   (mc_rng.hpp: philox_unit)
  * f32: u = fma(x, 2^-32, 2^-33) in (0,1];  f64: u = ((x_hi:x_lo >> 12) + 0.5) 2^-52 in (0,1)
  *   radius = sqrt(-2 ln u_a),  z_even = radius cos(2 pi u_b),  z_odd = radius sin(2 pi u_b)
  * The f32 radius is written with log2 (the HIP kernel's v_log_f32 is a base-2 log). */
 void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
 {
-    uint32_t ctr[4] = {(uint32_t)unit, (uint32_t)(unit >> 32), block, domain};
+    uint32_t ctr[4] = {(uint32_t)(unit >> 32), (uint32_t)unit, block, domain};
     uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t x[4];
     orc_philox4x32_10(ctr, key, x);

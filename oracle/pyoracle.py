@@ -102,6 +102,12 @@ def _arr(a, X):
 # ------------------------------------------------------------------------------------------
 # thin pythonic wrappers
 # ------------------------------------------------------------------------------------------
+def counter(unit, block, domain):
+    """The engine's Philox counter for a 64-bit unit index: {unit_hi, unit_lo, block, domain}
+    (montecarlocuda_amd/csrc/mc_rng.hpp: philox_unit; oracle/mc_oracle_impl.h: orc_dev_normals)."""
+    return [(unit >> 32) & 0xFFFFFFFF, unit & 0xFFFFFFFF, block, domain]
+
+
 def philox(ctr, key):
     c = (C.c_uint32 * 4)(*ctr)
     k = (C.c_uint32 * 2)(*key)

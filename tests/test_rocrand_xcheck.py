@@ -19,14 +19,24 @@ def test_oracle_philox_equals_rocrand_engine(po, tmp_path):
     subprocess.check_call([hipcc, "-O1", "-w", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "cpp", "rocrand_xcheck.cpp"),
                            "-o", str(exe)])
     rng = np.random.default_rng(7)
-    cases = [(0, 0, 0, 0), (0x4D435F4D49333535, 0, 0, 1), (0x4D435F4D49333535, 24999999, 0, 1), (1, (1 << 32) - 1, 3, 2),
-             (2 ** 64 - 1, (1 << 32), 63, 3), (12345, (7 << 32) + 5, 0, 1)]
+    # (seed, unit, block, domain); rocRAND's offset is 4 * (counter words 1:0), which must fit 64 bits: the
+    # engine keeps a unit's LOW word in counter word 1 (po.counter), so the low word stays below 2^30 here
+    cases = [(0, 0, 0, 0), (0x4D435F4D49333535, 0, 0, 1), (0x4D435F4D49333535, 24999999, 0, 1), (1, (1 << 30) - 1, 3, 2),
+             (2 ** 64 - 1, (0xFFFFFFFF << 32) + 77, 63, 3), (12345, (7 << 32) + 5, 0, 1)]
     for _ in range(300):
-        cases.append((int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2)), int(rng.integers(0, 2 ** 61)),
+        cases.append((int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2)),
+                      (int(rng.integers(0, 2 ** 32)) << 32) | int(rng.integers(0, 2 ** 30)),
                       int(rng.integers(0, 2 ** 31)), int(rng.integers(0, 2 ** 31))))
-    text = "".join(f"{s} {u} {b} {d}\n" for s, u, b, d in cases)
+    ctrs = [po.counter(u, b, d) for _, u, b, d in cases]
+    text = "".join(f"{s} {(c[1] << 32) | c[0]} {c[2]} {c[3]}\n" for (s, _, _, _), c in zip(cases, ctrs))
     out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.split("\n")
-    for (s, u, b, d), line in zip(cases, out):
+    for (s, u, b, d), c, line in zip(cases, ctrs, out):
         want = [int(x, 16) for x in line.split()]
-        got = po.philox([u & 0xFFFFFFFF, u >> 32, b, d], [s & 0xFFFFFFFF, s >> 32])
-        assert got == want, (s, u, b, d)
+        assert len(want) == 4, (line, s, u, b, d)
+        assert po.philox(c, [s & 0xFFFFFFFF, s >> 32]) == want, (s, u, b, d)
+        # the oracle's normals are built from exactly these words (f32: word k -> uniform k)
+        z = po.dev_normals("f32", s, d, u, b)
+        ua = np.float32(np.float32(want[0]) * np.float32(2.0 ** -32) + np.float32(2.0 ** -33))
+        if ua < 1:
+            r2 = float(z[0]) ** 2 + float(z[1]) ** 2
+            assert r2 == pytest.approx(-2.0 * np.log(float(ua)), rel=2e-5), (s, u, b, d)
