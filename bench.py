@@ -71,9 +71,14 @@ def kernel_name(prod, X, inputs):
         return "mc::vanilla_f32_kernel" if X == "f32" else "mc::vanilla_kernel<f64>"
     if prod == "basket":
         n = len(inputs["s"])
+        pad = (n + 3) // 4 * 4
         if X == "f32":
-            return f"mc::basket_f32_kernel<{n}>" if n <= 16 else "mc::basket_dyn_kernel<f32>"
-        return f"mc::basket_kernel<f64, {n}>" if n <= 8 else (f"mc::basket_tiled_kernel<f64, {n}>" if n <= 16 else "mc::basket_dyn_kernel<f64>")
+            if n <= 12:
+                return f"mc::basket_f32_kernel<{n}>"
+            return f"mc::basket_tiled_f32_kernel<{n if n <= 14 else pad}>" if n <= 32 else "mc::basket_dyn_f32_kernel"
+        if n <= 8:
+            return f"mc::basket_kernel<f64, {n}>"
+        return f"mc::basket_tiled_kernel<f64, {n if n <= 16 else pad}>" if n <= 32 else "mc::basket_dyn_kernel<f64>"
     return f"mc::cva_kernel<{X}>"
 
 

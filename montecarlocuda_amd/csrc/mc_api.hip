@@ -712,13 +712,18 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     return MC_OK;
 }
 
-// Which kernel family prices a basket of n assets (in-process A/B on MI355X: tools/generic_basket_speed.py):
-//   n <= basket_static_max      constants as kernel arguments / LDS-staged (basket_kernel, basket_f32_kernel)
-//   fp64, 9 <= n <= 16          constants as scalar-loaded tiles, normals in registers (basket_tiled_kernel):
-//                               +14...+20 % over the kernel-argument form at n >= 10, +3 % at 9, -1 % at <= 8
-//   otherwise (n up to 64)      generic tiled kernel, normals in LDS (basket_dyn_kernel)
-// MC_BASKET_STATIC_MAX_F32 / _F64 and MC_BASKET_TILED_MIN_F64 (read once per process) move the limits for
-// experiments and for the tests that compare the families bit for bit.
+// Which kernel family prices a basket of n assets (measured on MI355X: tools/generic_basket_speed.py, runs
+// alternated in one gpurun call):
+//   n <= basket_static_max (fp32: 12, fp64: 8)
+//                      constants as kernel arguments / LDS-staged (basket_f32_kernel, basket_kernel)
+//   up to 32 assets    constants as scalar-loaded tiles, normals in registers (basket_tiled_f32_kernel,
+//                      basket_tiled_kernel).  fp64 9..16, one kernel per size: +3 % at 9, +14...+20 % at 10..16 over
+//                      the kernel-argument form; fp32 13, 14, 16 (15 runs the 16 kernel): +5...+8 %, below 12 the
+//                      LDS-staged form wins; 17..32: one kernel per multiple of 4 on the zero-padded buffer,
+//                      +19...+39 % over the generic kernel
+//   33..64 assets      generic tiled kernel, normals in LDS (basket_dyn_kernel, basket_dyn_f32_kernel)
+// MC_BASKET_STATIC_MAX_F32 / _F64 and MC_BASKET_TILED_MIN (read once per process) move the limits for
+// experiments and for the tests that compare the families.
 static int env_int(const char *name, int fallback, int lo, int hi)
 {
     const char *e = getenv(name);
@@ -728,13 +733,13 @@ static int env_int(const char *name, int fallback, int lo, int hi)
 template <class Real>
 static int basket_static_max()
 {
-    static const int limit = sizeof(Real) == 4 ? env_int("MC_BASKET_STATIC_MAX_F32", MC_MAX_ASSETS, 0, MC_MAX_ASSETS)
+    static const int limit = sizeof(Real) == 4 ? env_int("MC_BASKET_STATIC_MAX_F32", 12, 0, MC_MAX_ASSETS)
                                                : env_int("MC_BASKET_STATIC_MAX_F64", 8, 0, MC_MAX_ASSETS);
     return limit;
 }
 static int basket_tiled_min()
 {
-    static const int limit = env_int("MC_BASKET_TILED_MIN_F64", 9, 9, 1000);
+    static const int limit = env_int("MC_BASKET_TILED_MIN", 9, 9, 1000);
     return limit;
 }
 
@@ -793,11 +798,28 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     k.cv = c->control ? 1 : 0;
     size_t lds = (size_t)np * GROUP * sizeof(Real);
     auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
-    if (sizeof(Real) == 8 && n >= basket_tiled_min() && n <= 16) {  // fp64: normals in registers, no dynamic LDS
+    bool pairs = false;  // two paths per lane
+    if constexpr (sizeof(Real) == 4) {
+        pairs = true;
+        if (n >= 13 && n >= basket_tiled_min() && n <= 32) {  // normals in registers, no dynamic LDS
+            lds = 0;
+            switch (n <= 14 ? n : np) {  // 13, 14: own kernels; 15..32: one per multiple of 4 (zero-padded buffer)
+#define MC_CASE(NA) case NA: kernel = c->antithetic ? basket_tiled_f32_kernel<NA, true> : basket_tiled_f32_kernel<NA, false>; break;
+                MC_CASE(13) MC_CASE(14) MC_CASE(16) MC_CASE(20) MC_CASE(24) MC_CASE(28) MC_CASE(32)
+#undef MC_CASE
+            }
+        } else {
+            kernel = c->antithetic ? basket_dyn_f32_kernel<true> : basket_dyn_f32_kernel<false>;
+            lds *= 2;  // the lane's column holds packed pairs
+        }
+    } else if (n >= basket_tiled_min() && n <= 32) {  // fp64: normals in registers, no dynamic LDS
         lds = 0;
-        switch (n) {
+        // 9..16 assets: one kernel per size; 17..32: one per multiple of 4 (the buffer is zero-padded to whole tiles,
+        // padded rows carry coef = 0 and padded columns multiply real normals by 0)
+        switch (n <= 16 ? n : np) {
 #define MC_CASE(NA) case NA: kernel = c->antithetic ? basket_tiled_kernel<Real, NA, true> : basket_tiled_kernel<Real, NA, false>; break;
             MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
+            MC_CASE(20) MC_CASE(24) MC_CASE(28) MC_CASE(32)
 #undef MC_CASE
         }
     }
@@ -806,7 +828,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
-        const int g = grid_for(c, s.count);
+        const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
         launch_sim_lds(prof, kernel, g, lds, st, k, w, c->partials + slot, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;

@@ -669,6 +669,93 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
     store_partial(partials, acc_s, acc_q);
 }
 
+// fp32 form of the generic kernel: TWO paths per lane (units i and i + stride), one in each half of a packed
+// register pair, like basket_f32_kernel -- the uniforms' scaling, the radius scaling, z = r trig, every fma of
+// the tiled mat-vec and the weighted sums issue as v_pk_*_f32, and each scalar-loaded tile value and each
+// loop step serves two paths.  The lane's LDS column holds packed pairs (8 bytes per asset).
+template <bool ANTI>
+__global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const BasketDyn<float> o, const Work w,
+                                                               double2 *__restrict__ partials, float *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    f2 *g = reinterpret_cast<f2 *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
+    const int nb = (o.n + 3) >> 2, np = nb * 4;             // nb Philox blocks (4 normals each) per path
+    typedef const __attribute__((address_space(4))) float *cptr;
+    const cptr tiles = (cptr)o.consts, base = tiles + 8 * nb * (nb + 1), coef = base + np, wg = coef + np;
+    const uint32_t stride = gridDim.x * GROUP;
+    const f2 scale = bcast(0x1p-32f), half = bcast(0x1p-33f), neg2ln2 = bcast(NEG_2LN2_F32);
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += 2 * stride) {
+        const bool has_b = i + stride < w.n_units;  // false only in a range's last trip
+        const uint32_t cA = w.unit_lo + i, cB = w.unit_lo + (has_b ? i + stride : i);
+        for (int b = 0; b < nb; ++b) {
+            const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
+            const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
+            const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
+            const f2 ax = pk_fma((f2){(float)ra.y, (float)rb.y}, scale, half);
+            const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
+            const f2 az = pk_fma((f2){(float)ra.w, (float)rb.w}, scale, half);
+            const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
+            const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
+            const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
+            const f2 rz = {__builtin_amdgcn_sqrtf(tz.x), __builtin_amdgcn_sqrtf(tz.y)};
+            g[(4 * b + 0) * GROUP] = rx * (f2){__builtin_amdgcn_cosf(ax.x), __builtin_amdgcn_cosf(ax.y)};
+            g[(4 * b + 1) * GROUP] = rx * (f2){__builtin_amdgcn_sinf(ax.x), __builtin_amdgcn_sinf(ax.y)};
+            g[(4 * b + 2) * GROUP] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
+            g[(4 * b + 3) * GROUP] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
+        }
+        f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f}, lg = bcast(o.cg), lgm = bcast(o.cg);
+        cptr tile = tiles;
+        for (int A = 0; A < nb; ++A) {
+            f2 x[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                x[r] = bcast(base[4 * A + r]);
+            for (int c4 = 0; c4 <= A; ++c4, tile += 16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f2 gb = g[(4 * c4 + j) * GROUP];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        x[r] = pk_fma(bcast(tile[4 * j + r]), gb, x[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f2 cf = bcast(coef[4 * A + r]), wr = bcast(wg[4 * A + r]);
+                basket = pk_fma(cf, (f2){__builtin_amdgcn_exp2f(x[r].x), __builtin_amdgcn_exp2f(x[r].y)}, basket);
+                lg = pk_fma(wr, x[r], lg);
+                if (ANTI) {
+                    const f2 xm = pk_fma(bcast(-1.0f), x[r], bcast(2.0f * base[4 * A + r]));
+                    mirror = pk_fma(cf, (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
+                    lgm = pk_fma(wr, xm, lgm);
+                }
+            }
+        }
+        const f2 zero = {0.0f, 0.0f}, strike = bcast(o.strike);
+        f2 p = __builtin_elementwise_max(basket - strike, zero);
+        if (o.cv)
+            p -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lg.x), __builtin_amdgcn_exp2f(lg.y)} - strike, zero);
+        if (ANTI) {
+            f2 pm = __builtin_elementwise_max(mirror - strike, zero);
+            if (o.cv)
+                pm -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lgm.x), __builtin_amdgcn_exp2f(lgm.y)} - strike, zero);
+            p = bcast(0.5f) * (p + pm);
+        }
+        if (!has_b)
+            p.y = 0.0f;
+        acc_s += (double)p.x + (double)p.y;
+        acc_q = __builtin_fma((double)p.x, (double)p.x, __builtin_fma((double)p.y, (double)p.y, acc_q));
+        if (out) {
+            out[i] = p.x;
+            if (has_b)
+                out[i + stride] = p.y;
+        }
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
 // ---- tiled basket with register-resident normals: the larger fp64 sizes -----------------------
 // Same constant buffer and tile layout as the generic kernel, but the asset count is bounded at compile
 // time, the normals stay in registers and everything is unrolled (padding rows, columns and the zeros
@@ -773,6 +860,113 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const BasketDyn<Rea
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)
             out[i] = p;
+    }
+    group_sum2(acc_s, acc_q);
+    store_partial(partials, acc_s, acc_q);
+}
+
+// fp32 form of the tiled kernel (12..32 assets): two paths per lane in packed halves (like basket_f32_kernel
+// and basket_dyn_f32_kernel), normals in registers, each whole 4 x 4 tile (16 floats) one scalar load issued a
+// tile ahead.  Plain max for the payoff (no power-of-two rescale: the host folds none for these sizes).
+template <int NA, bool ANTI>
+__global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const BasketDyn<float> o, const Work w,
+                                                                 double2 *__restrict__ partials, float *__restrict__ out)
+{
+    constexpr int NB = (NA + 3) / 4, NP = 4 * NB, NT = NB * (NB + 1) / 2;
+    typedef const __attribute__((address_space(4))) float *cptr;
+    const cptr tiles = (cptr)o.consts, base = tiles + 16 * NT, coef = base + NP, wg = coef + NP;
+    const uint32_t stride = gridDim.x * GROUP;
+    const f2 scale = bcast(0x1p-32f), half = bcast(0x1p-33f), neg2ln2 = bcast(NEG_2LN2_F32);
+    double acc_s = 0.0, acc_q = 0.0;
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += 2 * stride) {
+        const bool has_b = i + stride < w.n_units;  // false only in a range's last trip
+        const uint32_t cA = w.unit_lo + i, cB = w.unit_lo + (has_b ? i + stride : i);
+        f2 g[NP];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
+            const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
+            const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
+            const f2 ax = pk_fma((f2){(float)ra.y, (float)rb.y}, scale, half);
+            const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
+            const f2 az = pk_fma((f2){(float)ra.w, (float)rb.w}, scale, half);
+            const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
+            const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
+            const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
+            const f2 rz = {__builtin_amdgcn_sqrtf(tz.x), __builtin_amdgcn_sqrtf(tz.y)};
+            g[4 * b + 0] = rx * (f2){__builtin_amdgcn_cosf(ax.x), __builtin_amdgcn_cosf(ax.y)};
+            g[4 * b + 1] = rx * (f2){__builtin_amdgcn_sinf(ax.x), __builtin_amdgcn_sinf(ax.y)};
+            g[4 * b + 2] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
+            g[4 * b + 3] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
+        }
+        f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f}, lg = bcast(o.cg), lgm = bcast(o.cg);
+        float tl[2][16];
+        int off = 0;
+        asm volatile("" : "+s"(off) : "v"(g[0].x));
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            tl[0][k] = tiles[off + k];
+        int t = 0;  // tile counter (compile-time after unrolling)
+#pragma unroll
+        for (int A = 0; A < NB; ++A) {
+            constexpr int ROWS_LAST = NA - 4 * (NB - 1);
+            const int rows = A == NB - 1 ? ROWS_LAST : 4;  // rows of this block row that exist
+            f2 x[4];
+            float cf[4], wr[4], bs[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < rows) {
+                    bs[r] = base[off + 4 * A + r];
+                    cf[r] = coef[off + 4 * A + r];
+                    wr[r] = wg[off + 4 * A + r];
+                    x[r] = bcast(bs[r]);
+                }
+#pragma unroll
+            for (int c4 = 0; c4 <= A; ++c4, ++t) {
+                if (t + 1 < NT) {  // next tile: issued now, used after this one's fmas
+                    asm volatile("" : "+s"(off) : "v"(x[0].x));
+#pragma unroll
+                    for (int k = 0; k < 16; ++k)
+                        tl[(t + 1) & 1][k] = tiles[off + 16 * (t + 1) + k];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (r < rows && 4 * c4 + j <= 4 * A + r)   // an existing row, inside the lower triangle
+                            x[r] = pk_fma(bcast(tl[t & 1][4 * j + r]), g[4 * c4 + j], x[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (r < rows) {
+                    basket = pk_fma(bcast(cf[r]), (f2){__builtin_amdgcn_exp2f(x[r].x), __builtin_amdgcn_exp2f(x[r].y)}, basket);
+                    lg = pk_fma(bcast(wr[r]), x[r], lg);
+                    if (ANTI) {
+                        const f2 xm = pk_fma(bcast(-1.0f), x[r], bcast(2.0f * bs[r]));
+                        mirror = pk_fma(bcast(cf[r]), (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
+                        lgm = pk_fma(bcast(wr[r]), xm, lgm);
+                    }
+                }
+        }
+        const f2 zero = {0.0f, 0.0f}, strike = bcast(o.strike);
+        f2 p = __builtin_elementwise_max(basket - strike, zero);
+        if (o.cv)
+            p -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lg.x), __builtin_amdgcn_exp2f(lg.y)} - strike, zero);
+        if (ANTI) {
+            f2 pm = __builtin_elementwise_max(mirror - strike, zero);
+            if (o.cv)
+                pm -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lgm.x), __builtin_amdgcn_exp2f(lgm.y)} - strike, zero);
+            p = bcast(0.5f) * (p + pm);
+        }
+        if (!has_b)
+            p.y = 0.0f;
+        acc_s += (double)p.x + (double)p.y;
+        acc_q = __builtin_fma((double)p.x, (double)p.x, __builtin_fma((double)p.y, (double)p.y, acc_q));
+        if (out) {
+            out[i] = p.x;
+            if (has_b)
+                out[i + stride] = p.y;
+        }
     }
     group_sum2(acc_s, acc_q);
     store_partial(partials, acc_s, acc_q);

@@ -494,7 +494,7 @@ def test_basket_kernel_families_agree_bitwise_in_f64(mc, eng, n_assets):
     with normals in registers (basket_tiled_kernel, the default for 9..16 assets), generic tiled with normals in
     LDS (basket_dyn_kernel) -- run the same fma chains in the same order (padding adds exact zeros), so their
     per-path payoffs are identical bits.  The families are selected through MC_BASKET_STATIC_MAX_F64 /
-    MC_BASKET_TILED_MIN_F64, which are read once per process: hence the child processes."""
+    MC_BASKET_TILED_MIN, which are read once per process: hence the child processes."""
     import json
     import subprocess
     import sys
@@ -507,8 +507,8 @@ def test_basket_kernel_families_agree_bitwise_in_f64(mc, eng, n_assets):
             "with mc.Engine(0) as e:\n"
             "    np.save(sys.argv[2], e.basket_paths(b, 5000, %d, 77, 'f64'))\n" % (ROOT, SEED))
     families = {"arguments": dict(MC_BASKET_STATIC_MAX_F64="16"),
-                "tiled": dict(MC_BASKET_STATIC_MAX_F64="8", MC_BASKET_TILED_MIN_F64="9"),
-                "generic": dict(MC_BASKET_STATIC_MAX_F64="0", MC_BASKET_TILED_MIN_F64="1000")}
+                "tiled": dict(MC_BASKET_STATIC_MAX_F64="8", MC_BASKET_TILED_MIN="9"),
+                "generic": dict(MC_BASKET_STATIC_MAX_F64="0", MC_BASKET_TILED_MIN="1000")}
     with tempfile.TemporaryDirectory() as d:
         json.dump(b, open(os.path.join(d, "b.json"), "w"))
         for name, env in families.items():
