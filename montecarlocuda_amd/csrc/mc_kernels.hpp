@@ -4,15 +4,18 @@
 // dp/MonteCarloKernel.cu:133-177,179-220,222-283):
 //   * a persistent-style grid (blocks x 256 lanes) strides over "units" of work; a unit is one
 //     Philox block of vanilla paths (4 in f32, 2 in f64) or one whole basket / CVA path;
-//   * everything a lane needs is in registers: counter-based normals (mc_rng.hpp), option
-//     constants in SGPRs (kernel arguments), per-lane fp64 (sum, sum2) accumulators;
+//   * everything a lane needs is in registers: counter-based normals (mc_rng.hpp), per-lane fp64
+//     (sum, sum2) accumulators; wave-uniform constants never cost a VALU slot -- kernel arguments in
+//     SGPRs while they fit, otherwise LDS-staged (broadcast ds_read) or fetched tile by tile with
+//     scalar loads from constant memory (the basket kernels), per-date rows through scalar loads (CVA);
 //   * one DPP+LDS reduction and one 16-byte store per workgroup at the end (mc_reduce.hpp).
-// HBM traffic per launch: kernel arguments in, 16 B per workgroup out -- the kernels are bound
-// by VALU/transcendental issue, not by memory (DESIGN.md "Roofline").
+// HBM traffic per launch: kernel arguments (and a table of <= 20 KB) in, 16 B per workgroup out --
+// the kernels are bound by VALU/transcendental issue, not by memory (DESIGN.md "Roofline").
 //
 // `Work` describes one segment: units [unit_lo, unit_lo + n_units) with a common high word
-// (the host splits a range so that unit_lo + n_units <= 2^32 and n_units <= 2^31; keeping the
-// high counter word wave-uniform moves a multiply per Philox block to the scalar unit).
+// (the host splits a range so that unit_lo + n_units <= 2^32 and n_units <= 2^31; only the low
+// word differs between lanes, which moves part of Philox's first rounds to the scalar unit:
+// mc_rng.hpp, philox_unit).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
