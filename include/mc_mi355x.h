@@ -52,7 +52,7 @@ const char *mc_last_error(void);
 #define MC_DOMAIN_BASKET 2u
 #define MC_DOMAIN_CVA 3u
 
-#define MC_MAX_ASSETS 16         /* basket sizes with a register-resident kernel: 1..16 */
+#define MC_MAX_ASSETS 16         /* basket sizes whose constants can travel as kernel arguments: 1..16 */
 #define MC_MAX_ASSETS_GENERIC 64 /* larger baskets (17..64) run a generic LDS-staged kernel */
 
 /* ---- inputs (layouts == reference MonteCarlo.h of that precision) ------------------- */

@@ -743,9 +743,9 @@ static int basket_tiled_min()
     return limit;
 }
 
-// Baskets beyond the compiled sizes: fold the constants exactly like basket_launch_n (no power-of-two
-// rescale: the generic kernel takes the plain max), park them in the context's table buffer and run
-// the LDS-staged kernel.
+// The table-driven families: fold the constants exactly like basket_launch_n (no power-of-two rescale:
+// these kernels take the plain max), lay them out in 4 x 4 tiles, park them in the context's table
+// buffer and run the tiled kernel of the size, or the generic one beyond 32 assets.
 template <class Real>
 static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
                              const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot)
