@@ -53,7 +53,7 @@ const char *mc_last_error(void);
 #define MC_DOMAIN_CVA 3u
 
 #define MC_MAX_ASSETS 16         /* basket sizes whose constants can travel as kernel arguments: 1..16 */
-#define MC_MAX_ASSETS_GENERIC 64 /* larger baskets (17..64) run a generic LDS-staged kernel */
+#define MC_MAX_ASSETS_GENERIC 64 /* largest basket: sizes up to 32 have register-resident kernels, 33..64 a generic one */
 
 /* ---- inputs (layouts == reference MonteCarlo.h of that precision) ------------------- */
 typedef struct { float s, k, r, v, t; } mc_option_f32;   /* OptionData, sp/MonteCarlo.h:33-39 */
