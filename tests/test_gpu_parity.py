@@ -161,7 +161,7 @@ def test_vanilla_shards_add_up_and_geometry_does_not_matter(mc, eng, X):
 
 # ---- basket -------------------------------------------------------------------------------
 @pytest.mark.parametrize("X", ["f32", "f64"])
-@pytest.mark.parametrize("n_assets", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 16])
+@pytest.mark.parametrize("n_assets", [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 13, 14, 15, 16])
 def test_basket_per_path_and_sums(mc, eng, po, X, n_assets):
     b = basket_inputs(mc, n_assets, X)
     n = 6000
@@ -470,7 +470,7 @@ def test_async_launches_are_graph_capturable(mc):
 
 
 @pytest.mark.parametrize("X", ["f32", "f64"])
-@pytest.mark.parametrize("n_assets", [17, 24, 33, 64])
+@pytest.mark.parametrize("n_assets", [17, 24, 30, 33, 64])
 def test_generic_basket_beyond_compiled_sizes(mc, eng, po, X, n_assets):
     """n > 16 runs the LDS-staged generic kernel (the reference's N is any compile-time constant):
     same stream, same estimator, same tolerances as the specialised kernels; also antithetic."""
