@@ -1049,6 +1049,30 @@ __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const Cv
     return a - b;
 }
 
+// fp64: the two dates of one Philox block together, so that their four Hastings reciprocals share one v_rcp_f64.
+// Same operations per date as bs_exposure except for that shared reciprocal.
+__device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaStep<double> &sa, double ln_b, double W_b,
+                                             const CvaStep<double> &sb, double &ee_a, double &ee_b)
+{
+#ifdef MC_AB_CVA_PER_DATE
+    ee_a = bs_exposure(ln_a, W_a, sa);
+    ee_b = bs_exposure(ln_b, W_b, sb);
+#else
+    const double spot_a = exp_f64(ln_a), spot_b = exp_f64(ln_b);
+    const double d1a = __builtin_fma(W_a, sa.g, sa.e1), d2a = __builtin_fma(W_a, sa.g, sa.e2);
+    const double d1b = __builtin_fma(W_b, sb.g, sb.e1), d2b = __builtin_fma(W_b, sb.g, sb.e2);
+    const double A_a = 0.39894228040143267793994605993438 * exp_f64(__builtin_fma(-0.5 * d1a, d1a, ln_a));
+    const double A_b = 0.39894228040143267793994605993438 * exp_f64(__builtin_fma(-0.5 * d1b, d1b, ln_b));
+    double k1a, k2a, k1b, k2b;
+    recip4_pos(__builtin_fma(0.2316419, fabs(d1a), 1.0), __builtin_fma(0.2316419, fabs(d2a), 1.0),
+               __builtin_fma(0.2316419, fabs(d1b), 1.0), __builtin_fma(0.2316419, fabs(d2b), 1.0), k1a, k2a, k1b, k2b);
+    const double t1a = A_a * hastings_poly(k1a), t2a = A_a * hastings_poly(k2a);
+    const double t1b = A_b * hastings_poly(k1b), t2b = A_b * hastings_poly(k2b);
+    ee_a = (d1a > 0 ? spot_a - t1a : t1a) - (d2a > 0 ? sa.disc - t2a : t2a);
+    ee_b = (d1b > 0 ? spot_b - t1b : t1b) - (d2b > 0 ? sb.disc - t2b : t2b);
+#endif
+}
+
 template <class Real, bool ANTI>
 __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, uint32_t c0)
 {
@@ -1058,6 +1082,24 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
     const int n_dates = o.n_bs + o.last_intrinsic;
     for (int j0 = 0; j0 < n_dates; j0 += NPB) {
         block_normals(c0, w.unit_hi, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, w.seed_lo, w.seed_hi, z);
+        if constexpr (sizeof(Real) == 8) {
+            if (j0 + 1 < o.n_bs) {  // wave-uniform: both dates of this block have a closed-form exposure
+                const CvaStep<double> sa = o.steps[j0], sb = o.steps[j0 + 1];
+                const double W_a = W + z[0], W_b = W_a + z[1];
+                W = W_b;
+                double ee_a, ee_b;
+                bs_exposure2(fma_r(W_a, o.bx, sa.xk), W_a, sa, fma_r(W_b, o.bx, sb.xk), W_b, sb, ee_a, ee_b);
+                if (ANTI) {
+                    double em_a, em_b;
+                    bs_exposure2(fma_r(-W_a, o.bx, sa.xk), -W_a, sa, fma_r(-W_b, o.bx, sb.xk), -W_b, sb, em_a, em_b);
+                    ee_a += em_a;
+                    ee_b += em_b;
+                }
+                acc = fma_r(sa.dp, ee_a, acc);
+                acc = fma_r(sb.dp, ee_b, acc);
+                continue;
+            }
+        }
 #pragma unroll
         for (int jj = 0; jj < NPB; ++jj) {
             const int j = j0 + jj;  // wave-uniform: the table is read through scalar loads

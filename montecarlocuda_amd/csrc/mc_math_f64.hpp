@@ -135,6 +135,20 @@ __device__ __forceinline__ void recip2_pos(double a, double b, double &ra, doubl
 #endif
 }
 
+// Four reciprocals from ONE v_rcp_f64: r = 1/(a1 a2 b1 b2), then products (14 instructions for four results
+// instead of 16 for two pairs, and one 16-cycle v_rcp_f64 instead of two).  Operands in [1, 3]: no range issue.
+__device__ __forceinline__ void recip4_pos(double a1, double a2, double b1, double b2, double &ra1, double &ra2, double &rb1,
+                                           double &rb2)
+{
+    const double pa = a1 * a2, pb = b1 * b2;
+    const double r = recip_pos(pa * pb);
+    const double qa = r * pb, qb = r * pa;  // 1/(a1 a2), 1/(b1 b2)
+    ra1 = qa * a2;
+    ra2 = qa * a1;
+    rb1 = qb * b2;
+    rb2 = qb * b1;
+}
+
 // natural log of a positive normal double
 __device__ __forceinline__ double log_unit(double x)
 {
@@ -216,8 +230,13 @@ __device__ __forceinline__ void sincos_turns_tab(uint32_t lo, uint32_t hi, doubl
     double pc = __builtin_fma(z, -1.0 / 720, 1.0 / 24);
     pc = __builtin_fma(z, pc, -0.5);
     const double cm = z * pc;                            // cos b - 1
+#ifdef MC_AB_LONG_COMBINE
     sin_out = e.x + __builtin_fma(e.x, cm, e.y * sb);
     cos_out = e.y + __builtin_fma(e.y, cm, -(e.x * sb));
+#else   // two fmas each instead of mul + fma + add: max error 1.65e-16 instead of 1.10e-16 (tools/check_f64_tables.c)
+    sin_out = __builtin_fma(e.y, sb, __builtin_fma(e.x, cm, e.x));
+    cos_out = __builtin_fma(-e.x, sb, __builtin_fma(e.y, cm, e.y));
+#endif
 }
 
 // (sin, cos) of 2*pi*u for u in [0, 1]: quadrant q = rint(4u), y = 4u - q in [-1/2, 1/2]

@@ -52,8 +52,8 @@ static void sincos_turns_tab(uint32_t lo, uint32_t hi, double *s, double *c)
     double pc = fma(z, -1.0 / 720, 1.0 / 24);
     pc = fma(z, pc, -0.5);
     const double cm = z * pc;
-    *s = e.x + fma(e.x, cm, e.y * sb);
-    *c = e.y + fma(e.y, cm, -(e.x * sb));
+    *s = fma(e.y, sb, fma(e.x, cm, e.x));
+    *c = fma(-e.x, sb, fma(e.y, cm, e.y));
 }
 
 static double exp_tab(double x)
