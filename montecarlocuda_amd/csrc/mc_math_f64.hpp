@@ -20,10 +20,10 @@
 // polynomial length for one 16-byte LDS read each -- LDS reads do not occupy the VALU:
 //   neg2log_unit_tab(u) ~16 + ds_read     128-entry table over the reduced mantissa: -2 ln m = t_i + S(m c2_i + 2),
 //                                         S a 7-term series on |r'| <= 2^-7            (replaces log_unit + a multiply)
-//   sincos_turns_tab    ~21 + ds_read     256-entry table of (sin, cos) at the slot centres, angle-addition with
-//                                         3-term series on |b| <= 2 pi / 512            (replaces sincos_turns)
+//   sincos_turns_tab    ~18 + ds_read     256-entry table of (sin, cos) at the slot centres, angle-addition with
+//                                         2-/3-term series on |b| <= 2 pi / 512          (replaces sincos_turns)
 // tools/check_f64_tables.c (host twin, vs 80-bit libm over 4e7 inputs): -2 ln u within 2.8e-16 relative,
-// sin/cos within 1.1e-16 absolute, the normal within 1.8e-15 absolute -- the same as the polynomial forms.
+// sin/cos within 1.7e-16 absolute, the normal within 1.8e-15 absolute -- the same as the polynomial forms.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -224,8 +224,7 @@ __device__ __forceinline__ void sincos_turns_tab(uint32_t lo, uint32_t hi, doubl
     const double y = __hiloint2double((int)mant_hi, (int)mant_lo) - (1.0 + 0x1p-9);   // (J mod 2^44) 2^-52 - 2^-9
     const double b = __builtin_fma(y, 6.283185307179586477, 6.283185307179586477 * 0x1p-53);
     const double z = b * b;
-    double ps = __builtin_fma(z, -1.0 / 5040, 1.0 / 120);
-    ps = __builtin_fma(z, ps, -1.0 / 6);
+    const double ps = __builtin_fma(z, 1.0 / 120, -1.0 / 6);   // sin b = b + b z ps; the next term is < 1e-17
     const double sb = __builtin_fma(z * b, ps, b);       // sin b
     double pc = __builtin_fma(z, -1.0 / 720, 1.0 / 24);
     pc = __builtin_fma(z, pc, -0.5);

@@ -46,8 +46,7 @@ static void sincos_turns_tab(uint32_t lo, uint32_t hi, double *s, double *c)
     const double y = dl - (1.0 + 0x1p-9);
     const double b = fma(y, 6.283185307179586477, 6.283185307179586477 * 0x1p-53);
     const double z = b * b;
-    double ps = fma(z, -1.0 / 5040, 1.0 / 120);
-    ps = fma(z, ps, -1.0 / 6);
+    const double ps = fma(z, 1.0 / 120, -1.0 / 6);   // sin b = b + b z ps; the next term is < 1e-17
     const double sb = fma(z * b, ps, b);
     double pc = fma(z, -1.0 / 720, 1.0 / 24);
     pc = fma(z, pc, -0.5);
