@@ -73,13 +73,16 @@ __device__ __forceinline__ void stage_f64_tables()
 // x = n ln2 + r, |r| <= ln2/2, Taylor to r^13: 19 instructions, max error 0.86 ulp.
 #if !defined(MC_AB_OCML_EXP) && !defined(MC_AB_EXP_POLY) && !defined(MC_AB_NO_TABLES)
 // Table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128;  e^x = 2^e * T_j * (1 + r + r^2/2 + ... + r^5/120).
-// 15 instructions + one 8-byte LDS read; max error 1.03 ulp (tools/check_f64_tables.c).
+// 14 instructions + one 8-byte LDS read; max error 1.03 ulp (tools/check_f64_tables.c).
 __device__ __forceinline__ double exp_f64(double x)
 {
-    const double n = __builtin_rint(x * 92.332482616893656877);
+    // n = rint(64 x / ln 2) by the 1.5 * 2^52 trick: after the fma the integer sits in the low mantissa bits
+    // (|n| < 2^31), so the int conversion is a register read and the rounding is the fma's own
+    const double shifted = __builtin_fma(x, 92.332482616893656877, 0x1.8p52);
+    const double n = shifted - 0x1.8p52;
     double r = __builtin_fma(n, -6.93147180369123816490e-01 / 64, x);
     r = __builtin_fma(n, -1.90821492927058770002e-10 / 64, r);
-    const int ni = (int)n;
+    const int ni = __double2loint(shifted);
     const double T = reinterpret_cast<const double *>(f64_tables + 384)[ni & 63];
     double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
     p = __builtin_fma(r, p, 1.0 / 6);

@@ -57,10 +57,13 @@ static void sincos_turns_tab(uint32_t lo, uint32_t hi, double *s, double *c)
 
 static double exp_tab(double x)
 {
-    const double n = rint(x * 92.332482616893656877);          /* 64 / ln 2 */
+    const double shifted = fma(x, 92.332482616893656877, 0x1.8p52);   /* 64 / ln 2; integer lands in the low mantissa bits */
+    const double n = shifted - 0x1.8p52;
     double r = fma(n, -6.93147180369123816490e-01 / 64, x);
     r = fma(n, -1.90821492927058770002e-10 / 64, r);
-    const int ni = (int)n;
+    uint32_t shi, slo;
+    split(shifted, &shi, &slo);
+    const int ni = (int)slo;
     const double T = ((const double *)(TAB + 384))[ni & 63];
     double p = fma(r, 1.0 / 120, 1.0 / 24);
     p = fma(r, p, 1.0 / 6);
