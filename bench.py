@@ -357,10 +357,10 @@ def main():
                 "note": "the same kernel, one launch at a time on one stream after the timed region"}
         if (prod, X) == ("vanilla", "f32"):
             # SURVEY 8d's second fraction: the issue-slot ceiling of this kernel's instruction mix.  Per wave-trip
-            # (4 paths per lane) the ISA has 52 full-rate VALU instructions (4.1-4.2 cycles each next to multiplies,
-            # tools/ubench) and 12 transcendentals (8.1-8.3 cycles); with the lower ends 310.4 cycles; 1024 SIMDs x
+            # (4 paths per lane) the ISA has 51 full-rate VALU instructions (4.1-4.2 cycles each next to multiplies,
+            # tools/ubench) and 12 transcendentals (8.1-8.3 cycles); with the lower ends 306.3 cycles; 1024 SIMDs x
             # 64 lanes at the clock tools/clock_probe.py measures inside this kernel (2.39 GHz).
-            cycles, clock = 52 * 4.1 + 12 * 8.1, 2.39e9
+            cycles, clock = 51 * 4.1 + 12 * 8.1, 2.39e9
             ceiling = 1024 * 64 * 4 / cycles * clock
             best = max(out["roofline"]["kernel_paths_per_s"] or 0, (exclusive and shard_count / exclusive[1]) or 0, value / world)
             out["roofline"]["issue_model"] = {

@@ -24,6 +24,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -164,7 +165,10 @@ static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_
     philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);  /* counter = {unit_hi, unit_lo, block, domain} */
 #ifdef MC_SINGLE_PRECISION
     for (int h = 0; h < 2; ++h) {
-        const float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f), ub = fmaf((float)x[2 * h + 1], 0x1p-32f, 0x1p-33f);
+        const float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f);
+        const uint32_t ub_bits = (x[2 * h + 1] >> 9) | 0x3f800000u;  /* angle in revolutions, in [1, 2): mc_rng.hpp angle_f32 */
+        float ub;
+        memcpy(&ub, &ub_bits, 4);
         const float radius = sqrtf(-1.3862943611198906f * log2f(ua));
         const double ang = 2.0 * M_PI * (double)ub;
         z[2 * h] = radius * (float)cos(ang);

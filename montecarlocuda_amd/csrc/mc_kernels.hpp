@@ -79,7 +79,7 @@ __device__ __forceinline__ void vanilla_unit_pk(const VanillaF32 &o, const Work 
     const u32x4 r = philox_unit(c0, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi);
     const f2 scale = {0x1p-32f, 0x1p-32f}, half = {0x1p-33f, 0x1p-33f};
     const f2 ua = __builtin_elementwise_fma((f2){(float)r.x, (float)r.z}, scale, half);  // radius uniforms
-    const f2 ub = __builtin_elementwise_fma((f2){(float)r.y, (float)r.w}, scale, half);  // angle uniforms
+    const f2 ub = {angle_f32(r.y), angle_f32(r.w)};  // angle uniforms (revolutions, in [1, 2))
     const f2 t = (f2){__builtin_amdgcn_logf(ua.x), __builtin_amdgcn_logf(ua.y)} * (f2){o.radius2, o.radius2};
     const f2 rad = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
     const f2 c = {__builtin_amdgcn_cosf(ub.x), __builtin_amdgcn_cosf(ub.y)};
@@ -478,9 +478,9 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, Co
         const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
         // Box-Muller pair X = words (x, y), pair Z = words (z, w); halves = {path A, path B}
         const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
-        const f2 ax = pk_fma((f2){(float)ra.y, (float)rb.y}, scale, half);
+        const f2 ax = {angle_f32(ra.y), angle_f32(rb.y)};
         const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
-        const f2 az = pk_fma((f2){(float)ra.w, (float)rb.w}, scale, half);
+        const f2 az = {angle_f32(ra.w), angle_f32(rb.w)};
         const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
         const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
         const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
@@ -695,9 +695,9 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const BasketDyn<f
             const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
             const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
             const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
-            const f2 ax = pk_fma((f2){(float)ra.y, (float)rb.y}, scale, half);
+            const f2 ax = {angle_f32(ra.y), angle_f32(rb.y)};
             const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
-            const f2 az = pk_fma((f2){(float)ra.w, (float)rb.w}, scale, half);
+            const f2 az = {angle_f32(ra.w), angle_f32(rb.w)};
             const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
             const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
             const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
@@ -890,9 +890,9 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const BasketDyn
             const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
             const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
             const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
-            const f2 ax = pk_fma((f2){(float)ra.y, (float)rb.y}, scale, half);
+            const f2 ax = {angle_f32(ra.y), angle_f32(rb.y)};
             const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
-            const f2 az = pk_fma((f2){(float)ra.w, (float)rb.w}, scale, half);
+            const f2 az = {angle_f32(ra.w), angle_f32(rb.w)};
             const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
             const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
             const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
@@ -1039,7 +1039,7 @@ __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const Cv
 {
     const double spot = exp_f64(ln_spot);
     const double d1 = __builtin_fma(W, st.g, st.e1), d2 = __builtin_fma(W, st.g, st.e2);
-    const double A = 0.39894228040143267793994605993438 * exp_f64(__builtin_fma(-0.5 * d1, d1, ln_spot));
+    const double A = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1, d1, ln_spot), -800.0));  // d1 runs away as tau -> 0
     double k1, k2;
     recip2_pos(__builtin_fma(0.2316419, fabs(d1), 1.0), __builtin_fma(0.2316419, fabs(d2), 1.0), k1, k2);
     const double t1 = A * hastings_poly(k1);
@@ -1061,8 +1061,8 @@ __device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaS
     const double spot_a = exp_f64(ln_a), spot_b = exp_f64(ln_b);
     const double d1a = __builtin_fma(W_a, sa.g, sa.e1), d2a = __builtin_fma(W_a, sa.g, sa.e2);
     const double d1b = __builtin_fma(W_b, sb.g, sb.e1), d2b = __builtin_fma(W_b, sb.g, sb.e2);
-    const double A_a = 0.39894228040143267793994605993438 * exp_f64(__builtin_fma(-0.5 * d1a, d1a, ln_a));
-    const double A_b = 0.39894228040143267793994605993438 * exp_f64(__builtin_fma(-0.5 * d1b, d1b, ln_b));
+    const double A_a = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));  // d1 runs away as tau -> 0
+    const double A_b = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1b, d1b, ln_b), -800.0));
     double k1a, k2a, k1b, k2b;
     recip4_pos(__builtin_fma(0.2316419, fabs(d1a), 1.0), __builtin_fma(0.2316419, fabs(d2a), 1.0),
                __builtin_fma(0.2316419, fabs(d1b), 1.0), __builtin_fma(0.2316419, fabs(d2b), 1.0), k1a, k2a, k1b, k2b);

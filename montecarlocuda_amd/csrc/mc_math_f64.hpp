@@ -76,8 +76,10 @@ __device__ __forceinline__ void stage_f64_tables()
 // 14 instructions + one 8-byte LDS read; max error 1.03 ulp (tools/check_f64_tables.c).
 __device__ __forceinline__ double exp_f64(double x)
 {
-    // n = rint(64 x / ln 2) by the 1.5 * 2^52 trick: after the fma the integer sits in the low mantissa bits
-    // (|n| < 2^31), so the int conversion is a register read and the rounding is the fma's own
+    // n = rint(64 x / ln 2) by the 1.5 * 2^52 trick: after the fma the integer sits in the low mantissa bits,
+    // so the int conversion is a register read and the rounding is the fma's own.  PRECONDITION |x| < 2e7
+    // (|n| < 2^31): beyond it the low word is garbage and so is the result -- callers whose argument can run
+    // away (CVA's exp(-d1^2/2) next to maturity) clamp it first.
     const double shifted = __builtin_fma(x, 92.332482616893656877, 0x1.8p52);
     const double n = shifted - 0x1.8p52;
     double r = __builtin_fma(n, -6.93147180369123816490e-01 / 64, x);

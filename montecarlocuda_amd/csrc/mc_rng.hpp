@@ -75,6 +75,15 @@ __device__ __forceinline__ float u01_f32(uint32_t x)
     return __builtin_fmaf((float)x, 0x1p-32f, 0x1p-33f);
 }
 
+// Angle uniform, in REVOLUTIONS, for v_sin_f32 / v_cos_f32: the top 23 bits of the word as the mantissa of a
+// float in [1, 2) -- one v_alignbit_b32, no conversion and no scaling.  sin and cos are periodic in whole
+// revolutions, so 1 + f and f give the same point of the circle; f = (x >> 9) 2^-23 takes 2^23 equally spaced
+// angles.  (The radius uniform keeps the (0, 1] form above: it goes through a logarithm.)
+__device__ __forceinline__ float angle_f32(uint32_t x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_alignbit(0x7fu, x, 9));
+}
+
 // Box-Muller on hardware transcendentals: v_log_f32 is log2, v_sin/v_cos_f32 take their
 // argument in revolutions, so 2*pi never appears.  `scale2` multiplies the squared radius:
 //   scale2 = -2 ln2        ->  plain N(0,1) pair
@@ -83,7 +92,7 @@ __device__ __forceinline__ void box_muller_f32(uint32_t xa, uint32_t xb, float s
                                                float &z_sin)
 {
     const float ua = u01_f32(xa);
-    const float ub = u01_f32(xb);
+    const float ub = angle_f32(xb);
     const float radius = __builtin_amdgcn_sqrtf(scale2 * __builtin_amdgcn_logf(ua));
     z_cos = radius * __builtin_amdgcn_cosf(ub);
     z_sin = radius * __builtin_amdgcn_sinf(ub);

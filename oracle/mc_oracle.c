@@ -5,6 +5,7 @@
  */
 #define _GNU_SOURCE
 #include <math.h>
+#include <string.h>
 #include <stdint.h>
 #include <stdlib.h>
 

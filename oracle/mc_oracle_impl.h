@@ -219,7 +219,7 @@ void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REA
 
 /* One Philox block -> NPB normals (NPB = 4 in f32, 2 in f64) by two-branch Box-Muller.
  *   counter = { unit_hi, unit_lo, block, domain },  key = { seed_lo, seed_hi }   (mc_rng.hpp: philox_unit)
- * f32: u = fma(x, 2^-32, 2^-33) in (0,1];  f64: u = ((x_hi:x_lo >> 12) + 0.5) 2^-52 in (0,1)
+ * f32: radius uniform u_a = fma(x, 2^-32, 2^-33) in (0,1], angle u_b = 1 + (x >> 9) 2^-23 revolutions;  f64: u = ((x_hi:x_lo >> 12) + 0.5) 2^-52 in (0,1)
  *   radius = sqrt(-2 ln u_a),  z_even = radius cos(2 pi u_b),  z_odd = radius sin(2 pi u_b)
  * The f32 radius is written with log2 (the HIP kernel's v_log_f32 is a base-2 log). */
 void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
@@ -231,7 +231,10 @@ void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t
 #if ORC_IS_F32
     for (int h = 0; h < 2; h++) {
         float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f);
-        float ub = fmaf((float)x[2 * h + 1], 0x1p-32f, 0x1p-33f);
+        /* angle in revolutions: top 23 bits of the word as the mantissa of a float in [1, 2) (mc_rng.hpp: angle_f32) */
+        uint32_t ub_bits = (x[2 * h + 1] >> 9) | 0x3f800000u;
+        float ub;
+        memcpy(&ub, &ub_bits, 4);
         float radius = sqrtf(-1.3862943611198906f * log2f(ua)); /* -2 ln 2 */
         double ang = 2.0 * M_PI * (double)ub;
         z[2 * h] = radius * (float)cos(ang);

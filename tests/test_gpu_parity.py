@@ -222,6 +222,18 @@ def test_basket_c3_c4_full_size_properties(mc, eng, po):
 
 
 # ---- CVA ----------------------------------------------------------------------------------
+def test_cva_last_date_a_hair_before_maturity_stays_finite(eng, po):
+    """75 dates in fp64 leave a residual maturity of 1.4e-15 on the last date: d1 ~ 1e7 there and
+    exp(-d1^2/2) has an argument of -1e14.  Every path must come out finite and equal to the oracle's
+    (a table-driven exp whose rounding trick is only valid for |x| < 2e7 once turned half of them into NaN)."""
+    c = dict(CVA0, n_grid=75)
+    got = eng.cva_paths(c, 200000, SEED, 0, "f64")
+    assert np.isfinite(got).all()
+    want, _ = po.dev_cva("f64", c, SEED, 0, 20000)
+    assert np.abs(got[:20000] - f64(want)).max() <= TOL["f64"]["cva"]
+    assert np.isfinite(eng.cva_paths(c, 200000, SEED, 0, "f32")).all()
+
+
 @pytest.mark.parametrize("X", ["f32", "f64"])
 @pytest.mark.parametrize("n_grid", [1, 2, 3, 25, 50, 75, 250, 256, 500])
 def test_cva_per_path_and_sums(eng, po, X, n_grid):
