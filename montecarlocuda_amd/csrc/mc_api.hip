@@ -414,6 +414,12 @@ static int upload_table(mc_context *c, hipStream_t st, const std::vector<char> &
 // ---------------------------------------------------------------------------------------
 static inline bool finite_pos(double x) { return std::isfinite(x) && x > 0; }
 
+// The fp64 kernels' exp is table-driven with a rounding trick that needs |x| < 2e7 (mc_math_f64.hpp); any model
+// whose exponent can leave the range of a double (|x| > ~700 at the generator's largest normal, 8.3 sigma) is
+// rejected up front instead of pricing garbage.
+constexpr double Z_MAX_F64 = 8.3;
+static inline bool exponent_in_range(double bound) { return std::isfinite(bound) && bound < 700.0; }
+
 template <class Real> struct VanillaTraits;
 template <> struct VanillaTraits<float> {
     using Opt = VanillaF32;
@@ -469,6 +475,8 @@ template <> struct VanillaTraits<double> {
         k.strike = o.k;
         k.spot = o.s;
         scale1 = scale2 = 1.0;
+        if (!exponent_in_range(std::fabs(k.drift) + k.vol * Z_MAX_F64))
+            return fail(MC_ERR_INVALID, "vanilla: (r - v^2/2) t and v sqrt(t) put the terminal spot outside the range of a double");
         return MC_OK;
     }
 };
@@ -656,6 +664,11 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
             m[a][b] = va * sqrt_t * (double)o.p[a * NA + b] * sc;
         base[a] = (((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc;
         coef[a] = (double)o.w[a] * (double)o.s[a];
+        double bound = std::fabs(base[a]);
+        for (int b = 0; b <= a; ++b)
+            bound += std::fabs(m[a][b]) * Z_MAX_F64;
+        if (!exponent_in_range(bound / sc))
+            return fail(MC_ERR_INVALID, "basket: asset %d's drift and volatility put its terminal price outside the range of a double", a);
     }
     scale = 1.0;
     if (is_f32) {
@@ -771,6 +784,11 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
         const double va = (double)o.v[a];
         host[n_tiles + a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
         host[n_tiles + np + a] = (Real)((double)o.w[a] * (double)o.s[a]);
+        double bound = std::fabs((double)host[n_tiles + a]);
+        for (int b = 0; b <= a; ++b)
+            bound += std::fabs((double)o.v[a] * sqrt_t * (double)o.p[a * n + b] * sc) * Z_MAX_F64;
+        if (!exponent_in_range(bound / sc))
+            return fail(MC_ERR_INVALID, "basket: asset %d's drift and volatility put its terminal price outside the range of a double", a);
     }
     double cg_dyn = 0;
     if (c->control) {
@@ -926,6 +944,8 @@ static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaS
     args.bx = (Real)((double)step_vol * sc);
     args.lgd = v.lgd;
     args.strike = o.k;
+    if (!exponent_in_range(std::fabs(ln_s0) + (double)v.n_grid * (std::fabs((double)step_drift) + std::fabs((double)step_vol) * Z_MAX_F64)))
+        return fail(MC_ERR_INVALID, "cva: drift and volatility put the simulated spot outside the range of a double");
     return MC_OK;
 }
 

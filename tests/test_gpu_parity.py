@@ -342,6 +342,15 @@ def test_invalid_arguments_are_errors_not_crashes(mc, eng):
         eng.basket(dict(s=[1.0] * n, v=[.1] * n, p=np.eye(n).tolist(), d=[0.0] * n, w=[1 / n] * n, k=1.0, t=1.0, r=0.0), 10)
     with pytest.raises(mc.McError):
         mc.Engine(99)
+    # models whose exponent would leave the range of a double are refused, not priced as garbage
+    with pytest.raises(mc.McError, match="range of a double"):
+        eng.vanilla(dict(VAN, v=60.0, t=4.0), 10, SEED, 0, "f64")
+    for n in (3, 12, 40):
+        wild = dict(s=[100.0] * n, v=[90.0] * n, p=np.eye(n).tolist(), d=[0.0] * n, w=[1 / n] * n, k=100.0, t=1.0, r=0.0)
+        with pytest.raises(mc.McError, match="range of a double"):
+            eng.basket(wild, 10, SEED, 0, "f64")
+    with pytest.raises(mc.McError, match="range of a double"):
+        eng.cva(dict(CVA0, v=30.0, n_grid=50), 10, SEED, 0, "f64")
 
 
 # ---- randomized inputs ----------------------------------------------------------------------------
