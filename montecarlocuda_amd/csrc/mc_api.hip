@@ -944,7 +944,9 @@ static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaS
     args.bx = (Real)((double)step_vol * sc);
     args.lgd = v.lgd;
     args.strike = o.k;
-    if (!exponent_in_range(std::fabs(ln_s0) + (double)v.n_grid * (std::fabs((double)step_drift) + std::fabs((double)step_vol) * Z_MAX_F64)))
+    // W is a sum of up to n_grid normals: its worst case is astronomically unlikely, so only the hard limit of the
+    // device's exp (|x| < 2e7) is enforced here; an honest overflow of the spot gives inf, as it would on any machine
+    if (!(std::fabs(ln_s0) + (double)v.n_grid * (std::fabs((double)step_drift) + std::fabs((double)step_vol) * Z_MAX_F64) < 1e7))
         return fail(MC_ERR_INVALID, "cva: drift and volatility put the simulated spot outside the range of a double");
     return MC_OK;
 }

@@ -350,7 +350,7 @@ def test_invalid_arguments_are_errors_not_crashes(mc, eng):
         with pytest.raises(mc.McError, match="range of a double"):
             eng.basket(wild, 10, SEED, 0, "f64")
     with pytest.raises(mc.McError, match="range of a double"):
-        eng.cva(dict(CVA0, v=30.0, n_grid=50), 10, SEED, 0, "f64")
+        eng.cva(dict(CVA0, v=3.0e5, n_grid=50), 10, SEED, 0, "f64")
 
 
 # ---- randomized inputs ----------------------------------------------------------------------------

@@ -12,6 +12,7 @@ from oracle import pyoracle as po     # the checker
 po.build()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+EXTREME = len(sys.argv) > 3 and sys.argv[3] == "extreme"   # tiny / large vols and maturities, far strikes, odd rates
 TOL = {"f32": dict(pay=2e-6, cva=2e-5), "f64": dict(pay=1e-14, cva=1e-13)}
 worst, bad = {}, 0
 eng = {(a, c): mc.Engine(0) for a in (False, True) for c in (False, True)}
@@ -37,11 +38,16 @@ for it in range(cases):
     prod = rng.choice(["vanilla", "basket", "basket", "cva"])
     spot = float(np.exp(rng.uniform(np.log(5), np.log(500))))
     r, t = float(rng.uniform(0.0, 0.08)), float(rng.choice([0.25, 0.5, 1.0, 2.0, 3.0]))
+    vol_lo, vol_hi, k_lo, k_hi = 0.05, 0.6, 0.6, 1.5
+    if EXTREME:
+        r, t = float(rng.uniform(-0.05, 0.4)), float(np.exp(rng.uniform(np.log(1e-4), np.log(30.0))))
+        vol_lo, vol_hi, k_lo, k_hi = 0.002, 1.5, 0.05, 20.0
     if prod == "vanilla":
-        o = dict(s=spot, k=spot * float(rng.uniform(0.6, 1.5)), r=r, v=float(rng.uniform(0.05, 0.6)), t=t)
+        o = dict(s=spot, k=spot * float(rng.uniform(k_lo, k_hi)), r=r, v=float(rng.uniform(vol_lo, vol_hi)), t=t)
         got = eng[(anti, False)].vanilla_paths(o, n_paths, seed, first, X).astype(np.float64)
         want, _ = po.dev_vanilla(X, o, seed, first, n_paths, antithetic=anti)
-        note((prod, X), float(np.abs(got - want.astype(np.float64)).max()), TOL[X]["pay"] * spot * 3, (o, anti, first, n_paths))
+        level = spot * float(np.exp(max(0.0, r) * t + 4 * o["v"] * np.sqrt(t)))   # payoffs (and their rounding) scale with the reachable spot
+        note((prod, X), float(np.abs(got - want.astype(np.float64)).max()), TOL[X]["pay"] * level * 3, (o, anti, first, n_paths))
     elif prod == "basket":
         n = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 19, 23, 28, 32, 33, 40, 64]))
         cv = bool(rng.random() < 0.3)
@@ -53,18 +59,21 @@ for it in range(cases):
         w = rng.uniform(0.5, 1.5, n)
         w = (w / w.sum() * float(rng.uniform(0.8, 1.2))).tolist()
         s = (spot * rng.uniform(0.7, 1.3, n)).tolist()
-        b = dict(s=s, v=rng.uniform(0.05, 0.5, n).tolist(), p=L.tolist(), d=(rng.uniform(-0.02, 0.02, n) if rng.random() < 0.3 else np.zeros(n)).tolist(),
-                 w=w, k=float(np.dot(w, s) * rng.uniform(0.7, 1.3)), t=t, r=r)
+        b = dict(s=s, v=rng.uniform(vol_lo, min(vol_hi, 0.9), n).tolist(), p=L.tolist(), d=(rng.uniform(-0.02, 0.02, n) if rng.random() < 0.3 else np.zeros(n)).tolist(),
+                 w=w, k=float(np.dot(w, s) * rng.uniform(max(k_lo, 0.3), min(k_hi, 3.0))), t=t, r=r)
         got = eng[(anti, cv)].basket_paths(b, n_paths, seed, first, X).astype(np.float64)
         want, _ = po.dev_basket(X, b, seed, first, n_paths, antithetic=anti, control=cv)
-        level = float(np.dot(w, s)) * (1 + 4 * max(b["v"]) * np.sqrt(t))      # payoffs scale with the basket level and its spread
+        level = float(np.dot(w, s)) * float(np.exp(max(0.0, r) * t + 4 * max(b["v"]) * np.sqrt(t)))   # reachable basket level
         note((prod, X), float(np.abs(got - want.astype(np.float64)).max()), TOL[X]["pay"] * level * 4 * (1 + n / 16), (n, anti, cv, first, n_paths))
     else:
-        c = dict(s=spot, k=spot * float(rng.uniform(0.7, 1.3)), r=r, v=float(rng.uniform(0.1, 0.5)), t=t,
-                 defint=float(rng.uniform(0.005, 0.1)), lgd=float(rng.uniform(0.2, 0.9)), n_grid=int(rng.integers(1, 300)))
+        c = dict(s=spot, k=spot * float(rng.uniform(max(k_lo, 0.2), min(k_hi, 5.0))), r=r, v=float(rng.uniform(max(vol_lo, 0.02), min(vol_hi, 1.0))), t=t,
+                 defint=float(rng.uniform(0.005, 0.1)), lgd=float(rng.uniform(0.2, 0.9)), n_grid=int(rng.integers(1, 1500 if EXTREME else 300)))
         got = eng[(anti, False)].cva_paths(c, min(n_paths, 200), seed, first, X).astype(np.float64)
         want, _ = po.dev_cva(X, c, seed, first, min(n_paths, 200), antithetic=anti)
-        note((prod, X), float(np.abs(got - want.astype(np.float64)).max()), TOL[X]["cva"] * spot / 100 * 3, (c, anti, first))
+        level = spot * float(np.exp(max(0.0, r) * t + 4 * c["v"] * np.sqrt(t)))
+        note((prod, X), float(np.abs(got - want.astype(np.float64)).max()), TOL[X]["cva"] * level / 100 * 3 * (1 + c["n_grid"] / 256), (c, anti, first))
+if not all(np.isfinite(v) for v in worst.values()):
+    bad += 1
 for k in sorted(worst):
     print(f"{k[0]:8s} {k[1]}: worst error / bound = {worst[k]:.3f}")
 print(f"{cases} cases, {bad} violations")
