@@ -1,0 +1,25 @@
+"""The library's Makefile rule must list every local file the translation unit includes: a header missing from the
+prerequisites means `make` keeps a stale libmc_mi355x.so after an edit to it (that happened once with
+mc_math_f64.hpp, and a fix was "tested" against the old binary)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "montecarlocuda_amd", "csrc")
+
+
+def local_includes(path, seen):
+    for name in re.findall(r'^\s*#\s*include\s+"([^"]+)"', open(path).read(), flags=re.M):
+        full = os.path.join(CSRC, name)
+        if os.path.exists(full) and name not in seen:
+            seen.add(name)
+            local_includes(full, seen)
+    return seen
+
+
+def test_makefile_lists_every_included_file():
+    needed = local_includes(os.path.join(CSRC, "mc_api.hip"), set())
+    assert {"mc_kernels.hpp", "mc_rng.hpp", "mc_math_f64.hpp", "mc_tables_f64.inc", "mc_reduce.hpp"} <= needed
+    rule = re.search(r"^libmc_mi355x\.so:(.*)$", open(os.path.join(CSRC, "Makefile")).read(), flags=re.M).group(1).split()
+    missing = sorted(n for n in needed if n not in rule)
+    assert not missing, f"Makefile rule for libmc_mi355x.so does not depend on {missing}"
