@@ -53,3 +53,30 @@ def test_cva_driver_all_grids():
     assert out.count("--- exposure dates:") == 5
     vals = [float(x) for x in re.findall(r"^(0\.1[89]\d+) $", out, flags=re.M)]
     assert len(vals) >= 20 and all(0.17 < v < 0.21 for v in vals)
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_basket_driver_with_sixteen_assets(X, tmp_path):
+    """The reference's "edit #define N" as a build variable: legacy and host libraries plus the basket driver built
+    for N = 16 in a scratch directory (the in-tree N = 3 builds stay untouched), linked against the in-tree engine.
+    The GPU leg then runs the tiled kernels; CPU twin and GPU agree to rounding on the shared stream."""
+    csrc, inc = os.path.join(ROOT, "montecarlocuda_amd", "csrc"), os.path.join(ROOT, "include")
+    prec = [] if X == "f64" else ["-DMC_SINGLE_PRECISION"]
+    common = ["-DN=16", f"-I{inc}", *prec, f"-L{csrc}", "-lmc_mi355x", f"-Wl,-rpath,{csrc}"]
+    subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", str(tmp_path / f"libmcgpu_{X}.so"),
+                           os.path.join(csrc, "legacy_abi.c"), *common])
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared", "-o",
+                           str(tmp_path / f"libmchost_{X}.so"), os.path.join(csrc, "host_path.c"), *common, "-lm"])
+    exe = tmp_path / f"basketOpt16_{X}"
+    # the scratch directory comes first on the link line and in the run path: csrc holds N = 3 builds of the same names
+    subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-DN=16", f"-I{inc}", *prec, f"-I{os.path.join(ROOT, 'drivers')}", "-o", str(exe),
+                           os.path.join(ROOT, "drivers", "basketOpt.c"), f"-L{tmp_path}", f"-Wl,-rpath,{tmp_path}", f"-lmcgpu_{X}",
+                           f"-lmchost_{X}", f"-L{csrc}", f"-Wl,-rpath,{csrc}", "-lmc_mi355x", "-lm"])
+    out = subprocess.run([str(exe), "4"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "Basket Option with 16 underlyings" in out.stdout and "zero pivot" not in out.stdout
+    cpu = floats_after(out.stdout, "Expected price, I.C., time [s]\n", 3)
+    gpu = floats_after(out.stdout, "Speedup :\n", 4)
+    tol = 2e-6 if X == "f64" else 2e-4
+    assert abs(cpu[0] - gpu[0]) < tol and abs(cpu[1] - gpu[1]) < tol
+    assert 0.0 < gpu[0] < 100.0 and gpu[1] > 0
