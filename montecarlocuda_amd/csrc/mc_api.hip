@@ -965,8 +965,28 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     memcpy(key.data(), key_vals, sizeof key_vals);
     static thread_local std::vector<CvaStep<Real>> tab;
     if (int rc = build_cva_table<Real>(*v, tab, args)) return rc;
-    const size_t bytes = tab.size() * sizeof(CvaStep<Real>);
-    if (int rc = upload_table(c, st, key, tab.data(), bytes)) return rc;
+    const size_t step_bytes = tab.size() * sizeof(CvaStep<Real>);
+    size_t bytes = step_bytes;
+    args.pairs = nullptr;
+    if constexpr (sizeof(Real) == 4) {
+        // fp32: the closed-form rows once more, two dates per row and field by field, so that a date pair's
+        // {g, g'} ... {dp, dp'} are adjacent scalars = ready-made operands of the packed instructions
+        static thread_local std::vector<float> blob;
+        const int n_pairs = args.n_bs / 2;
+        blob.resize(step_bytes / sizeof(float) + (size_t)12 * n_pairs);
+        memcpy(blob.data(), tab.data(), step_bytes);
+        float *row = blob.data() + step_bytes / sizeof(float);
+        for (int q = 0; q < n_pairs; ++q, row += 12) {
+            const CvaStep<float> &a = tab[2 * q], &b = tab[2 * q + 1];
+            const float vals[12] = {a.g, b.g, a.e1, b.e1, a.e2, b.e2, a.xk, b.xk, a.disc, b.disc, a.dp, b.dp};
+            memcpy(row, vals, sizeof vals);
+        }
+        bytes = blob.size() * sizeof(float);
+        if (int rc = upload_table(c, st, key, blob.data(), bytes)) return rc;
+        args.pairs = (const float *)((const char *)c->d_table + step_bytes);
+    } else {
+        if (int rc = upload_table(c, st, key, tab.data(), bytes)) return rc;
+    }
     args.steps = (const CvaStep<Real> *)c->d_table;
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;

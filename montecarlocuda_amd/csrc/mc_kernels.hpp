@@ -994,6 +994,8 @@ struct CvaStep {
 template <class Real>
 struct CvaArgs {
     const CvaStep<Real> *steps;  // n_bs Black-Scholes dates (+1 intrinsic date if last_intrinsic)
+    const float *pairs;          // fp32 only: the same rows for date pairs (2q, 2q + 1), field by field:
+                                 // {g, g', e1, e1', e2, e2', xk, xk', disc, disc', dp, dp'}, floor(n_bs / 2) pairs
     int n_bs;                    // dates priced with the closed form
     int last_intrinsic;          // 1: one more date, residual maturity == 0
     Real bx;                     // v sqrt(dt) (times log2 e in f32)
@@ -1024,6 +1026,37 @@ __device__ __forceinline__ float bs_exposure(float ln2_spot, float W, const CvaS
     const float a = d.x > 0 ? spot - t.x : t.x;
     const float b = d.y > 0 ? st.disc - t.y : t.y;
     return a - b;
+}
+
+// fp32, TWO consecutive dates of one path in the halves of every packed op (the form above packs d1, d2 of one
+// date): the same operations per date, but the spot's exponent, A, the selects' subtractions and the dp-weighted
+// accumulation now issue packed as well.  `row` = 12 floats {g, e1, e2, xk, disc, dp} x {date, next date}.
+__device__ __forceinline__ f2 bs_exposure_dates(f2 ln2_spot, f2 W, const float *row)
+{
+    const f2 g = {row[0], row[1]}, e1 = {row[2], row[3]}, e2 = {row[4], row[5]}, disc = {row[8], row[9]};
+    const f2 spot = {__builtin_amdgcn_exp2f(ln2_spot.x), __builtin_amdgcn_exp2f(ln2_spot.y)};
+    const f2 d1 = __builtin_elementwise_fma(W, g, e1), d2 = __builtin_elementwise_fma(W, g, e2);
+    const f2 a = __builtin_elementwise_fma(d1 * (f2){-0.72134752044448170f, -0.72134752044448170f}, d1, ln2_spot);
+    const f2 A = (f2){0.3989422804014327f, 0.3989422804014327f} * (f2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f2 c = {0.2316419f, 0.2316419f}, one = {1.0f, 1.0f};
+    const f2 den1 = __builtin_elementwise_fma(c, __builtin_elementwise_abs(d1), one);
+    const f2 den2 = __builtin_elementwise_fma(c, __builtin_elementwise_abs(d2), one);
+    const f2 k1 = {__builtin_amdgcn_rcpf(den1.x), __builtin_amdgcn_rcpf(den1.y)};
+    const f2 k2 = {__builtin_amdgcn_rcpf(den2.x), __builtin_amdgcn_rcpf(den2.y)};
+    const f2 c4 = {1.330274429f, 1.330274429f}, c3 = {-1.821255978f, -1.821255978f}, c2 = {1.781477937f, 1.781477937f},
+             c1 = {-0.356563782f, -0.356563782f}, c0 = {0.31938153f, 0.31938153f};
+    f2 p1 = __builtin_elementwise_fma(k1, c4, c3), p2 = __builtin_elementwise_fma(k2, c4, c3);
+    p1 = __builtin_elementwise_fma(k1, p1, c2);
+    p2 = __builtin_elementwise_fma(k2, p2, c2);
+    p1 = __builtin_elementwise_fma(k1, p1, c1);
+    p2 = __builtin_elementwise_fma(k2, p2, c1);
+    p1 = __builtin_elementwise_fma(k1, p1, c0);
+    p2 = __builtin_elementwise_fma(k2, p2, c0);
+    const f2 t1 = p1 * k1 * A, t2 = p2 * k2 * A;
+    const f2 s1 = spot - t1, s2 = disc - t2;
+    const f2 va = {d1.x > 0 ? s1.x : t1.x, d1.y > 0 ? s1.y : t1.y};
+    const f2 vb = {d2.x > 0 ? s2.x : t2.x, d2.y > 0 ? s2.y : t2.y};
+    return va - vb;
 }
 
 __device__ __forceinline__ double hastings_poly(double k)
@@ -1078,10 +1111,29 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
 {
     constexpr int NPB = npb<Real>::value;
     Real W = 0, acc = 0;
+    f2 acc2 = {0.0f, 0.0f};  // fp32: even / odd dates of the packed date pairs
     Real z[NPB];
     const int n_dates = o.n_bs + o.last_intrinsic;
     for (int j0 = 0; j0 < n_dates; j0 += NPB) {
         block_normals(c0, w.unit_hi, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, w.seed_lo, w.seed_hi, z);
+        if constexpr (sizeof(Real) == 4) {
+#ifndef MC_AB_CVA_F32_PER_DATE
+            if (j0 + 3 < o.n_bs) {  // wave-uniform: all four dates of this block have a closed-form exposure
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float *row = o.pairs + 12 * (j0 / 2 + h);
+                    const f2 Wp = {W + z[2 * h], (W + z[2 * h]) + z[2 * h + 1]};
+                    W = Wp.y;
+                    const f2 bx = {o.bx, o.bx}, xk = {row[6], row[7]}, dp = {row[10], row[11]};
+                    f2 ee = bs_exposure_dates(__builtin_elementwise_fma(Wp, bx, xk), Wp, row);
+                    if (ANTI)
+                        ee += bs_exposure_dates(__builtin_elementwise_fma(-Wp, bx, xk), -Wp, row);
+                    acc2 = __builtin_elementwise_fma(dp, ee, acc2);
+                }
+                continue;
+            }
+#endif
+        }
         if constexpr (sizeof(Real) == 8) {
             if (j0 + 1 < o.n_bs) {  // wave-uniform: both dates of this block have a closed-form exposure
                 const CvaStep<double> sa = o.steps[j0], sb = o.steps[j0 + 1];
@@ -1125,6 +1177,8 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
             }
         }
     }
+    if constexpr (sizeof(Real) == 4)
+        acc += acc2.x + acc2.y;
     return acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);
 }
 
