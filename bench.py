@@ -322,13 +322,14 @@ def main():
         value = units_per_step * K / elapsed
         kernel_s = (kernel_ms_total / samples) * 1e-3 if samples else None
         ach = flop_per_path * shard_count / kernel_s / 1e12 if kernel_s else None
-        traffic = None
+        traffic = valu_busy = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(args.workload, {}).get("hbm_bytes_per_launch")
+                rec = json.load(open(pmc)).get(args.workload, {})
+                traffic, valu_busy = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_long_launch")
             except Exception:
-                traffic = None
+                traffic = valu_busy = None
         out = {
             "metric": "Monte Carlo paths/sec", "value": value, "unit": "paths/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
@@ -342,6 +343,7 @@ def main():
                          "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,
                          "kernel": kernel_name(prod, X, inputs), "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
                          "kernel_samples": samples, "flop_per_path": flop_per_path,
+                         "valu_busy": valu_busy,   # PMC, committed profile of a ~10 ms launch of this kernel (not measured live)
                          "kernel_paths_per_s": shard_count / kernel_s if kernel_s else None,
                          "concurrent_launches": len(engines), "step_period_us": elapsed / K * 1e6,
                          "note": "with 2 streams consecutive launches overlap (a launch's tail and finishing kernel run "
