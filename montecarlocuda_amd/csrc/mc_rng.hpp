@@ -103,11 +103,11 @@ constexpr float NEG_2LN2_F32 = -1.3862943611198906f;
 // ---- f64 ---------------------------------------------------------------------------------
 // 52-bit uniform strictly inside (0,1): ((hi:lo >> 12) + 0.5) * 2^-52, exact in double.
 // Built from bits: [1,2) mantissa fill, then one exact add of -(1 - 2^-53)
-// (v_alignbit, v_lshrrev, v_or, v_add_f64 instead of two int->double conversions and two fmas).
+// (two v_alignbit + v_add_f64 instead of two int->double conversions and two fmas).
 __device__ __forceinline__ double u01_f64(uint32_t lo, uint32_t hi)
 {
     const uint32_t mant_lo = __builtin_amdgcn_alignbit(hi, lo, 12);
-    const uint32_t mant_hi = (hi >> 12) | 0x3ff00000u;
+    const uint32_t mant_hi = __builtin_amdgcn_alignbit(0x3ffu, hi, 12);  // (hi >> 12) | 0x3ff00000 in one instruction
     return __hiloint2double((int)mant_hi, (int)mant_lo) + (-1.0 + 0x1p-53);
 }
 
