@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="independent (context, HIP stream) pairs the steps rotate over; >1 lets consecutive pricing "
                          "calls overlap each other's launch gaps and finishing kernels")
+    ap.add_argument("--stream-source", default="torch", choices=["torch", "context"],
+                    help="where the launch streams come from: torch's stream pool, or each context's own stream")
     ap.add_argument("--profile-every", type=int, default=8)
     ap.add_argument("--blocks", type=int, default=0, help="workgroups per launch (0 = the engine's default, 8 per CU)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -158,6 +160,13 @@ def main():
     ap.add_argument("--exclusive-launches", type=int, default=50,
                     help="after the timed region, this many launches one at a time on one stream, each timed on the device: "
                          "the kernel's duration without a neighbour (roofline.exclusive); 0 = skip")
+    ap.add_argument("--finish", default="fused", choices=["fused", "kernel"],
+                    help="fused (default): the last workgroup of a call adds the per-workgroup pairs inside the simulation "
+                         "kernel (one launch per call). kernel: a second one-workgroup launch does (A/B baseline)")
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed device work before the warm-up steps, so that the W warm-up steps and the K timed steps "
+                         "run at the GPU's sustained clock (a cold MI355X needs tens of ms of load to ramp; with --warmup 5 "
+                         "the timed region would otherwise measure the ramp).  Reported as config.preheat_ms; 0 = off")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
@@ -177,6 +186,8 @@ def main():
     torch.cuda.set_device(local)
     grouped = dist.is_initialized()   # one process per GPU under torch.distributed.run (RCCL), also for N=1
     engines = [mc.Engine(local, args.blocks) for _ in range(max(1, args.streams))]
+    for e_ in engines:
+        e_.set_finish(args.finish == "fused")
     eng = engines[0]
     prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
     if callable(inputs):
@@ -188,7 +199,10 @@ def main():
     seed = mc.MC_DEFAULT_SEED
     # Explicit non-default streams, one per context; the first is made torch's CURRENT stream so that
     # torch's copies and RCCL's waits are ordered behind the launches.
-    streams = [torch.cuda.Stream(device=local) for _ in engines]
+    if args.stream_source == "context":   # every context's own non-blocking stream (mc_context_stream)
+        streams = [torch.cuda.ExternalStream(e.stream, device=local) for e in engines]
+    else:
+        streams = [torch.cuda.Stream(device=local) for _ in engines]
     stream = streams[0]
     torch.cuda.set_stream(stream)
     assert all(s_.cuda_stream != 0 for s_ in streams)
@@ -240,6 +254,20 @@ def main():
             dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
+    preheat_ms = 0.0
+    if args.preheat_ms > 0:
+        # same kernel, same inputs, its own output slot; path ranges far above the timed steps'
+        scratch = torch.zeros((len(engines), 3), dtype=torch.float64, device="cuda")
+        t_pre = time.perf_counter()
+        j = 0
+        while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+            for _ in range(64):
+                e = j % len(engines)
+                engines[e].launch(prod, X, structs[e][0], seed, (1 << 50) + j * shard_count, shard_count, scratch[e].data_ptr(),
+                                  streams[e].cuda_stream)
+                j += 1
+            torch.cuda.synchronize()
+        preheat_ms = (time.perf_counter() - t_pre) * 1e3
     for i in range(W):
         step(i)
     drain()
@@ -337,7 +365,8 @@ def main():
             "config": {"workload": desc, "paths_per_gpu_per_step": shard_count, "global_paths_per_step": units_per_step,
                        "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
-                       "grid": f"{eng.blocks}x256", "streams": len(engines)},
+                       "grid": f"{eng.blocks}x256", "streams": len(engines), "finish": args.finish,
+                       "preheat_ms": round(preheat_ms, 1)},
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
             "roofline": {"bound": "valu", "achieved": ach, "peak": PEAK_TFLOPS[X], "unit": "TFLOP/s",
                          "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,

@@ -17,7 +17,7 @@ static double now_s(void)
 }
 
 /* <prog> [multiplier] [--no-cpu]   : simulations = multiplier x 131072, as in the reference */
-static int parse_args(int argc, char **argv, int *multiplier, int *run_cpu)
+__attribute__((unused)) static int parse_args(int argc, char **argv, int *multiplier, int *run_cpu)
 {
     *multiplier = 8;
     *run_cpu = 1;

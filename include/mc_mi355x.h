@@ -82,7 +82,10 @@ typedef struct {
     double confidence;  /* 1.96 s / sqrt(n)        dp/MonteCarloKernel.cu:421-422          */
     double sum, sum2;   /* sum and sum of squares of the per-path values                   */
     uint64_t n;         /* paths simulated                                                 */
-    float kernel_ms;    /* device time of the simulation + reduction kernels (HIP events)  */
+    float kernel_ms;    /* device time of the call's kernels (HIP events around them)       */
+    float wall_ms;      /* host wall-clock of the whole call: entry to return, launch, wait and
+                         * 24-byte read-back included (what the reference's drivers time around
+                         * dev_*: dp/vanillaOpt.cu:77-83); context creation is NOT in it          */
 } mc_result;
 
 /* ---- context ------------------------------------------------------------------------ */
@@ -116,6 +119,13 @@ int mc_context_set_antithetic(mc_context *ctx, int on);
  * all-reduce.  Needs w[a] > 0, s[a] > 0, k > 0.  Combines with antithetic variates.  Typical
  * variance reduction on the BASELINE baskets: ~150x (x2.5 more with antithetic). */
 int mc_context_set_control_variate(mc_context *ctx, int on);
+
+/* Where a call's per-workgroup (sum, sum2) pairs are added up (replaces the reference's D2H copy and host loop
+ * over blocks, dp/MonteCarloKernel.cu:405,416-419).  fused != 0 (default): inside the simulation kernel, by the
+ * last workgroup to arrive -- one launch per call.  fused == 0: by a second, one-workgroup launch (the A/B
+ * baseline; also selected by the environment variable MC_FINISH=kernel at context creation).  Both add the pairs
+ * in the same fixed order: the results are identical bits. */
+int mc_context_set_finish(mc_context *ctx, int fused);
 int mc_basket_control_mean_f32(const mc_basket_f32 *opt, double *mean);
 int mc_basket_control_mean_f64(const mc_basket_f64 *opt, double *mean);
 

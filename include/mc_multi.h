@@ -1,0 +1,81 @@
+/*
+ * mc_multi.h -- C ABI of libmc_multi.so: one pricing call sharded over several MI355X of one node, driven by
+ * ONE host process, closed by ONE RCCL all-reduce of the 24-byte {sum, sum2, n} triple over xGMI.
+ *
+ * New relative to the reference, which is strictly single-device (no cudaSetDevice, no NCCL/MPI anywhere:
+ * SURVEY 2.2); it fans out the reference's three GPU entry points
+ *     dev_basketOpt / dev_vanillaOpt / dev_cvaEquityOption      dp/MonteCarloKernel.cu:483,500,517
+ * the way BASELINE.json's north_star asks: host code stays in C, "paths shard embarrassingly across the 8 GPUs
+ * of one node with a final RCCL all-reduce of partial (sum, sum^2) over xGMI".
+ *
+ * How a call runs (mc_multi.cpp):
+ *   device g of G owns the contiguous global paths [first + floor(g n / G), first + floor((g+1) n / G))
+ *   (mc_shard_range), same seed: a path's normals depend only on (seed, global path index), so the union of the
+ *   shards IS the single-GPU sample; every device's launch (mc_*_launch_*, include/mc_mi355x.h) is enqueued from
+ *   the calling thread on that device's own stream and leaves its triple in that device's HBM; then ONE grouped
+ *   ncclAllReduce(count = 3, ncclDouble, ncclSum) on the same streams (communicators from ncclCommInitAll, created
+ *   once with the handle, never per call), 24 bytes read back from the first device, closing formulas on the host.
+ *   The pre-reduction triples are read back as well and added on the host in device order: the cross-check of the
+ *   collective (they must agree to 1e-12 relative, else the call fails) and, with MC_MULTI_REDUCE=host or
+ *   mc_multi_set_reduce(m, MC_REDUCE_HOST), the result itself -- no RCCL needed then (also the only way to list
+ *   one device twice, which RCCL refuses: used by the tests to exercise G > 1 on a one-GPU box).
+ *
+ * The legacy symbols (libmcgpu_f32/_f64.so) take this path when the environment variable MC_DEVICES is set
+ * ("0,1,2,3" or "all"); without it they keep using one device (MC_DEVICE) and never load RCCL.
+ *
+ * Results: sums differ from the single-device call only in the order of fp64 additions (per-workgroup pairs are
+ * added per device first): <= 1e-12 relative in fp64, <= 2e-9 in fp32 (the fp32 kernels add up to 16 values in
+ * float before each flush to double, and which 16 depends on the shard boundaries).  Errors: status codes as in
+ * mc_mi355x.h, text from mc_multi_last_error().
+ */
+#ifndef MC_MULTI_H_
+#define MC_MULTI_H_
+
+#include "mc_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mc_multi mc_multi;
+
+enum { MC_REDUCE_RCCL = 0, MC_REDUCE_HOST = 1 };
+
+/* devices: HIP device ordinals, n_devices of them; devices == NULL means 0 .. n_devices-1, and n_devices <= 0
+ * with devices == NULL means every visible device.  blocks as in mc_context_create (0 = default grid).
+ * One mc_context per listed device (replaces dp/MonteCarloKernel.cu:296 MonteCarlo_init, once instead of per call). */
+int mc_multi_create(const int *devices, int n_devices, int blocks, mc_multi **out);
+void mc_multi_destroy(mc_multi *m);
+int mc_multi_size(const mc_multi *m);
+/* the i-th device's context (e.g. for mc_context_info); owned by the handle */
+mc_context *mc_multi_context(mc_multi *m, int i);
+/* estimator switches, applied to every device (mc_context_set_antithetic / _control_variate) */
+int mc_multi_set_antithetic(mc_multi *m, int on);
+int mc_multi_set_control_variate(mc_multi *m, int on);
+/* MC_REDUCE_RCCL (default; MC_MULTI_REDUCE=host in the environment selects the other) or MC_REDUCE_HOST */
+int mc_multi_set_reduce(mc_multi *m, int mode);
+/* Text of the last failure of an mc_multi_* call on this thread ("" if none). */
+const char *mc_multi_last_error(void);
+/* |RCCL sum - host sum| / |host sum| of the last call's `sum` (0 when the host did the reduction) */
+double mc_multi_last_reduce_error(const mc_multi *m);
+
+/* Synchronous sharded runs.  out->kernel_ms = the slowest device's simulation time (HIP events on its stream),
+ * out->wall_ms = host wall-clock from the first launch to the closed estimate ("wall-clock from first
+ * launch to the all-reduced result").  Same arguments as mc_*_run_* (include/mc_mi355x.h). */
+int mc_multi_vanilla_run_f32(mc_multi *m, const mc_option_f32 *opt, uint64_t seed, uint64_t first_path,
+                             uint64_t n_paths, mc_result *out);
+int mc_multi_vanilla_run_f64(mc_multi *m, const mc_option_f64 *opt, uint64_t seed, uint64_t first_path,
+                             uint64_t n_paths, mc_result *out);
+int mc_multi_basket_run_f32(mc_multi *m, const mc_basket_f32 *opt, uint64_t seed, uint64_t first_path,
+                            uint64_t n_paths, mc_result *out);
+int mc_multi_basket_run_f64(mc_multi *m, const mc_basket_f64 *opt, uint64_t seed, uint64_t first_path,
+                            uint64_t n_paths, mc_result *out);
+int mc_multi_cva_run_f32(mc_multi *m, const mc_cva_f32 *cva, uint64_t seed, uint64_t first_path,
+                         uint64_t n_paths, mc_result *out);
+int mc_multi_cva_run_f64(mc_multi *m, const mc_cva_f64 *cva, uint64_t seed, uint64_t first_path,
+                         uint64_t n_paths, mc_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_MULTI_H_ */

@@ -18,15 +18,20 @@
  * numThreads is accepted and ignored (it only shaped the reference's reduction, :163);
  * nothing is printed on success (set MC_VERBOSE=1 for one line per call).
  * Environment: MC_DEVICE (default 0), MC_SEED (default MC_DEFAULT_SEED), MC_VERBOSE,
+ * MC_DEVICES="0,1,2,3" or "all" (every call is sharded over these GPUs of the node and closed by one RCCL
+ * all-reduce of the triple: include/mc_multi.h; libmc_multi.so -- and with it RCCL -- is loaded only then),
  * MC_ANTITHETIC=1 (antithetic-variates estimator instead of the reference's plain one),
  * MC_CONTROL_VARIATE=1 (dev_basketOpt only: geometric-basket control variate).
  */
+#define _GNU_SOURCE   /* dladdr */
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "MonteCarlo.h"
-#include "mc_mi355x.h"
+#include "mc_multi.h"
 
 #ifdef MC_SINGLE_PRECISION
 #define API(name) name##_f32
@@ -42,10 +47,94 @@ typedef mc_cva_f64 api_cva;
 
 static mc_context *g_ctx;
 
+/* ---- several GPUs (MC_DEVICES): libmc_multi.so, loaded on demand from this library's own directory ---- */
+static mc_multi *g_multi;
+static const char *(*multi_last_error)(void);
+static void (*multi_destroy)(mc_multi *);
+typedef int (*multi_run_fn)(mc_multi *, const void *, uint64_t, uint64_t, uint64_t, mc_result *);
+static multi_run_fn multi_vanilla, multi_basket, multi_cva;
+
 static void die(const char *what)
 {
-    fprintf(stderr, "Error %s: %s\n", what, mc_last_error());
+    const char *text = mc_last_error();
+    if (multi_last_error && multi_last_error()[0])
+        text = multi_last_error();
+    fprintf(stderr, "Error %s: %s\n", what, text);
     exit(1);
+}
+
+static void drop_multi(void)
+{
+    if (g_multi)
+        multi_destroy(g_multi);
+    g_multi = NULL;
+}
+
+static void *multi_symbol(void *lib, const char *name)
+{
+    void *p = dlsym(lib, name);
+    if (!p) {
+        fprintf(stderr, "Error: libmc_multi.so lacks %s\n", name);
+        exit(1);
+    }
+    return p;
+}
+
+/* NULL unless MC_DEVICES is set */
+static mc_multi *multi(void)
+{
+    const char *list = getenv("MC_DEVICES");
+    if (g_multi || !list || !list[0])
+        return g_multi;
+    char path[4096] = "libmc_multi.so";
+    Dl_info here;
+    if (dladdr((void *)&multi, &here) && here.dli_fname) {   /* next to this library, wherever it was installed */
+        const char *slash = strrchr(here.dli_fname, '/');
+        if (slash && (size_t)(slash - here.dli_fname) + 16 < sizeof path) {
+            memcpy(path, here.dli_fname, (size_t)(slash - here.dli_fname) + 1);
+            strcpy(path + (slash - here.dli_fname) + 1, "libmc_multi.so");
+        }
+    }
+    void *lib = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) {
+        fprintf(stderr, "Error: MC_DEVICES is set but %s cannot be loaded: %s\n", path, dlerror());
+        exit(1);
+    }
+    int (*create)(const int *, int, int, mc_multi **) = (int (*)(const int *, int, int, mc_multi **))multi_symbol(lib, "mc_multi_create");
+    int (*set_anti)(mc_multi *, int) = (int (*)(mc_multi *, int))multi_symbol(lib, "mc_multi_set_antithetic");
+    int (*set_cv)(mc_multi *, int) = (int (*)(mc_multi *, int))multi_symbol(lib, "mc_multi_set_control_variate");
+    multi_last_error = (const char *(*)(void))multi_symbol(lib, "mc_multi_last_error");
+    multi_destroy = (void (*)(mc_multi *))multi_symbol(lib, "mc_multi_destroy");
+#ifdef MC_SINGLE_PRECISION
+    multi_vanilla = (multi_run_fn)multi_symbol(lib, "mc_multi_vanilla_run_f32");
+    multi_basket = (multi_run_fn)multi_symbol(lib, "mc_multi_basket_run_f32");
+    multi_cva = (multi_run_fn)multi_symbol(lib, "mc_multi_cva_run_f32");
+#else
+    multi_vanilla = (multi_run_fn)multi_symbol(lib, "mc_multi_vanilla_run_f64");
+    multi_basket = (multi_run_fn)multi_symbol(lib, "mc_multi_basket_run_f64");
+    multi_cva = (multi_run_fn)multi_symbol(lib, "mc_multi_cva_run_f64");
+#endif
+    int devices[64], n = 0;
+    if (strcmp(list, "all") != 0) {
+        for (const char *p = list; *p && n < 64;) {
+            char *end;
+            const long d = strtol(p, &end, 10);
+            if (end == p) {
+                fprintf(stderr, "Error: MC_DEVICES=\"%s\" is not a comma-separated list of device numbers (or \"all\")\n", list);
+                exit(1);
+            }
+            devices[n++] = (int)d;
+            p = *end == ',' ? end + 1 : end;
+        }
+    }
+    if (create(n ? devices : NULL, n, 0, &g_multi) != MC_OK)
+        die("creating the multi-device handle (MC_DEVICES)");
+    if (getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC")))
+        set_anti(g_multi, 1);
+    if (getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE")))
+        set_cv(g_multi, 1);
+    atexit(drop_multi);
+    return g_multi;
 }
 
 static void drop_context(void)
@@ -91,8 +180,8 @@ static OptionValue finish(const mc_result *r, const char *what)
     v.Expected = (mc_real)r->expected;
     v.Confidence = (mc_real)r->confidence;
     if (getenv("MC_VERBOSE"))
-        printf("%s: %llu paths, kernel %.3f ms, value %.9g +- %.3g\n", what, (unsigned long long)r->n,
-               r->kernel_ms, r->expected, r->confidence);
+        printf("%s: %llu paths, kernel %.3f ms, call %.3f ms, value %.9g +- %.3g\n", what, (unsigned long long)r->n,
+               r->kernel_ms, r->wall_ms, r->expected, r->confidence);
     return v;
 }
 
@@ -101,7 +190,8 @@ OptionValue dev_vanillaOpt(OptionData *opt, int numBlocks, int numThreads, int s
     (void)numThreads;
     const api_option o = {opt->s, opt->k, opt->r, opt->v, opt->t};
     mc_result r;
-    if (API(mc_vanilla_run)(context(), &o, seed(), 0, path_count(numBlocks, sims), &r) != MC_OK)
+    const uint64_t n = path_count(numBlocks, sims);
+    if ((multi() ? multi_vanilla(g_multi, &o, seed(), 0, n, &r) : API(mc_vanilla_run)(context(), &o, seed(), 0, n, &r)) != MC_OK)
         die("in dev_vanillaOpt");
     return finish(&r, "dev_vanillaOpt");
 }
@@ -112,7 +202,8 @@ OptionValue dev_basketOpt(MultiOptionData *option, int numBlocks, int numThreads
     const api_basket b = {N, option->s, option->v, &option->p[0][0], option->d, option->w,
                           option->k, option->t, option->r};
     mc_result r;
-    if (API(mc_basket_run)(context(), &b, seed(), 0, path_count(numBlocks, sims), &r) != MC_OK)
+    const uint64_t n = path_count(numBlocks, sims);
+    if ((multi() ? multi_basket(g_multi, &b, seed(), 0, n, &r) : API(mc_basket_run)(context(), &b, seed(), 0, n, &r)) != MC_OK)
         die("in dev_basketOpt");
     return finish(&r, "dev_basketOpt");
 }
@@ -123,7 +214,8 @@ OptionValue dev_cvaEquityOption(CVA *cva, int numBlocks, int numThreads, int sim
     const api_cva c = {cva->defInt, cva->lgd,
                        {cva->option.s, cva->option.k, cva->option.r, cva->option.v, cva->option.t}, cva->n};
     mc_result r;
-    if (API(mc_cva_run)(context(), &c, seed(), 0, path_count(numBlocks, sims), &r) != MC_OK)
+    const uint64_t n = path_count(numBlocks, sims);
+    if ((multi() ? multi_cva(g_multi, &c, seed(), 0, n, &r) : API(mc_cva_run)(context(), &c, seed(), 0, n, &r)) != MC_OK)
         die("in dev_cvaEquityOption");
     return finish(&r, "dev_cvaEquityOption");
 }

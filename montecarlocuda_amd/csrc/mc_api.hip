@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -59,6 +61,11 @@ struct mc_context {
     char name[128] = {0};
     hipStream_t stream = nullptr;
     double2 *partials = nullptr;  // MAX_SEGMENTS * blocks + 2 (vanilla edge launches)
+    uint32_t *tickets = nullptr;  // arrival tickets of the in-kernel final reduction (mc_reduce.hpp: Tail), zero between calls
+    bool fused = true;            // final reduction inside the simulation kernel (false: second launch, finish_kernel)
+    hipEvent_t last_use = nullptr;       // recorded behind every enqueued call
+    hipStream_t last_stream = nullptr;   // stream of the most recent call
+    bool used = false;
     double *d_triple = nullptr;   // result slot of the synchronous runs
     double *d_triple9 = nullptr;  // three result slots (price, delta, vega), allocated on first use
     double *h_triple = nullptr;   // pinned
@@ -128,6 +135,25 @@ extern "C" int mc_device_count(void)
     return n;
 }
 
+static int context_allocate(mc_context *c)
+{
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIPCHK(hipMalloc(&c->partials, sizeof(double2) * ((size_t)MAX_SEGMENTS * c->blocks + 2)));
+    HIPCHK(hipMalloc(&c->tickets, sizeof(uint32_t) * TICKET_WORDS));
+    HIPCHK(hipMemset(c->tickets, 0, sizeof(uint32_t) * TICKET_WORDS));
+    HIPCHK(hipMalloc(&c->d_triple, 3 * sizeof(double)));
+    HIPCHK(hipHostMalloc(&c->h_triple, 3 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipEventCreate(&c->ev0));
+    HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipEventCreateWithFlags(&c->table_copied, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming));
+    if (const char *e = getenv("MC_FINISH"))   // "kernel": the two-launch form (A/B baseline); default: fused
+        c->fused = strcmp(e, "kernel") != 0;
+    return MC_OK;
+}
+
+extern "C" void mc_context_destroy(mc_context *c);
+
 extern "C" int mc_context_create(int device, int blocks, mc_context **out)
 {
     if (!out)
@@ -153,13 +179,10 @@ extern "C" int mc_context_create(int device, int blocks, mc_context **out)
         delete c;
         return fail(MC_ERR_INVALID, "blocks=%d too large", blocks);
     }
-    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc(&c->partials, sizeof(double2) * ((size_t)MAX_SEGMENTS * c->blocks + 2)));
-    HIPCHK(hipMalloc(&c->d_triple, 3 * sizeof(double)));
-    HIPCHK(hipHostMalloc(&c->h_triple, 3 * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipEventCreate(&c->ev0));
-    HIPCHK(hipEventCreate(&c->ev1));
-    HIPCHK(hipEventCreateWithFlags(&c->table_copied, hipEventDisableTiming));
+    if (int rc = context_allocate(c)) {
+        mc_context_destroy(c);  // frees whatever was allocated before the failure (keeps the error text)
+        return rc;
+    }
     *out = c;
     return MC_OK;
 }
@@ -172,6 +195,8 @@ extern "C" void mc_context_destroy(mc_context *c)
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->partials);
+    (void)hipFree(c->tickets);
+    if (c->last_use) (void)hipEventDestroy(c->last_use);
     (void)hipFree(c->d_triple);
     (void)hipFree(c->d_triple9);
     (void)hipHostFree(c->h_triple);
@@ -206,6 +231,14 @@ extern "C" int mc_context_set_antithetic(mc_context *c, int on)
     if (!c)
         return fail(MC_ERR_INVALID, "NULL context");
     c->antithetic = on != 0;
+    return MC_OK;
+}
+
+extern "C" int mc_context_set_finish(mc_context *c, int fused)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    c->fused = fused != 0;
     return MC_OK;
 }
 
@@ -348,6 +381,53 @@ static int grid_for(const mc_context *c, uint32_t n_units)
     return (int)(need < (uint64_t)c->blocks ? (need ? need : 1) : c->blocks);
 }
 
+// One pricing call = one or more simulation launches that share the context's pair buffer.  The Tail tells every
+// launch where its pairs go and how many pairs the whole call has, so that the last workgroup to arrive can close the
+// call inside the kernel (mc_reduce.hpp); in the two-launch form (MC_FINISH=kernel) total stays 0 and
+// finish_call launches finish_kernel behind the simulation kernels.
+static Tail make_tail(const mc_context *c, int total, double scale1, double scale2, uint64_t n, double *d_triple,
+                      int planes = 1, int plane_stride = 0)
+{
+    Tail t;
+    t.partials = c->partials;
+    t.tickets = c->tickets;
+    t.triple = d_triple;
+    t.scale1 = scale1;
+    t.scale2 = scale2;
+    t.n_paths = (double)n;
+    t.slot_base = 0;
+    t.total = c->fused ? (uint32_t)total : 0u;
+    t.planes = (uint32_t)planes;
+    t.plane_stride = (uint32_t)plane_stride;
+    return t;
+}
+
+// The context owns ONE pair buffer, ONE ticket block and ONE constant table, so its calls must execute one after the
+// other.  Calls on one stream are ordered by the stream; a call on a DIFFERENT stream than the previous one is ordered
+// behind everything enqueued so far on that previous stream (event record there, wait here) -- correct for any
+// interleaving, and free in the usual case of one stream per context.
+static int begin_call(mc_context *c, hipStream_t st)
+{
+    HIPCHK(hipSetDevice(c->device));
+    if (c->used && st != c->last_stream) {
+        HIPCHK(hipEventRecord(c->last_use, c->last_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->last_use, 0));
+    }
+    c->last_stream = st;
+    c->used = true;
+    return MC_OK;
+}
+
+static int finish_call(mc_context *c, const Tail &t, int total, hipStream_t st)
+{
+    if (!c->fused)
+        for (uint32_t q = 0; q < t.planes; ++q)
+            finish_kernel<<<1, GROUP, 0, st>>>(c->partials + (size_t)q * t.plane_stride, total, t.scale1, t.scale2, t.n_paths,
+                                               t.triple + 3 * q);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
 // NULL is the HIP null stream, as in every HIP API (the context's own stream: mc_context_stream)
 static hipStream_t pick_stream(mc_context *, void *stream) { return (hipStream_t)stream; }
 
@@ -415,22 +495,22 @@ static int upload_table(mc_context *c, hipStream_t st, const std::vector<char> &
 static inline bool finite_pos(double x) { return std::isfinite(x) && x > 0; }
 
 // The fp64 kernels' exp is table-driven with a rounding trick that needs |x| < 2e7 (mc_math_f64.hpp); any model
-// whose exponent can leave the range of a double (|x| > ~700 at the generator's largest normal, 8.3 sigma) is
-// rejected up front instead of pricing garbage.
-constexpr double Z_MAX_F64 = 8.3;
+// whose exponent can leave the range of a double (|x| > ~700 at the generator's largest normal) is rejected up
+// front instead of pricing garbage.  The 52-bit uniform bottoms out at 2^-53: |z| <= sqrt(2 * 53 ln 2) = 8.572.
+constexpr double Z_MAX_F64 = 8.58;
 static inline bool exponent_in_range(double bound) { return std::isfinite(bound) && bound < 700.0; }
 
 template <class Real> struct VanillaTraits;
 template <> struct VanillaTraits<float> {
     using Opt = VanillaF32;
     using In = mc_option_f32;
-    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, double2 *partials, int grid,
+    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
                            hipStream_t st)
     {
         if (anti)
-            launch_sim(prof, vanilla_f32_kernel<true>, grid, st, k, w, partials);
+            launch_sim(prof, vanilla_f32_kernel<true>, grid, st, tail, k, w);
         else
-            launch_sim(prof, vanilla_f32_kernel<false>, grid, st, k, w, partials);
+            launch_sim(prof, vanilla_f32_kernel<false>, grid, st, tail, k, w);
     }
     static int prepare(const In &o, Opt &k_, double &scale1, double &scale2)
     {
@@ -458,13 +538,13 @@ template <> struct VanillaTraits<float> {
 template <> struct VanillaTraits<double> {
     using Opt = VanillaF64;
     using In = mc_option_f64;
-    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, double2 *partials, int grid,
+    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
                            hipStream_t st)
     {
         if (anti)
-            launch_sim(prof, vanilla_kernel<Opt, double, true>, grid, st, k, w, partials);
+            launch_sim(prof, vanilla_kernel<Opt, double, true>, grid, st, tail, k, w);
         else
-            launch_sim(prof, vanilla_kernel<Opt, double, false>, grid, st, k, w, partials);
+            launch_sim(prof, vanilla_kernel<Opt, double, false>, grid, st, tail, k, w);
     }
     static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
     {
@@ -499,46 +579,48 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         scale2 *= 0.25;
     }
     const auto masked = anti ? vanilla_masked_kernel<typename T::Opt, Real, true> : vanilla_masked_kernel<typename T::Opt, Real, false>;
-    HIPCHK(hipSetDevice(c->device));
+    if (int rc = begin_call(c, st)) return rc;
     const uint64_t end = first + n;
-    int slot = 0;
     std::vector<Segment> segs;
     ProfileScope prof(c);
+    // plan first: the launches of the call and their grids (every launch needs the call's total pair count)
+    const uint64_t head = first / NPB, tail_unit = end / NPB;
+    bool has_head = false, has_tail = false;
     if (out) {
         const uint64_t u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
         if (int rc = plan_segments(u0, u1 - u0, segs)) return rc;
-        for (const Segment &s : segs) {
-            const Work w = make_work(seed, s, first, end);
-            const int g = grid_for(c, s.count);
-            masked<<<g, GROUP, 0, st>>>(k, w, c->partials + slot, out, (Real)scale1);
-            slot += g;
-        }
     } else {
         const uint64_t u_full0 = (first + NPB - 1) / NPB, u_full1 = end / NPB;
-        if (u_full1 > u_full0) {
+        if (u_full1 > u_full0)
             if (int rc = plan_segments(u_full0, u_full1 - u_full0, segs)) return rc;
-            for (const Segment &s : segs) {
-                const Work w = make_work(seed, s, first, end);
-                const int g = grid_for(c, s.count);
-                T::launch_hot(prof, anti, k, w, c->partials + slot, g, st);
-                slot += g;
-            }
-        }
         // partial units at the edges of the range (at most two single-unit launches)
-        const uint64_t head = first / NPB, tail = end / NPB;
-        const bool has_head = (first % NPB) != 0;
-        const bool has_tail = (end % NPB) != 0 && !(has_head && tail == head);
-        for (int e = 0; e < 2; ++e) {
-            if (!(e == 0 ? has_head : has_tail))
-                continue;
-            const Work w = make_work(seed, Segment{e == 0 ? head : tail, 1u}, first, end);
-            masked<<<1, GROUP, 0, st>>>(k, w, c->partials + slot, nullptr, (Real)1);
-            slot += 1;
-        }
+        has_head = (first % NPB) != 0;
+        has_tail = (end % NPB) != 0 && !(has_head && tail_unit == head);
     }
-    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale1, scale2, (double)n, d_triple);
-    HIPCHK(hipGetLastError());
-    return MC_OK;
+    int total = (has_head ? 1 : 0) + (has_tail ? 1 : 0);
+    for (const Segment &s : segs)
+        total += grid_for(c, s.count);
+    Tail t = make_tail(c, total, scale1, scale2, n, d_triple);
+    int slot = 0;
+    for (const Segment &s : segs) {
+        const Work w = make_work(seed, s, first, end);
+        const int g = grid_for(c, s.count);
+        t.slot_base = (uint32_t)slot;
+        if (out)
+            masked<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
+        else
+            T::launch_hot(prof, anti, k, w, t, g, st);
+        slot += g;
+    }
+    for (int e = 0; e < 2; ++e) {
+        if (!(e == 0 ? has_head : has_tail))
+            continue;
+        const Work w = make_work(seed, Segment{e == 0 ? head : tail_unit, 1u}, first, end);
+        t.slot_base = (uint32_t)slot;
+        masked<<<1, GROUP, 0, st>>>(t, k, w, nullptr, (Real)1);
+        slot += 1;
+    }
+    return finish_call(c, t, total, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -565,13 +647,25 @@ static void greeks_prepare(const mc_option_f64 &o, GreeksF64 &k)
 template <class Real, class In, class Opt>
 static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first, uint64_t n, mc_vanilla_greeks *out)
 {
+    const auto wall0 = std::chrono::steady_clock::now();
     if (int rc = check_common(c, o, first, n, out)) return rc;
     if (!finite_pos(o->s) || !finite_pos(o->k) || !(o->v >= 0) || !(o->t >= 0) || !std::isfinite((double)o->r))
         return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
     if (c->antithetic)
         return fail(MC_ERR_UNSUPPORTED, "greeks: only the plain estimator is implemented");
+    {   // the pricing paths' exponent-range guards (VanillaTraits<>::prepare): refuse inputs whose terminal spot
+        // overflows the simulation type instead of returning inf/NaN sums with MC_OK
+        const double drift = ((double)o->r - 0.5 * (double)o->v * (double)o->v) * (double)o->t;
+        const double vol = (double)o->v * std::sqrt((double)o->t);
+        const bool ok = sizeof(Real) == 4 ? std::fabs(std::ceil((drift + vol * 6.77) * 1.4426950408889634074)) < 100 &&
+                                                std::fabs(drift - vol * 6.77) * 1.4426950408889634074 < 100
+                                          : exponent_in_range(std::fabs(drift) + vol * Z_MAX_F64);
+        if (!ok)
+            return fail(MC_ERR_INVALID, "greeks: (r - v^2/2) t and v sqrt(t) put the terminal spot outside the range of the simulation type");
+    }
     constexpr uint64_t NPB = npb<Real>::value;
-    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    if (int rc = begin_call(c, st)) return rc;
     Opt k;
     greeks_prepare(*o, k);
     const uint64_t end = first + n, u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
@@ -582,18 +676,20 @@ static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first,
     const int plane = 2 * c->blocks + 2;   // pairs reserved per quantity
     if (!c->d_triple9)
         HIPCHK(hipMalloc(&c->d_triple9, 9 * sizeof(double)));
-    hipStream_t st = c->stream;
     HIPCHK(hipEventRecord(c->ev0, st));
+    int total = 0;
+    for (const Segment &s : segs)
+        total += grid_for(c, s.count);
+    Tail t = make_tail(c, total, 1.0, 1.0, n, c->d_triple9, 3, plane);
     int slot = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, first, end);
         const int g = grid_for(c, s.count);
-        vanilla_greeks_kernel<Opt, Real><<<g, GROUP, 0, st>>>(k, w, c->partials + slot, plane);
+        t.slot_base = (uint32_t)slot;
+        vanilla_greeks_kernel<Opt, Real><<<g, GROUP, 0, st>>>(t, k, w);
         slot += g;
     }
-    for (int q = 0; q < 3; ++q)
-        finish_kernel<<<1, GROUP, 0, st>>>(c->partials + (size_t)q * plane, slot, 1.0, 1.0, (double)n, c->d_triple9 + 3 * q);
-    HIPCHK(hipGetLastError());
+    if (int rc = finish_call(c, t, total, st)) return rc;
     HIPCHK(hipEventRecord(c->ev1, st));
     double h[9];
     HIPCHK(hipMemcpyAsync(h, c->d_triple9, sizeof h, hipMemcpyDeviceToHost, st));
@@ -606,6 +702,9 @@ static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first,
         r[q]->sum = h[3 * q], r[q]->sum2 = h[3 * q + 1], r[q]->n = (uint64_t)h[3 * q + 2], r[q]->kernel_ms = ms;
         mc_closing(r[q]->sum, r[q]->sum2, r[q]->n, disc, &r[q]->expected, &r[q]->confidence);
     }
+    const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    for (int q = 0; q < 3; ++q)
+        r[q]->wall_ms = wall;
     return MC_OK;
 }
 
@@ -632,27 +731,28 @@ template <> constexpr double exp_scale<float>() { return 1.4426950408889634074; 
 // the kernel of each precision: f32 = two paths per lane in packed halves, f64 = one path per lane
 template <int NA>
 static void basket_launch_kernel(ProfileScope &prof, bool anti, const BasketArgs<float, NA> &k, const Work &w,
-                                 double2 *partials, float *out, double scale, int grid, hipStream_t st)
+                                 const Tail &tail, float *out, double scale, int grid, hipStream_t st)
 {
     if (anti)
-        launch_sim(prof, basket_f32_kernel<NA, true>, grid, st, k, w, partials, out, (float)scale);
+        launch_sim(prof, basket_f32_kernel<NA, true>, grid, st, tail, k, w, out, (float)scale);
     else
-        launch_sim(prof, basket_f32_kernel<NA, false>, grid, st, k, w, partials, out, (float)scale);
+        launch_sim(prof, basket_f32_kernel<NA, false>, grid, st, tail, k, w, out, (float)scale);
 }
 template <int NA>
 static void basket_launch_kernel(ProfileScope &prof, bool anti, const BasketArgs<double, NA> &k, const Work &w,
-                                 double2 *partials, double *out, double, int grid, hipStream_t st)
+                                 const Tail &tail, double *out, double, int grid, hipStream_t st)
 {
     if (anti)
-        launch_sim(prof, basket_kernel<double, NA, true>, grid, st, k, w, partials, out);
+        launch_sim(prof, basket_kernel<double, NA, true>, grid, st, tail, k, w, out);
     else
-        launch_sim(prof, basket_kernel<double, NA, false>, grid, st, k, w, partials, out);
+        launch_sim(prof, basket_kernel<double, NA, false>, grid, st, tail, k, w, out);
 }
 
 template <class Real, int NA>
 static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
-                           const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot, double &scale)
+                           const std::vector<Segment> &segs, hipStream_t st, Real *out, uint64_t n_paths, double *d_triple)
 {
+    double scale = 1.0;
     BasketArgs<Real, NA> k;
     constexpr bool is_f32 = sizeof(Real) == 4;
     const double sc = exp_scale<Real>();
@@ -682,6 +782,9 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
                 x += std::fabs(m[a][b]) * zmax;
             bound += std::fabs(coef[a]) * std::exp2(x);
         }
+        // a negative strike RAISES the payoff: basket - K <= bound + |K| must still fit the [0,1] clamp
+        if ((double)o.k < 0)
+            bound += -(double)o.k;
         const double kk = bound > 0 ? std::ceil(std::log2(bound)) : 0;
         if (!(std::fabs(kk) < 100))
             return fail(MC_ERR_INVALID, "basket f32: inputs out of the float range (scale 2^%g)", kk);
@@ -712,17 +815,20 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
         k.cg = (Real)((cg + std::log(W)) * sc - (is_f32 ? std::log2(scale) : 0.0));
         k.cv = 1;
     }
+    int total = 0, slot = 0;
+    for (const Segment &s : segs)
+        total += grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
+    Tail t = make_tail(c, total, out_scale, out_scale * out_scale, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
-        basket_launch_kernel<NA>(prof, c->antithetic, k, w, c->partials + slot, out ? out + done : (Real *)nullptr,
-                                 out_scale, g, st);
+        t.slot_base = (uint32_t)slot;
+        basket_launch_kernel<NA>(prof, c->antithetic, k, w, t, out ? out + done : (Real *)nullptr, out_scale, g, st);
         slot += g;
         done += s.count;
     }
-    scale = out_scale;
-    return MC_OK;
+    return finish_call(c, t, total, st);
 }
 
 // Which kernel family prices a basket of n assets (measured on MI355X: tools/generic_basket_speed.py, runs
@@ -761,7 +867,7 @@ static int basket_tiled_min()
 // buffer and run the tiled kernel of the size, or the generic one beyond 32 assets.
 template <class Real>
 static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
-                             const std::vector<Segment> &segs, hipStream_t st, Real *out, int &slot)
+                             const std::vector<Segment> &segs, hipStream_t st, Real *out, uint64_t n_paths, double *d_triple)
 {
     // layout of BasketDyn::consts: 4 x 4 tiles of the folded lower-triangular matrix, block-row by block-row
     // (tile (A, c4) = 16 reals, index 4 j + r = m[4A + r][4 c4 + j], zero outside the triangle / beyond n),
@@ -843,15 +949,20 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     }
     if (lds)
         HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int total = 0, slot = 0;
+    for (const Segment &s : segs)
+        total += grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
+    Tail tail = make_tail(c, total, 1.0, 1.0, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
-        launch_sim_lds(prof, kernel, g, lds, st, k, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+        tail.slot_base = (uint32_t)slot;
+        launch_sim_lds(prof, kernel, g, lds, st, tail, k, w, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;
     }
-    return MC_OK;
+    return finish_call(c, tail, total, st);
 }
 
 template <class Real>
@@ -864,25 +975,21 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
         return fail(MC_ERR_INVALID, "basket: NULL array");
     if (!(o->t >= 0) || !std::isfinite((double)o->r) || !std::isfinite((double)o->k))
         return fail(MC_ERR_INVALID, "basket: need t>=0 and finite r, k");
-    HIPCHK(hipSetDevice(c->device));
+    if (int rc = begin_call(c, st)) return rc;
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;
-    int slot = 0, rc = MC_OK;
-    double scale = 1.0;
+    int rc = MC_OK;
     ProfileScope prof(c);
     switch (o->n <= basket_static_max<Real>() ? o->n : 0) {
-#define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, slot, scale); break;
+#define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, n, d_triple); break;
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
         MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
 #undef MC_CASE
     default:
-        rc = basket_launch_dyn<Real>(c, prof, *o, seed, segs, st, out, slot);
+        rc = basket_launch_dyn<Real>(c, prof, *o, seed, segs, st, out, n, d_triple);
         break;
     }
-    if (rc) return rc;
-    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, scale, scale * scale, (double)n, d_triple);
-    HIPCHK(hipGetLastError());
-    return MC_OK;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -955,7 +1062,7 @@ template <class Real>
 static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint64_t seed, uint64_t first, uint64_t n,
                        double *d_triple, hipStream_t st, Real *out)
 {
-    HIPCHK(hipSetDevice(c->device));
+    if (int rc = begin_call(c, st)) return rc;
     CvaArgs<Real> args;
     // the table depends only on the inputs: rebuild and re-upload only when they change
     const double key_vals[9] = {(double)v->defint, (double)v->lgd, (double)v->option.s, (double)v->option.k,
@@ -990,22 +1097,24 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     args.steps = (const CvaStep<Real> *)c->d_table;
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;
-    int slot = 0;
+    int total = 0, slot = 0;
+    for (const Segment &s : segs)
+        total += grid_for(c, s.count);
+    Tail t = make_tail(c, total, 1.0, 1.0, n, d_triple);
     uint64_t done = 0;
     ProfileScope prof(c);
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
+        t.slot_base = (uint32_t)slot;
         if (c->antithetic)
-            launch_sim(prof, cva_kernel<Real, true>, g, st, args, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+            launch_sim(prof, cva_kernel<Real, true>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
         else
-            launch_sim(prof, cva_kernel<Real, false>, g, st, args, w, c->partials + slot, out ? out + done : (Real *)nullptr);
+            launch_sim(prof, cva_kernel<Real, false>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;
     }
-    finish_kernel<<<1, GROUP, 0, st>>>(c->partials, slot, 1.0, 1.0, (double)n, d_triple);
-    HIPCHK(hipGetLastError());
-    return MC_OK;
+    return finish_call(c, t, total, st);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1064,6 +1173,7 @@ extern "C" int mc_chol_f64(int n, const double *c, double *a) { return chol_impl
 template <class Enq>
 static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, Enq enqueue)
 {
+    const auto wall0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipEventRecord(c->ev0, c->stream));
     if (int rc = enqueue(c->stream, c->d_triple)) return rc;
@@ -1080,6 +1190,7 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         return fail(MC_ERR_HIP, "device returned n=%llu, expected %llu", (unsigned long long)out->n,
                     (unsigned long long)n);
     mc_closing(out->sum, out->sum2, out->n, discount, &out->expected, &out->confidence);
+    out->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     return MC_OK;
 }
 

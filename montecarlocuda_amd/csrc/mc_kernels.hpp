@@ -8,7 +8,8 @@
 //     (sum, sum2) accumulators; wave-uniform constants never cost a VALU slot -- kernel arguments in
 //     SGPRs while they fit, otherwise LDS-staged (broadcast ds_read) or fetched tile by tile with
 //     scalar loads from constant memory (the basket kernels), per-date rows through scalar loads (CVA);
-//   * one DPP+LDS reduction and one 16-byte store per workgroup at the end (mc_reduce.hpp).
+//   * one DPP+LDS reduction and one 16-byte store per workgroup at the end; the last workgroup of the call to
+//     arrive adds the pairs and writes the call's {sum, sum2, n} (mc_reduce.hpp: finish_group).
 // HBM traffic per launch: kernel arguments (and a table of <= 20 KB) in, 16 B per workgroup out --
 // the kernels are bound by VALU/transcendental issue, not by memory (DESIGN.md "Roofline").
 //
@@ -134,8 +135,7 @@ __device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w,
 constexpr uint32_t VANILLA_F32_FLUSH = 8;
 
 template <bool ANTI>
-__global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, const Work w,
-                                                            double2 *__restrict__ partials)
+__global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const VanillaF32 o, const Work w)
 {
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
@@ -166,12 +166,12 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const VanillaF32 o, 
     acc_s += (double)(s2.x + s2.y);
     acc_q += (double)(q2.x + q2.y);
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // f64 (and the generic form): each unit's payoffs go straight into the fp64 accumulators.
 template <class Opt, class Real, bool ANTI>
-__global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work w, double2 *__restrict__ partials)
+__global__ __launch_bounds__(GROUP) void vanilla_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w)
 {
     stage_tables<Real>();
     constexpr int NPB = npb<Real>::value;
@@ -191,15 +191,14 @@ __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Opt o, const Work 
         acc_q += (double)q;
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // Masked kernel: honours the path window (partial first/last units) and optionally stores
 // every per-path payoff (currency units) to `out[p - first_path]`.  Used for range edges and
 // by the parity tests; never on the hot path.
 template <class Opt, class Real, bool ANTI>
-__global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Opt o, const Work w,
-                                                               double2 *__restrict__ partials,
+__global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w,
                                                                Real *__restrict__ out, Real out_scale)
 {
     stage_tables<Real>();
@@ -223,14 +222,14 @@ __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Opt o, cons
         }
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // =========================================================================================
 // Vanilla call with pathwise Greeks (the reference prices only).  Per path, on the same
 // normal as the pricing kernels:  S_T = S exp(drift + vol z),  I = [S_T > K],
 //     payoff = I (S_T - K),   d payoff / dS = I S_T / S,   d payoff / d sigma = I S_T (sqrt(T) z - sigma T)
-// Three (sum, sum2) pairs per workgroup: partials[q * pair_stride + block], q = price, delta, vega.
+// Three (sum, sum2) pairs per workgroup, one per plane of the call's pair buffer: q = price, delta, vega.
 // Always honours the path window (no separate hot variant: a secondary kernel).
 // =========================================================================================
 struct GreeksF32 { float drift2, vol2, spot, strike, sqrt_t, sigma_t; };   // exponent in log2 units
@@ -240,8 +239,7 @@ __device__ __forceinline__ float greeks_spot(const GreeksF32 &o, float z) { retu
 __device__ __forceinline__ double greeks_spot(const GreeksF64 &o, double z) { return o.spot * exp_f64(__builtin_fma(o.vol, z, o.drift)); }
 
 template <class Opt, class Real>
-__global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Opt o, const Work w, double2 *__restrict__ partials,
-                                                               int pair_stride)
+__global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w)
 {
     stage_tables<Real>();
     constexpr int NPB = npb<Real>::value;
@@ -269,8 +267,9 @@ __global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Opt o, cons
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         group_sum2(acc[2 * q], acc[2 * q + 1]);
-        store_partial(partials + (size_t)q * pair_stride, acc[2 * q], acc[2 * q + 1]);
+        publish_pair(late_tail(acc[2 * q]), q, acc[2 * q], acc[2 * q + 1]);
     }
+    arrive_and_finish(late_tail(acc[0]));
 }
 
 // =========================================================================================
@@ -430,8 +429,7 @@ __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, Const
 }
 
 template <class Real, int NA, bool ANTI>
-__global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA> o, const Work w,
-                                                       double2 *__restrict__ partials,
+__global__ __launch_bounds__(GROUP) void basket_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketArgs<Real, NA> o, const Work w,
                                                        Real *__restrict__ out)
 {
     stage_tables<Real>();
@@ -454,7 +452,7 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const BasketArgs<Real, NA
             out[i] = p;
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // ---- f32 basket: TWO paths per lane, one in each half of a packed-f32 register pair ----------
@@ -525,8 +523,7 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, Co
 constexpr uint32_t BASKET_F32_FLUSH = 8;
 
 template <int NA, bool ANTI>
-__global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<float, NA> o, const Work w,
-                                                           double2 *__restrict__ partials, float *__restrict__ out,
+__global__ __launch_bounds__(GROUP) void basket_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketArgs<float, NA> o, const Work w, float *__restrict__ out,
                                                            float out_scale)
 {
     const uint32_t stride = gridDim.x * GROUP;
@@ -576,7 +573,7 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const BasketArgs<floa
     acc_s += (double)(s2.x + s2.y);
     acc_q += (double)(q2.x + q2.y);
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // ---- generic basket: runtime asset count beyond the compiled sizes (17 .. MC_MAX_ASSETS_GENERIC) ----
@@ -598,8 +595,7 @@ struct BasketDyn {
 };
 
 template <class Real, bool ANTI>
-__global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real> o, const Work w,
-                                                           double2 *__restrict__ partials, Real *__restrict__ out)
+__global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -669,7 +665,7 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
             out[i] = p;
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // fp32 form of the generic kernel: TWO paths per lane (units i and i + stride), one in each half of a packed
@@ -677,8 +673,7 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const BasketDyn<Real>
 // the tiled mat-vec and the weighted sums issue as v_pk_*_f32, and each scalar-loaded tile value and each
 // loop step serves two paths.  The lane's LDS column holds packed pairs (8 bytes per asset).
 template <bool ANTI>
-__global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const BasketDyn<float> o, const Work w,
-                                                               double2 *__restrict__ partials, float *__restrict__ out)
+__global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<float> o, const Work w, float *__restrict__ out)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     f2 *g = reinterpret_cast<f2 *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
@@ -756,7 +751,7 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const BasketDyn<f
         }
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // ---- tiled basket with register-resident normals: the larger fp64 sizes -----------------------
@@ -770,8 +765,7 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const BasketDyn<f
 // is an offset it cannot see through: an empty volatile asm that redefines `off` (always 0) and is tied
 // to the value computed just before, which also fixes where in the trip each load is issued.
 template <class Real, int NA, bool ANTI>
-__global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const BasketDyn<Real> o, const Work w,
-                                                             double2 *__restrict__ partials, Real *__restrict__ out)
+__global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
     constexpr int NB = (NA + 3) / 4, NP = 4 * NB, NPB = npb<Real>::value, NBLK = (NA + NPB - 1) / NPB;
@@ -865,15 +859,14 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const BasketDyn<Rea
             out[i] = p;
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // fp32 form of the tiled kernel (12..32 assets): two paths per lane in packed halves (like basket_f32_kernel
 // and basket_dyn_f32_kernel), normals in registers, each whole 4 x 4 tile (16 floats) one scalar load issued a
 // tile ahead.  Plain max for the payoff (no power-of-two rescale: the host folds none for these sizes).
 template <int NA, bool ANTI>
-__global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const BasketDyn<float> o, const Work w,
-                                                                 double2 *__restrict__ partials, float *__restrict__ out)
+__global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<float> o, const Work w, float *__restrict__ out)
 {
     constexpr int NB = (NA + 3) / 4, NP = 4 * NB, NT = NB * (NB + 1) / 2;
     typedef const __attribute__((address_space(4))) float *cptr;
@@ -972,7 +965,7 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const BasketDyn
         }
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // =========================================================================================
@@ -1183,8 +1176,7 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
 }
 
 template <class Real, bool ANTI>
-__global__ __launch_bounds__(GROUP) void cva_kernel(const CvaArgs<Real> o, const Work w,
-                                                    double2 *__restrict__ partials, Real *__restrict__ out)
+__global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
     const uint32_t stride = gridDim.x * GROUP;
@@ -1198,7 +1190,7 @@ __global__ __launch_bounds__(GROUP) void cva_kernel(const CvaArgs<Real> o, const
             out[i] = p;
     }
     group_sum2(acc_s, acc_q);
-    store_partial(partials, acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 // =========================================================================================

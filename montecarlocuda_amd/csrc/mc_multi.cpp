@@ -1,0 +1,300 @@
+// mc_multi.cpp -- libmc_multi.so: one pricing call over several MI355X from one host process (include/mc_multi.h).
+//
+// A client of the single-device C ABI (include/mc_mi355x.h: one mc_context per device, mc_*_launch_* on that
+// device's stream) plus RCCL's C API, linked directly (librccl.so; no PyTorch anywhere near this file).  The
+// reference has no counterpart: it is single-device, default stream, synchronous; the entry points
+// fanned out here are dp/MonteCarloKernel.cu:483 (basket), :500 (vanilla), :517 (CVA).
+//
+// Host-only translation unit: no device code.  Everything a call enqueues -- G launches, one grouped all-reduce,
+// G + 1 small read-backs -- is asynchronous; the calling thread then waits for the G streams.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mc_multi.h"
+
+static thread_local std::string g_multi_error;
+
+extern "C" const char *mc_multi_last_error(void) { return g_multi_error.c_str(); }
+
+static int fail(int code, const char *fmt, ...)
+{
+    char buf[640];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_multi_error = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess)                                                                              \
+            return fail(MC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define NCCLCHK(call)                                                                                      \
+    do {                                                                                                   \
+        ncclResult_t r_ = (call);                                                                          \
+        if (r_ != ncclSuccess)                                                                             \
+            return fail(MC_ERR_HIP, "%s failed: %s (%s:%d)", #call, ncclGetErrorString(r_), __FILE__, __LINE__); \
+    } while (0)
+// a failing single-device call: pass its status and its own text on
+#define MCCHK(call)                                                        \
+    do {                                                                   \
+        int rc_ = (call);                                                  \
+        if (rc_ != MC_OK)                                                  \
+            return fail(rc_, "device %d: %s", m->devices[g], mc_last_error()); \
+    } while (0)
+
+struct mc_multi {
+    std::vector<int> devices;
+    std::vector<mc_context *> ctx;
+    std::vector<hipStream_t> stream;
+    std::vector<double *> d_send, d_recv;      // per device: its own triple, the all-reduced triple
+    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<ncclComm_t> comm;              // created on first use (ncclCommInitAll), kept for the handle's life
+    double *h_send = nullptr;                  // pinned, 3 doubles per device
+    double *h_recv = nullptr;                  // pinned, 3 doubles
+    int reduce = MC_REDUCE_RCCL;
+    bool control = false;
+    double last_reduce_error = 0.0;
+};
+
+extern "C" void mc_multi_destroy(mc_multi *m)
+{
+    if (!m)
+        return;
+    for (size_t g = 0; g < m->ctx.size(); ++g) {
+        (void)hipSetDevice(m->devices[g]);
+        if (g < m->stream.size() && m->stream[g]) (void)hipStreamSynchronize(m->stream[g]);
+        if (g < m->comm.size() && m->comm[g]) (void)ncclCommDestroy(m->comm[g]);
+        if (g < m->d_send.size()) (void)hipFree(m->d_send[g]);
+        if (g < m->d_recv.size()) (void)hipFree(m->d_recv[g]);
+        if (g < m->ev0.size() && m->ev0[g]) (void)hipEventDestroy(m->ev0[g]);
+        if (g < m->ev1.size() && m->ev1[g]) (void)hipEventDestroy(m->ev1[g]);
+        mc_context_destroy(m->ctx[g]);
+    }
+    (void)hipHostFree(m->h_send);
+    (void)hipHostFree(m->h_recv);
+    delete m;
+}
+
+static int multi_allocate(mc_multi *m, int blocks)
+{
+    const int G = (int)m->devices.size();
+    for (int g = 0; g < G; ++g) {
+        mc_context *c = nullptr;
+        MCCHK(mc_context_create(m->devices[g], blocks, &c));
+        m->ctx.push_back(c);
+        m->stream.push_back((hipStream_t)mc_context_stream(c));
+        HIPCHK(hipSetDevice(m->devices[g]));
+        double *s = nullptr, *r = nullptr;
+        HIPCHK(hipMalloc(&s, 3 * sizeof(double)));
+        m->d_send.push_back(s);
+        HIPCHK(hipMalloc(&r, 3 * sizeof(double)));
+        m->d_recv.push_back(r);
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(hipEventCreate(&a));
+        m->ev0.push_back(a);
+        HIPCHK(hipEventCreate(&b));
+        m->ev1.push_back(b);
+    }
+    HIPCHK(hipHostMalloc(&m->h_send, 3 * sizeof(double) * G, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&m->h_recv, 3 * sizeof(double), hipHostMallocDefault));
+    return MC_OK;
+}
+
+extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc_multi **out)
+{
+    if (!out)
+        return fail(MC_ERR_INVALID, "mc_multi_create: out is NULL");
+    *out = nullptr;
+    const int visible = mc_device_count();
+    if (visible <= 0)
+        return fail(MC_ERR_NO_DEVICE, "no HIP device visible (the HIP engine has no CPU fallback)");
+    if (!devices && n_devices <= 0)
+        n_devices = visible;
+    if (n_devices <= 0 || n_devices > 64)
+        return fail(MC_ERR_INVALID, "mc_multi_create: n_devices=%d", n_devices);
+    mc_multi *m = new mc_multi;
+    for (int g = 0; g < n_devices; ++g) {
+        const int d = devices ? devices[g] : g;
+        if (d < 0 || d >= visible) {
+            delete m;
+            return fail(MC_ERR_INVALID, "mc_multi_create: device %d out of range [0,%d)", d, visible);
+        }
+        m->devices.push_back(d);
+    }
+    if (const char *e = getenv("MC_MULTI_REDUCE"))
+        m->reduce = strcmp(e, "host") == 0 ? MC_REDUCE_HOST : MC_REDUCE_RCCL;
+    if (int rc = multi_allocate(m, blocks)) {
+        mc_multi_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return MC_OK;
+}
+
+extern "C" int mc_multi_size(const mc_multi *m) { return m ? (int)m->devices.size() : 0; }
+extern "C" mc_context *mc_multi_context(mc_multi *m, int i)
+{
+    return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr;
+}
+extern "C" double mc_multi_last_reduce_error(const mc_multi *m) { return m ? m->last_reduce_error : 0.0; }
+
+extern "C" int mc_multi_set_antithetic(mc_multi *m, int on)
+{
+    if (!m) return fail(MC_ERR_INVALID, "NULL handle");
+    for (mc_context *c : m->ctx)
+        mc_context_set_antithetic(c, on);
+    return MC_OK;
+}
+extern "C" int mc_multi_set_control_variate(mc_multi *m, int on)
+{
+    if (!m) return fail(MC_ERR_INVALID, "NULL handle");
+    for (mc_context *c : m->ctx)
+        mc_context_set_control_variate(c, on);
+    m->control = on != 0;
+    return MC_OK;
+}
+extern "C" int mc_multi_set_reduce(mc_multi *m, int mode)
+{
+    if (!m || (mode != MC_REDUCE_RCCL && mode != MC_REDUCE_HOST))
+        return fail(MC_ERR_INVALID, "mc_multi_set_reduce: bad argument");
+    m->reduce = mode;
+    return MC_OK;
+}
+
+// RCCL communicators, one per device, all in this process: created by the first call that needs them.
+static int ensure_comms(mc_multi *m)
+{
+    if (!m->comm.empty())
+        return MC_OK;
+    const int G = (int)m->devices.size();
+    for (int a = 0; a < G; ++a)
+        for (int b = a + 1; b < G; ++b)
+            if (m->devices[a] == m->devices[b])
+                return fail(MC_ERR_INVALID, "device %d is listed twice: RCCL needs distinct devices (MC_REDUCE_HOST accepts the list)",
+                            m->devices[a]);
+    std::vector<ncclComm_t> comm((size_t)G, nullptr);
+    NCCLCHK(ncclCommInitAll(comm.data(), G, m->devices.data()));
+    m->comm = comm;
+    return MC_OK;
+}
+
+// launch(g, ctx, first, count, d_triple, stream) enqueues device g's shard
+template <class Launch>
+static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount, double add_back, mc_result *out, Launch launch)
+{
+    if (!m) return fail(MC_ERR_INVALID, "NULL handle");
+    if (!out) return fail(MC_ERR_INVALID, "NULL output pointer");
+    if (n == 0) return fail(MC_ERR_INVALID, "n_paths == 0");
+    const int G = (int)m->devices.size();
+    if (m->reduce == MC_REDUCE_RCCL)
+        if (int rc = ensure_comms(m)) return rc;
+    const auto wall0 = std::chrono::steady_clock::now();
+    for (int g = 0; g < G; ++g) {
+        uint64_t lo = 0, cnt = 0;
+        mc_shard_range(n, g, G, &lo, &cnt);
+        HIPCHK(hipSetDevice(m->devices[g]));
+        HIPCHK(hipEventRecord(m->ev0[g], m->stream[g]));
+        if (cnt)
+            MCCHK(launch(g, m->ctx[g], first + lo, cnt, m->d_send[g], (void *)m->stream[g]));
+        else   // fewer paths than devices: this one contributes {0, 0, 0}
+            HIPCHK(hipMemsetAsync(m->d_send[g], 0, 3 * sizeof(double), m->stream[g]));
+        HIPCHK(hipEventRecord(m->ev1[g], m->stream[g]));
+    }
+    if (m->reduce == MC_REDUCE_RCCL) {
+        NCCLCHK(ncclGroupStart());
+        for (int g = 0; g < G; ++g)
+            NCCLCHK(ncclAllReduce(m->d_send[g], m->d_recv[g], 3, ncclDouble, ncclSum, m->comm[g], m->stream[g]));
+        NCCLCHK(ncclGroupEnd());
+    }
+    for (int g = 0; g < G; ++g) {
+        HIPCHK(hipSetDevice(m->devices[g]));
+        HIPCHK(hipMemcpyAsync(m->h_send + 3 * g, m->d_send[g], 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream[g]));
+        if (g == 0 && m->reduce == MC_REDUCE_RCCL)
+            HIPCHK(hipMemcpyAsync(m->h_recv, m->d_recv[0], 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream[0]));
+    }
+    float kernel_ms = 0;
+    for (int g = 0; g < G; ++g) {
+        HIPCHK(hipSetDevice(m->devices[g]));
+        HIPCHK(hipStreamSynchronize(m->stream[g]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, m->ev0[g], m->ev1[g]));
+        kernel_ms = ms > kernel_ms ? ms : kernel_ms;
+    }
+    // host sum in device order: the collective's cross-check, or the result itself
+    double host[3] = {0, 0, 0};
+    for (int g = 0; g < G; ++g)
+        for (int k = 0; k < 3; ++k)
+            host[k] += m->h_send[3 * g + k];
+    const double *tot = host;
+    m->last_reduce_error = 0.0;
+    if (m->reduce == MC_REDUCE_RCCL) {
+        tot = m->h_recv;
+        for (int k = 0; k < 3; ++k) {
+            const double err = std::fabs(m->h_recv[k] - host[k]), ref = std::fabs(host[k]);
+            if (!(err <= 1e-12 * ref))
+                return fail(MC_ERR_HIP, "RCCL all-reduce disagrees with the host sum of the %d device triples: word %d %.17g vs %.17g",
+                            G, k, m->h_recv[k], host[k]);
+            if (k == 0 && ref > 0)
+                m->last_reduce_error = err / ref;
+        }
+    }
+    out->sum = tot[0];
+    out->sum2 = tot[1];
+    out->n = (uint64_t)tot[2];
+    out->kernel_ms = kernel_ms;
+    if (out->n != n)
+        return fail(MC_ERR_HIP, "devices returned n=%llu in total, expected %llu", (unsigned long long)out->n, (unsigned long long)n);
+    mc_closing(out->sum, out->sum2, out->n, discount, &out->expected, &out->confidence);
+    out->expected += discount * add_back;
+    out->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return MC_OK;
+}
+
+#define MC_DEFINE_MULTI(X)                                                                                              \
+    extern "C" int mc_multi_vanilla_run_##X(mc_multi *m, const mc_option_##X *o, uint64_t seed, uint64_t first, uint64_t n, \
+                                            mc_result *out)                                                             \
+    {                                                                                                                   \
+        if (!o) return fail(MC_ERR_INVALID, "NULL option");                                                             \
+        return run_sharded(m, first, n, std::exp(-(double)o->r * (double)o->t), 0.0, out,                               \
+                           [&](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
+                               return mc_vanilla_launch_##X(c, o, seed, f, cnt, d, st);                                 \
+                           });                                                                                          \
+    }                                                                                                                   \
+    extern "C" int mc_multi_basket_run_##X(mc_multi *m, const mc_basket_##X *o, uint64_t seed, uint64_t first, uint64_t n, \
+                                           mc_result *out)                                                              \
+    {                                                                                                                   \
+        if (!o) return fail(MC_ERR_INVALID, "NULL basket");                                                             \
+        double mean = 0.0; /* control variate: the simulated quantity is payoff - control, add its closed-form mean back */ \
+        if (m && m->control && mc_basket_control_mean_##X(o, &mean) != MC_OK)                                           \
+            return fail(MC_ERR_INVALID, "%s", mc_last_error());                                                         \
+        return run_sharded(m, first, n, std::exp(-(double)o->r * (double)o->t), mean, out,                              \
+                           [&](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
+                               return mc_basket_launch_##X(c, o, seed, f, cnt, d, st);                                  \
+                           });                                                                                          \
+    }                                                                                                                   \
+    extern "C" int mc_multi_cva_run_##X(mc_multi *m, const mc_cva_##X *o, uint64_t seed, uint64_t first, uint64_t n,     \
+                                        mc_result *out)                                                                 \
+    {                                                                                                                   \
+        if (!o) return fail(MC_ERR_INVALID, "NULL cva");                                                                \
+        return run_sharded(m, first, n, 1.0, 0.0, out,                                                                  \
+                           [&](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
+                               return mc_cva_launch_##X(c, o, seed, f, cnt, d, st);                                     \
+                           });                                                                                          \
+    }
+
+MC_DEFINE_MULTI(f32)
+MC_DEFINE_MULTI(f64)

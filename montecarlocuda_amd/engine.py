@@ -66,6 +66,7 @@ class Estimate:
     sum2: float
     n: int
     kernel_ms: float = 0.0
+    wall_ms: float = 0.0
 
     def value(self) -> OptionValue:
         return OptionValue(self.expected, self.confidence)
@@ -101,7 +102,7 @@ def _as_cva(X, c) -> C.Structure:
 
 
 def _estimate(r: _lib.Result) -> Estimate:
-    return Estimate(r.expected, r.confidence, r.sum, r.sum2, int(r.n), float(r.kernel_ms))
+    return Estimate(r.expected, r.confidence, r.sum, r.sum2, int(r.n), float(r.kernel_ms), float(r.wall_ms))
 
 
 class Engine:
@@ -145,6 +146,10 @@ class Engine:
     def set_control_variate(self, on: bool):
         """Baskets: simulate payoff(arithmetic) - payoff(geometric) and add the geometric closed form back."""
         check(lib().mc_context_set_control_variate(self._ctx, 1 if on else 0))
+
+    def set_finish(self, fused: bool):
+        """Final reduction inside the simulation kernel (default) or as a second launch (A/B baseline)."""
+        check(lib().mc_context_set_finish(self._ctx, 1 if fused else 0))
 
     def profile(self, every: int):
         """Sample the simulation kernel's device time on every `every`-th launch (0 = off)."""

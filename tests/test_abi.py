@@ -96,3 +96,40 @@ def test_no_gpu_is_a_loud_error(mc):
         pytest.skip("a GPU is visible")
     with pytest.raises(mc.McError, match="no HIP device"):
         mc.Engine(0)
+
+
+MULTI_LIB = os.path.join(ROOT, "montecarlocuda_amd", "csrc", "libmc_multi.so")
+
+
+def test_multi_library_exports_every_declared_symbol(mc):
+    """libmc_multi.so (several GPUs from one process, RCCL) loads without a GPU -- it links librccl and
+    libamdhip64 directly -- and exports every symbol include/mc_multi.h declares."""
+    assert os.path.exists(MULTI_LIB)
+    L = C.CDLL(MULTI_LIB)
+    header = open(os.path.join(INC, "mc_multi.h")).read()
+    declared = set(re.findall(r"\b(mc_multi_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) == 15, sorted(declared)
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    needed = subprocess.check_output(["readelf", "-d", MULTI_LIB], text=True)
+    assert "librccl.so" in needed and "libmc_mi355x.so" in needed      # RCCL's C API, linked directly
+    assert "torch" not in needed
+
+
+def test_multi_without_a_gpu_is_a_loud_error(mc):
+    if mc._lib.lib().mc_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    L = C.CDLL(MULTI_LIB)
+    L.mc_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.mc_multi_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    assert L.mc_multi_create(None, 0, 0, C.byref(h)) == 3      # MC_ERR_NO_DEVICE
+    assert b"no HIP device" in L.mc_multi_last_error() and not h.value
+
+
+def test_legacy_library_does_not_pull_in_rccl(mc):
+    """The single-GPU drop-in libraries stay light: RCCL (a 570 MB library) is loaded only when MC_DEVICES asks
+    for several GPUs (legacy_abi.c dlopens libmc_multi.so then)."""
+    for X in ("f32", "f64"):
+        needed = subprocess.check_output(["readelf", "-d", mc._lib.LEGACY[X]], text=True)
+        assert "librccl" not in needed and "libmc_multi" not in needed and "libmc_mi355x.so" in needed

@@ -1,0 +1,69 @@
+"""libmc_multi.so (include/mc_multi.h): one pricing call over several GPUs from ONE C process, closed by one
+RCCL all-reduce -- exercised from C (tests/c/multi_check.c, no Python or torch in that process), through the
+legacy symbols (MC_DEVICES) and through the strong-scaling driver.  On a one-GPU box the RCCL path runs with a
+communicator of one and the G > 1 sharding with a repeated device + host reduction; with more devices visible
+the same binary also runs all of them under RCCL and asserts multi == single (1e-12 rel in fp64)."""
+import json
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "montecarlocuda_amd", "csrc")
+pytestmark = pytest.mark.gpu
+
+
+def build_check(tmp_path):
+    exe = tmp_path / "multi_check"
+    subprocess.check_call(["gcc", "-std=gnu11", "-O2", "-Wall", f"-I{ROOT}/include", os.path.join(ROOT, "tests", "c", "multi_check.c"),
+                           "-o", str(exe), f"-L{CSRC}", "-lmc_multi", "-lmc_mi355x", "-lm", f"-Wl,-rpath,{CSRC}",
+                           f"-Wl,-rpath-link,{CSRC}:/opt/rocm/lib"])
+    return exe
+
+
+def test_c_multi_device_path_matches_single_device(tmp_path):
+    exe = build_check(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900)
+    print(out.stdout[-6000:])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "all checks passed" in out.stdout and "MISMATCH" not in out.stdout
+    assert "{0} rccl" in out.stdout and "{0,0,0} host" in out.stdout
+    if int(re.search(r"visible devices: (\d+)", out.stdout).group(1)) > 1:
+        assert "all rccl" in out.stdout
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_legacy_symbols_shard_over_MC_DEVICES(X):
+    """dev_vanillaOpt / dev_basketOpt / dev_cvaEquityOption with MC_DEVICES set go through libmc_multi.so (loaded
+    on demand); the C drivers' GPU legs must print the single-device numbers."""
+    exe = {p: os.path.join(ROOT, "drivers", f"{p}Opt_{X}") for p in ("vanilla", "basket", "cva")}
+    if not all(os.path.exists(e) for e in exe.values()):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")], stdout=subprocess.DEVNULL)
+
+    def gpu_numbers(prog, env):
+        out = subprocess.run([prog, "8", "--no-cpu"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        return [line for line in out.stdout.splitlines() if re.match(r"^-?\d+\.\d+", line)][:2], out.stdout
+    for prog in exe.values():
+        single, _ = gpu_numbers(prog, {})
+        multi, text = gpu_numbers(prog, {"MC_DEVICES": "0", "MC_VERBOSE": "1"})
+        assert single and single == multi, (prog, single, multi)
+        three, _ = gpu_numbers(prog, {"MC_DEVICES": "0,0,0", "MC_MULTI_REDUCE": "host"})
+        assert [round(float(a), 4) for a in three] == [round(float(a), 4) for a in single]
+    bad = subprocess.run([exe["vanilla"], "8", "--no-cpu"], capture_output=True, text=True, env=dict(os.environ, MC_DEVICES="0,99"))
+    assert bad.returncode == 1 and "out of range" in bad.stderr
+
+
+def test_strong_scaling_driver_emits_json():
+    exe = os.path.join(ROOT, "drivers", "multiBench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe, "--small", "--reps", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    rows = [json.loads(line) for line in out.stdout.splitlines()]
+    runs = [r for r in rows if "workload" in r]
+    assert len(runs) >= 4 and all(r["wall_ms_median"] > 0 and r["rccl_vs_host_rel"] <= 1e-12 for r in runs)
+    assert any(r["workload"].startswith("C4 basket n=16") and 9.5 < r["value"] < 9.9 for r in runs)
+    assert any(r["workload"].startswith("C5 CVA") and 0.18 < r["value"] < 0.20 for r in runs)

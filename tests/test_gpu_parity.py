@@ -621,3 +621,36 @@ def test_vanilla_pathwise_greeks(eng, po, X):
     exact = (BS_EXACT, 0.5 * math.erfc(-d1 / math.sqrt(2)), s * math.sqrt(t) * math.exp(-0.5 * d1 * d1) / math.sqrt(2 * math.pi))
     for g, want in zip(big, exact):
         assert abs(g.expected - want) < 3.5 / 1.96 * g.confidence, (g.expected, want)
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("n_assets", [1, 4, 9, 12, 16])
+@pytest.mark.parametrize("strike", [-1000.0, -3.5, 0.0])
+def test_basket_zero_and_negative_strike(mc, eng, po, X, n_assets, strike):
+    """The reference's max(basket - K, 0) (dp/MonteCarloKernel.cu:99-100) holds for any K.  The fp32 kernels
+    of <= 12 assets fold the max into a [0,1] clamp after a power-of-two rescale: the scale must cover
+    basket + |K| for K < 0 (with K = -1000 on spots of 100 every path is worth ~1100, not the scale)."""
+    b = dict(basket_inputs(mc, n_assets, X), k=strike)
+    for anti in (False, True):
+        eng.set_antithetic(anti)
+        try:
+            got = f64(eng.basket_paths(b, 4001, SEED, 3, X))
+            e = eng.basket(b, 4001, SEED, 3, X)
+        finally:
+            eng.set_antithetic(False)
+        want, o = po.dev_basket(X, b, SEED, 3, 4001, antithetic=anti)
+        level = 100.0 * 4 + abs(strike)
+        assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * level * 2
+        assert e.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"]) and e.sum2 == pytest.approx(o["sum2"], rel=2 * TOL[X]["rel"])
+        assert got.min() >= -strike * 0.999   # every path is in the money by at least |K|
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_greeks_refuse_out_of_range_models(mc, eng, X):
+    """The Greeks entry point applies the pricing paths' exponent guards (a huge v sqrt(t) used to return
+    inf / NaN sums with MC_OK)."""
+    wild = dict(VAN, v=60.0, t=4.0)
+    with pytest.raises(mc.McError, match="range of the simulation type"):
+        eng.vanilla_greeks(wild, 1000, SEED, 0, X)
+    g = eng.vanilla_greeks(dict(VAN, v=0.9, t=4.0), 1000, SEED, 0, X)
+    assert all(math.isfinite(q.sum) and math.isfinite(q.sum2) for q in g)
