@@ -135,6 +135,84 @@ def cpu_all_cores(seconds=2.0):
             "sample": f"{n} paths in {dt:.2f} s", "price": float(v.Expected)}
 
 
+def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, backend, barrier, reps):
+    """BASELINE.json's strong-scaling target, measured on this N: ONE pricing call of configs[3] (C4: basket, 16 assets,
+    1e9 paths, fp64) and of configs[4] (C5: CVA, 256 dates x 1e7 paths, fp64) -- and of 10x those sizes --
+    sharded over the N ranks (mc_shard_range), timed wall-clock from the first launch to the all-reduced triple on the
+    host, max over ranks, 2 warm-ups then `reps` repeats.  The driver's lines for N = 1, 2, 4, 8 give
+    the efficiency T1 / (N TN) of each row."""
+    import numpy as np
+    rows = []
+    specs = [("C4", "basket", basket_inputs(mc, 16, "f64"), 10 ** 9, "Basket call, 16 correlated assets, 1e9 paths, fp64 (BASELINE configs[3])"),
+             ("C4x10", "basket", basket_inputs(mc, 16, "f64"), 10 ** 10, "the same, 1e10 paths"),
+             ("C5", "cva", CVA, 10 ** 7, "CVA on vanilla call, 256 dates x 1e7 paths, fp64 (BASELINE configs[4])"),
+             ("C5x10", "cva", CVA, 10 ** 8, "the same, 1e8 paths")]
+    out = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for name, prod, inputs, total, desc in specs:
+        struct, keep = eng.prepared(prod, "f64", inputs)
+        first, count = mc.shard_range(total, rank, world)
+        times = []
+        host = None
+        for r_ in range(-2, reps):
+            barrier()
+            t0 = time.perf_counter()
+            if count:
+                eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), stream.cuda_stream)
+            else:
+                out.zero_()
+            if grouped and backend == "nccl":
+                dist.all_reduce(out, op=dist.ReduceOp.SUM)      # RCCL, ordered behind the launch (current stream)
+                host = out.cpu()
+            else:
+                host = out.cpu()
+                if grouped:
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            dt = time.perf_counter() - t0
+            if r_ >= 0:
+                times.append(dt)
+        t = torch.tensor(times, dtype=torch.float64, device="cuda" if (grouped and backend == "nccl") else "cpu")
+        if grouped:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)            # a repeat ends when its slowest rank has the result
+        times = sorted(t.tolist())
+        s_, s2_, n_ = (float(x) for x in host.tolist())
+        disc = 1.0 if prod == "cva" else math.exp(-float(inputs["r"]) * float(inputs["t"]))
+        price, ci = mc.closing(s_, s2_, int(n_), disc)
+        med = float(np.median(times))
+        rows.append({"config": name, "workload": desc, "paths_total": total, "paths_per_gpu": count, "reps": reps,
+                     "wall_ms_median": med * 1e3, "wall_ms_min": times[0] * 1e3, "paths_per_s": total / med,
+                     "value": price, "confidence_95": ci, "paths_priced": int(n_)})
+    return {"scaling": "strong", "n_gpus": world, "rows": rows,
+            "timing": "wall-clock, first launch -> all-reduced {sum, sum2, n} on the host, max over ranks; 2 warm-ups",
+            "note": "strong-scaling efficiency of a row = wall_ms_median(N=1) / (N * wall_ms_median(N)), from the driver's "
+                    "own N = 1, 2, 4, 8 lines"}
+
+
+def c_multi_block(max_seconds):
+    """The same strong-scaling rows through the C library alone: drivers/multiBench (plain C, libmc_multi.so: ONE
+    process drives G = 1, 2, 4, 8 ... of the visible GPUs, shards + one direct RCCL all-reduce).  Run as a child
+    process with a time limit so that nothing it does can disturb the headline measurement above."""
+    import subprocess
+    exe = os.path.join(ROOT, "drivers", "multiBench")
+    if not os.path.exists(exe):
+        return {"error": "drivers/multiBench not built (make -C drivers)"}
+    try:
+        out = subprocess.run([exe, "--reps", "5"], capture_output=True, text=True, timeout=max_seconds)
+    except subprocess.TimeoutExpired:
+        return {"error": f"drivers/multiBench exceeded {max_seconds} s"}
+    rows = []
+    for line in out.stdout.splitlines():
+        try:
+            rows.append(json.loads(line))
+        except ValueError:
+            pass
+    res = {"command": "drivers/multiBench --reps 5", "rc": out.returncode, "rows": rows,
+           "what": "one C process, libmc_multi.so: mc_shard_range + mc_*_launch_* per device + ONE ncclAllReduce(3, ncclDouble); "
+                   "wall-clock first launch -> closed estimate"}
+    if out.returncode != 0:
+        res["error"] = (out.stderr or out.stdout)[-400:]
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,9 +226,12 @@ def main():
                          "rank g taking mc_shard_range(paths, g, N) of every step")
     ap.add_argument("--streams", type=int, default=2,
                     help="independent (context, HIP stream) pairs the steps rotate over; >1 lets consecutive pricing "
-                         "calls overlap each other's launch gaps and finishing kernels")
-    ap.add_argument("--stream-source", default="torch", choices=["torch", "context"],
-                    help="where the launch streams come from: torch's stream pool, or each context's own stream")
+                         "calls overlap each other's launch gaps, ramps and tails")
+    ap.add_argument("--stream-source", default="context", choices=["torch", "context"],
+                    help="where the launch streams come from: each context's own stream (mc_context_stream; default) or "
+                         "torch's stream pool.  Two streams of torch's pool were seen to share ONE hardware queue on some "
+                         "boxes (57.6 instead of 49.3 us/step: no overlap at all; GPU_MAX_HW_QUEUES=8 or a third stream "
+                         "restores it), the contexts' own streams never did: profiles/r02_stream_queue_sweep.log")
     ap.add_argument("--profile-every", type=int, default=8)
     ap.add_argument("--blocks", type=int, default=0, help="workgroups per launch (0 = the engine's default, 8 per CU)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -167,6 +248,11 @@ def main():
                     help="untimed device work before the warm-up steps, so that the W warm-up steps and the K timed steps "
                          "run at the GPU's sustained clock (a cold MI355X needs tens of ms of load to ramp; with --warmup 5 "
                          "the timed region would otherwise measure the ramp).  Reported as config.preheat_ms; 0 = off")
+    ap.add_argument("--strong-reps", type=int, default=5,
+                    help="repeats of each strong-scaling row (C4, C5 and 10x sizes sharded over the N ranks; 0 = skip the block)")
+    ap.add_argument("--c-multi-seconds", type=int, default=240,
+                    help="N=1 only: time limit of the child process drivers/multiBench (the C library's own multi-GPU path over "
+                         "1, 2, 4, 8 ... of the visible GPUs); 0 = skip")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
@@ -271,7 +357,7 @@ def main():
     for i in range(W):
         step(i)
     drain()
-    eng.profile(args.profile_every)
+    eng.profile(1 if K < 100 else args.profile_every)   # short runs: every launch of the first context is sampled
     barrier()
     t0 = time.perf_counter()
     for i in range(W, W + K):
@@ -337,6 +423,10 @@ def main():
                      "price_error_vs_black_scholes": abs(p64 - BS_EXACT),
                      "workload": "same option and path count, fp64 simulation (vanilla_kernel<f64>)"}
 
+    strong = None
+    if args.strong_reps > 0 and args.workload == "vanilla_f32":
+        strong = strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, args.backend, barrier, args.strong_reps)
+
     if rank == 0:
         tot = triples[W:].sum(dim=0).cpu().tolist()           # every step's triple is already all-reduced
         r, t_ = float(inputs["r"]), float(inputs["t"])
@@ -348,68 +438,93 @@ def main():
         assert int(tot[2]) == K * step_total, (tot[2], K * step_total)
         units_per_step = step_total
         value = units_per_step * K / elapsed
-        kernel_s = (kernel_ms_total / samples) * 1e-3 if samples else None
-        ach = flop_per_path * shard_count / kernel_s / 1e12 if kernel_s else None
-        traffic = valu_busy = None
+        # ---- roofline of the dominant kernel (the simulation kernel) -------------------------------------------
+        # Durations, all measured live with HIP events bound to the kernel's own dispatch on its launch stream:
+        #   exclusive   n launches one at a time after the timed region: the kernel's duration -> achieved / frac
+        #   in_region   sampled launches inside the timed region; with S streams S launches are co-resident and
+        #               share the machine, so this is NOT a per-kernel duration (kept for the record)
+        #   effective   one GPU's flop per step / the step period: what the whole job sustains per GPU
+        peak = PEAK_TFLOPS[X]
+        flop_launch = flop_per_path * shard_count
+        in_region_s = (kernel_ms_total / samples) * 1e-3 if samples else None
+        ex_n, ex_s = exclusive if exclusive else (0, None)
+        kernel_s = ex_s or in_region_s
+        ach = flop_launch / kernel_s / 1e12 if kernel_s else None
+        step_s = elapsed / K
+        committed = {}
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                rec = json.load(open(pmc)).get(args.workload, {})
-                traffic, valu_busy = rec.get("hbm_bytes_per_launch"), rec.get("valu_busy_long_launch")
+                committed = json.load(open(pmc)).get(args.workload, {})
             except Exception:
-                traffic = valu_busy = None
+                committed = {}
         out = {
             "metric": "Monte Carlo paths/sec", "value": value, "unit": "paths/s", "n_gpus": world, "steps": K,
-            "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": X, "data": "synthetic",
+            "warmup": W, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": X, "data": "synthetic", "timed_region_s": elapsed,
             "config": {"workload": desc, "paths_per_gpu_per_step": shard_count, "global_paths_per_step": units_per_step,
                        "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
-                       "grid": f"{eng.blocks}x256", "streams": len(engines), "finish": args.finish,
-                       "preheat_ms": round(preheat_ms, 1)},
+                       "grid": f"{eng.blocks}x256", "streams": len(engines), "stream_source": args.stream_source,
+                       "finish": args.finish, "preheat_ms": round(preheat_ms, 1)},
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
-            "roofline": {"bound": "valu", "achieved": ach, "peak": PEAK_TFLOPS[X], "unit": "TFLOP/s",
-                         "frac": (ach / PEAK_TFLOPS[X]) if ach else None, "traffic": traffic,
-                         "kernel": kernel_name(prod, X, inputs), "avg_kernel_us": kernel_s * 1e6 if kernel_s else None,
-                         "kernel_samples": samples, "flop_per_path": flop_per_path,
-                         "valu_busy": valu_busy,   # PMC, committed profile of a ~10 ms launch of this kernel (not measured live)
+            "roofline": {"bound": "valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                         "frac": (ach / peak) if ach else None,
+                         "traffic": committed.get("hbm_bytes_per_launch"),
+                         "traffic_source": (committed.get("source", "") + " (committed PMC profile, not measured in this run)")
+                         if committed else None,
+                         "kernel": kernel_name(prod, X, inputs), "flop_per_path": flop_per_path,
+                         "avg_kernel_us": kernel_s * 1e6 if kernel_s else None, "kernel_samples": ex_n if ex_s else samples,
                          "kernel_paths_per_s": shard_count / kernel_s if kernel_s else None,
-                         "concurrent_launches": len(engines), "step_period_us": elapsed / K * 1e6,
-                         "note": "with 2 streams consecutive launches overlap (a launch's tail and finishing kernel run "
-                                 "beside the next launch's head), so per-kernel durations exceed the step period"
-                                 if len(engines) > 1 else "one launch at a time"},
+                         "duration_basis": "exclusive: %d launches of the same kernel on the same inputs, one at a time on one "
+                                           "stream right after the timed region, each timed on the device by HIP events bound to "
+                                           "its dispatch" % ex_n if ex_s else "in-region samples (no exclusive phase was run)",
+                         "in_region": {"avg_kernel_us": in_region_s * 1e6 if in_region_s else None, "kernel_samples": samples,
+                                       "concurrent_launches": len(engines), "step_period_us": step_s * 1e6,
+                                       "note": "launches of different streams are co-resident and share the CUs: a launch lasts "
+                                               "about `concurrent_launches` step periods; not a per-kernel duration"},
+                         "effective": {"achieved": flop_launch / step_s / 1e12, "frac": flop_launch / step_s / 1e12 / peak,
+                                       "paths_per_s_per_gpu": shard_count / step_s,
+                                       "note": "flop of one GPU's step / step period (whole job, launch gaps and tails included)"}},
         }
-        if exclusive:
-            ex_n, ex_s = exclusive
-            ex_ach = flop_per_path * shard_count / ex_s / 1e12
-            out["roofline"]["exclusive"] = {
-                "avg_kernel_us": ex_s * 1e6, "launches": ex_n, "achieved": ex_ach, "frac": ex_ach / PEAK_TFLOPS[X],
-                "kernel_paths_per_s": shard_count / ex_s,
-                "note": "the same kernel, one launch at a time on one stream after the timed region"}
-        if (prod, X) == ("vanilla", "f32"):
-            # SURVEY 8d's second fraction: the issue-slot ceiling of this kernel's instruction mix.  Per wave-trip
-            # (4 paths per lane) the ISA has 51 full-rate VALU instructions (4.1-4.2 cycles each next to multiplies,
-            # tools/ubench) and 12 transcendentals (8.1-8.3 cycles); with the lower ends 306.3 cycles; 1024 SIMDs x
-            # 64 lanes at the clock tools/clock_probe.py measures inside this kernel (2.39 GHz).
-            cycles, clock = 51 * 4.1 + 12 * 8.1, 2.39e9
-            ceiling = 1024 * 64 * 4 / cycles * clock
-            best = max(out["roofline"]["kernel_paths_per_s"] or 0, (exclusive and shard_count / exclusive[1]) or 0, value / world)
+        # SURVEY 8d's second fraction: the issue-slot ceiling of the instruction mix the kernel actually issues, from the
+        # committed PMC instruction counts of this kernel (wave-instructions per launch: all VALU, fp32 transcendentals,
+        # fp64 rcp/sqrt) and the issue costs tools/ubench measured on MI355X: 4.1 cycles per VALU instruction of a
+        # wave64 next to multiplies, 8.1 per fp32 transcendental, 16.1 per v_rcp/sqrt_f64; 1024 SIMDs at 2.39 GHz.
+        if committed.get("valu_insts_per_launch") and kernel_s:
+            v_all = committed["valu_insts_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
+            t32 = committed.get("trans_f32_per_launch", 0.0) * shard_count / committed.get("paths_per_launch", shard_count)
+            t64 = committed.get("trans_f64_per_launch", 0.0) * shard_count / committed.get("paths_per_launch", shard_count)
+            cycles = (v_all - t32 - t64) * 4.1 + t32 * 8.1 + t64 * 16.1
+            ceil_s = cycles / 1024 / 2.39e9
+            out["roofline"]["issue_frac"] = ceil_s / kernel_s
             out["roofline"]["issue_model"] = {
-                "cycles_per_wave_trip": cycles, "paths_per_wave_trip": 256, "clock_hz": clock,
-                "ceiling_paths_per_s": ceiling, "achieved_paths_per_s": best, "frac": best / ceiling,
-                "note": "ceiling of the instruction mix actually issued (Philox is integer work and transcendentals are "
-                        "half-rate, so the flop fraction above cannot approach 1); achieved = best of the per-GPU whole-job "
-                        "rate and the two per-kernel rates"}
+                "valu_wave_insts_per_launch": v_all, "trans_f32": t32, "trans_f64_rcp_sqrt": t64, "cycles": cycles,
+                "simds": 1024, "clock_hz": 2.39e9, "ceiling_us": ceil_s * 1e6, "kernel_us": kernel_s * 1e6,
+                "frac_effective": ceil_s / step_s,
+                "source": committed.get("source", "") + " (committed PMC instruction counts, scaled to this launch's paths)",
+                "valu_busy_long_launch": committed.get("valu_busy_long_launch"),
+                "valu_busy_source": committed.get("valu_busy_source"),
+                "note": "issue_frac = time the SIMDs need just to issue this launch's VALU instructions / measured duration: "
+                        "Philox is integer work and transcendentals are half-rate, so the flop fraction cannot approach 1; "
+                        "this one can"}
         if prod == "vanilla":
             out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
         if fp64_side:
             out["fp64"] = fp64_side
+        if strong:
+            out["strong"] = strong
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds)
             if prod == "vanilla" and X == "f32":
                 extra = cpu_all_cores()
                 if extra:
                     out["cpu_all_cores"] = extra
+        if world == 1 and args.c_multi_seconds > 0 and args.workload == "vanilla_f32":
+            for e in engines:       # the child process gets the GPU to itself
+                e.close()
+            engines = []
+            out["c_multi"] = c_multi_block(args.c_multi_seconds)
         print(json.dumps(out), flush=True)
     if grouped:
         barrier()

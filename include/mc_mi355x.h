@@ -217,6 +217,14 @@ void mc_shard_range(uint64_t total, int rank, int world, uint64_t *first, uint64
  * non-positive pivots met (0 = the input was positive definite). */
 int mc_chol_f32(int n, const float *c, float *a);
 int mc_chol_f64(int n, const double *c, double *a);
+/* Covariance-matrix input (the reference's drivers take volatilities and a correlation matrix and
+ * call Chol themselves, dp/basketOpt.cu:34-61,96-99).  cov = row-major n x n covariance of the assets' annualised
+ * log-returns; like Chol (dp/MonteCarloHost.c:96-99) only its lower triangle is read.  Out: v[n] = sqrt(cov[a][a])
+ * and p[n*n] = Cholesky factor (reference semantics) of the correlation matrix cov[a][b] / (v[a] v[b]) -- the `v`
+ * and `p` of mc_basket_* / MultiOptionData.  Returns the number of non-positive pivots (0 = positive definite), or
+ * -1 for a bad argument (n < 1, NULL, a non-finite entry, a diagonal entry <= 0). */
+int mc_factor_from_cov_f32(int n, const float *cov, float *v, float *p);
+int mc_factor_from_cov_f64(int n, const double *cov, double *v, double *p);
 
 #ifdef __cplusplus
 }

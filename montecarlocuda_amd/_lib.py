@@ -70,7 +70,7 @@ CVA = {"f32": CvaF32, "f64": CvaF64}
 
 # every symbol include/mc_mi355x.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = ["mc_last_error", "mc_device_count", "mc_context_create", "mc_context_destroy", "mc_context_device",
-           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read", "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64"]
+           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read", "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
 for _x in ("f32", "f64"):
     for _p in ("vanilla", "basket", "cva"):
         EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]
@@ -107,6 +107,7 @@ def _declare(L: C.CDLL) -> C.CDLL:
         R = CT[X]
         RP = C.POINTER(R)
         getattr(L, f"mc_chol_{X}").argtypes = [C.c_int, RP, RP]
+        getattr(L, f"mc_factor_from_cov_{X}").argtypes = [C.c_int, RP, RP, RP]
         for prod, S in (("vanilla", OPTION[X]), ("basket", BASKET[X]), ("cva", CVA[X])):
             getattr(L, f"mc_{prod}_launch_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, C.c_void_p, C.c_void_p]
             getattr(L, f"mc_{prod}_run_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, C.POINTER(Result)]

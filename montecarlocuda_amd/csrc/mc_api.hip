@@ -1169,6 +1169,37 @@ static int chol_impl(int n, const Real *c, Real *a)
 extern "C" int mc_chol_f32(int n, const float *c, float *a) { return chol_impl<float>(n, c, a); }
 extern "C" int mc_chol_f64(int n, const double *c, double *a) { return chol_impl<double>(n, c, a); }
 
+// Covariance input.  The reference's drivers hold volatilities and a CORRELATION matrix and factor
+// the latter with Chol before either path runs (dp/basketOpt.cu:34-61,96-99); a caller who holds the covariance of
+// the annualised log-returns gets both inputs of the basket structs from it here: v_a = sqrt(cov_aa), correlation
+// cov_ab / (v_a v_b) with an exact unit diagonal, then Chol's factorisation (same arithmetic, same zero-pivot rule,
+// dp/MonteCarloHost.c:90-105).  Like Chol, only the lower triangle of the input is read.  All in Real.
+template <class Real>
+static int factor_from_cov(int n, const Real *cov, Real *v, Real *p)
+{
+    if (n < 1 || !cov || !v || !p)
+        return -1;
+    for (int a = 0; a < n; ++a) {
+        const Real var = cov[a * n + a];
+        if (!(var > 0) || !std::isfinite((double)var))
+            return -1;   // no volatility to extract
+        v[a] = std::sqrt(var);
+    }
+    std::vector<Real> corr((size_t)n * n, (Real)0);
+    for (int a = 0; a < n; ++a) {
+        corr[(size_t)a * n + a] = 1;
+        for (int b = 0; b < a; ++b) {
+            const Real c = cov[a * n + b];
+            if (!std::isfinite((double)c))
+                return -1;
+            corr[(size_t)a * n + b] = corr[(size_t)b * n + a] = c / (v[a] * v[b]);
+        }
+    }
+    return chol_impl<Real>(n, corr.data(), p);
+}
+extern "C" int mc_factor_from_cov_f32(int n, const float *cov, float *v, float *p) { return factor_from_cov<float>(n, cov, v, p); }
+extern "C" int mc_factor_from_cov_f64(int n, const double *cov, double *v, double *p) { return factor_from_cov<double>(n, cov, v, p); }
+
 // run = enqueue on the context stream between two events, wait, read 24 bytes, close
 template <class Enq>
 static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, Enq enqueue)

@@ -256,6 +256,20 @@ def chol(c, precision="f64"):
     return a, bad
 
 
+def factor_from_cov(cov, precision="f64"):
+    """Volatilities and Cholesky factor of the correlation matrix from a covariance matrix (mc_factor_from_cov_*).
+    Returns (v, factor, bad_pivots); raises ValueError for a non-positive or non-finite diagonal."""
+    cov = np.ascontiguousarray(cov, dtype=NP[precision])
+    n = cov.shape[0]
+    v = np.zeros(n, dtype=NP[precision])
+    p = np.zeros((n, n), dtype=NP[precision])
+    P = C.POINTER(_lib.CT[precision])
+    bad = getattr(lib(), f"mc_factor_from_cov_{precision}")(n, cov.ctypes.data_as(P), v.ctypes.data_as(P), p.ctypes.data_as(P))
+    if bad < 0:
+        raise ValueError("covariance matrix needs a finite, positive diagonal and finite entries")
+    return v, p, bad
+
+
 # ---- the reference's three entry points ------------------------------------------------------
 _default_engine: Optional[Engine] = None
 

@@ -60,6 +60,7 @@ void orc_closing(double sum, double sum2, long long n, double discount,
     REAL orc_cnd_##X(REAL d);                                                                    \
     REAL orc_bs_call_##X(REAL s, REAL k, REAL r, REAL v, REAL t);                                \
     void orc_chol_##X(int n, const REAL *c, REAL *a);                                            \
+    int orc_factor_from_cov_##X(int n, const REAL *cov, REAL *v, REAL *corr, REAL *a);           \
     /* reference CPU stream */                                                                   \
     void orc_host_uniforms_##X(unsigned seed, int count, REAL *out);                             \
     void orc_host_gaussians_##X(unsigned seed, int count, REAL *out);                            \

@@ -69,6 +69,29 @@ void FN(orc_chol)(int n, const REAL *c, REAL *a)
     free(work);
 }
 
+/* Covariance input: what a caller of the reference would do by hand before Chol when it holds a
+ * covariance matrix instead of (vols, correlation) -- v_a = sqrt(cov_aa), corr_ab = cov_ab / (v_a v_b) from the
+ * lower triangle, unit diagonal -- followed by the reference's Chol (dp/basketOpt.cu:96-99, dp/MonteCarloHost.c:90-105).
+ * Twin of mc_factor_from_cov_*; the Chol step is pinned by tests/golden/ref_chol.json and ref_cov.json. */
+int FN(orc_factor_from_cov)(int n, const REAL *cov, REAL *v, REAL *corr, REAL *a)
+{
+    for (int i = 0; i < n; i++) {
+        if (!(cov[i * n + i] > 0))
+            return -1;
+        v[i] = SQRT_R(cov[i * n + i]);
+    }
+    for (int i = 0; i < n; i++) {
+        corr[i * n + i] = 1;
+        for (int j = 0; j < i; j++)
+            corr[i * n + j] = corr[j * n + i] = cov[i * n + j] / (v[i] * v[j]);
+    }
+    FN(orc_chol)(n, corr, a);
+    int bad = 0;
+    for (int i = 0; i < n; i++)
+        bad += !(a[i * n + i] > 0);
+    return bad;
+}
+
 /* ===================================================================================== */
 /*  Reference CPU random stream: glibc rand(), cosine-branch Box-Muller                    */
 /* ===================================================================================== */

@@ -139,6 +139,19 @@ def chol(X, c):
     return out
 
 
+def factor_from_cov(X, cov):
+    """(v, corr, factor, bad_pivots): the covariance twin of chol (oracle/mc_oracle_impl.h: orc_factor_from_cov)."""
+    cov = np.ascontiguousarray(cov, dtype=NP[X])
+    n = cov.shape[0]
+    v, corr, a = np.zeros(n, dtype=NP[X]), np.zeros((n, n), dtype=NP[X]), np.zeros((n, n), dtype=NP[X])
+    P = C.POINTER(CT[X])
+    f = getattr(lib(), f"orc_factor_from_cov_{X}")
+    f.argtypes = [C.c_int, P, P, P, P]
+    f.restype = C.c_int
+    bad = f(n, cov.ctypes.data_as(P), v.ctypes.data_as(P), corr.ctypes.data_as(P), a.ctypes.data_as(P))
+    return v, corr, a, bad
+
+
 def host_uniforms(X, seed, count):
     out = np.zeros(count, dtype=NP[X])
     getattr(lib(), f"orc_host_uniforms_{X}")(seed, count, out.ctypes.data_as(C.POINTER(CT[X])))

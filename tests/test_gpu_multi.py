@@ -62,7 +62,7 @@ def test_strong_scaling_driver_emits_json():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")], stdout=subprocess.DEVNULL)
     out = subprocess.run([exe, "--small", "--reps", "3"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
-    rows = [json.loads(line) for line in out.stdout.splitlines()]
+    rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]   # RCCL prints a version banner
     runs = [r for r in rows if "workload" in r]
     assert len(runs) >= 4 and all(r["wall_ms_median"] > 0 and r["rccl_vs_host_rel"] <= 1e-12 for r in runs)
     assert any(r["workload"].startswith("C4 basket n=16") and 9.5 < r["value"] < 9.9 for r in runs)

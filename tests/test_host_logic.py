@@ -68,3 +68,32 @@ def test_basket_control_mean_matches_oracle_and_simulation(mc, po):
         assert abs(ctrl["expected"] - plain["expected"]) < 3.5 / 1.96 * plain["confidence"]
     with pytest.raises(mc.McError, match=r"w\[a\] > 0"):
         mc.basket_control_mean(dict(b, w=[1.0] * 15 + [-0.5]))
+
+
+def test_factor_from_cov_matches_reference_golden(mc, po):
+    """mc_factor_from_cov_* (SURVEY 8f-2): vols and Cholesky factor of the correlation matrix from a covariance
+    matrix, bit for bit what the reference's Chol returns for the hand-normalised matrix (tests/golden/ref_cov.json),
+    with the non-positive pivots counted instead of silently zeroed (SURVEY 2.3 #10)."""
+    for c in load_golden("ref_cov.json")["cases"]:
+        cov = np.array([[fromhex(x) for x in row] for row in c["cov"]])
+        v, p, bad = mc.factor_from_cov(cov, c["X"])
+        key = (c["X"], c["n"], c["name"])
+        assert (v.astype(np.float64) == np.array([fromhex(x) for x in c["v"]])).all(), key
+        assert (p.astype(np.float64) == np.array([[fromhex(x) for x in row] for row in c["a"]])).all(), key
+        assert bad == c["bad_pivots"], key
+        ov, _, oa, obad = po.factor_from_cov(c["X"], cov)
+        assert (ov == v).all() and (oa == p).all() and obad == bad
+    # only the lower triangle is read (as Chol does, MonteCarloHost.c:96-99)
+    cov = np.array([[0.09, 99.0], [0.03, 0.04]])
+    v, p, bad = mc.factor_from_cov(cov)
+    assert bad == 0 and v.tolist() == [0.3, 0.2] and p[1, 0] == 0.03 / (0.3 * 0.2)
+    # round trip: (diag(v) p)(diag(v) p)^T is the covariance again
+    rng = np.random.default_rng(11)
+    g = rng.standard_normal((7, 12)) * 0.25
+    cov = g @ g.T
+    v, p, bad = mc.factor_from_cov(cov)
+    m = v[:, None] * p
+    assert bad == 0 and np.abs(m @ m.T - cov).max() < 1e-14
+    for badcov in ([[0.0, 0.0], [0.0, 1.0]], [[-1.0, 0.0], [0.0, 1.0]], [[float("nan"), 0.0], [0.0, 1.0]], [[1.0, 0.0], [float("inf"), 1.0]]):
+        with pytest.raises(ValueError):
+            mc.factor_from_cov(badcov)

@@ -119,3 +119,26 @@ def test_live_reference_extra_seeds(po, X):
         e, ci = ref.basket(b, 4000, seed)
         r = po.host_basket(X, b, 4000, seed)
         assert (r["expected"], r["confidence"]) == (e, ci)
+
+
+def test_factor_from_cov_bitwise(po):
+    """Covariance input: normalise to vols + correlation, then the reference's Chol.  The golden
+    correlation and factor come from numpy scalars of the target precision and the compiled reference Chol
+    (tests/golden/gen_golden_cov.py); the oracle twin must reproduce v, the correlation and the factor bit for bit."""
+    cases = load_golden("ref_cov.json")["cases"]
+    assert len(cases) >= 24 and {c["n"] for c in cases} == {3, 4, 16}
+    for c in cases:
+        cov = np.array([[fromhex(x) for x in row] for row in c["cov"]])
+        v, corr, a, bad = po.factor_from_cov(c["X"], cov)
+        key = (c["X"], c["n"], c["name"])
+        assert (v.astype(np.float64) == np.array([fromhex(x) for x in c["v"]])).all(), key
+        assert (corr.astype(np.float64) == np.array([[fromhex(x) for x in row] for row in c["corr"]])).all(), key
+        assert (a.astype(np.float64) == np.array([[fromhex(x) for x in row] for row in c["a"]])).all(), key
+        assert bad == c["bad_pivots"], key
+    # live against the compiled reference where it is present
+    if po.ref_available("f64", 4):
+        rng = np.random.default_rng(5)
+        for X in ("f64", "f32"):
+            g = rng.standard_normal((4, 9)) * 0.2
+            v, corr, a, bad = po.factor_from_cov(X, g @ g.T)
+            assert (po.Ref(X, 4).chol(corr.tolist()) == a).all() and bad == 0
