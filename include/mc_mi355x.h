@@ -182,6 +182,33 @@ int mc_vanilla_greeks_run_f32(mc_context *ctx, const mc_option_f32 *opt, uint64_
 int mc_vanilla_greeks_run_f64(mc_context *ctx, const mc_option_f64 *opt, uint64_t seed,
                               uint64_t first_path, uint64_t n_paths, mc_vanilla_greeks *out);
 
+/* Likelihood-ratio forms of the same three numbers: delta = payoff z / (S sigma sqrt T), vega = payoff ((z^2 - 1) / sigma
+ * - z sqrt T), z the path's normal.  They differentiate the density instead of the payoff (no indicator), at the price
+ * of a larger variance on a smooth payoff like this one; needs v > 0 and t > 0. */
+int mc_vanilla_greeks_lr_run_f32(mc_context *ctx, const mc_option_f32 *opt, uint64_t seed,
+                                 uint64_t first_path, uint64_t n_paths, mc_vanilla_greeks *out);
+int mc_vanilla_greeks_lr_run_f64(mc_context *ctx, const mc_option_f64 *opt, uint64_t seed,
+                                 uint64_t first_path, uint64_t n_paths, mc_vanilla_greeks *out);
+
+/* ---- pathwise Greeks of the basket call ------------------------------------------------
+ * On the pricing kernels' stream and path indexing (reference formulas dp/MonteCarloKernel.cu:74-101), with
+ * B = sum_a w_a S_a(T), I = [B > K]:  price,  delta[a] = dV/dS_a = I w_a S_a(T) / S_a,
+ * vega[a] = dV/dv_a = I w_a S_a(T) (bt_a sqrt T - v_a T); discounted means with their own 95 % half-widths.
+ * delta and vega are caller arrays of opt->n results.  Plain estimator; the path is re-simulated once per asset. */
+int mc_basket_greeks_run_f32(mc_context *ctx, const mc_basket_f32 *opt, uint64_t seed, uint64_t first_path,
+                             uint64_t n_paths, mc_result *price, mc_result *delta, mc_result *vega);
+int mc_basket_greeks_run_f64(mc_context *ctx, const mc_basket_f64 *opt, uint64_t seed, uint64_t first_path,
+                             uint64_t n_paths, mc_result *price, mc_result *delta, mc_result *vega);
+
+/* ---- CVA with its pathwise delta ---------------------------------------------------------
+ * d CVA / d S_0 = LGD sum_j dp_j cnd(d1_j) S_j / S_0 on the CVA kernel's stream (reference loop
+ * dp/MonteCarloKernel.cu:241-262); not discounted, like the CVA itself (:466).  Plain estimator. */
+typedef struct { mc_result cva, delta; } mc_cva_greeks;
+int mc_cva_greeks_run_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed, uint64_t first_path,
+                          uint64_t n_paths, mc_cva_greeks *out);
+int mc_cva_greeks_run_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed, uint64_t first_path,
+                          uint64_t n_paths, mc_cva_greeks *out);
+
 /* ---- per-path values, for parity tests ---------------------------------------------------
  * h_out: HOST pointer to n_paths values (undiscounted payoffs / per-path CVA).  Same kernels
  * as above with a store of every value added; n_paths <= 2^26. */

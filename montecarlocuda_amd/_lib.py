@@ -64,6 +64,10 @@ class Greeks(C.Structure):
     _fields_ = [("price", Result), ("delta", Result), ("vega", Result)]
 
 
+class CvaGreeks(C.Structure):
+    _fields_ = [("cva", Result), ("delta", Result)]
+
+
 OPTION = {"f32": OptionF32, "f64": OptionF64}
 BASKET = {"f32": BasketF32, "f64": BasketF64}
 CVA = {"f32": CvaF32, "f64": CvaF64}
@@ -75,7 +79,7 @@ for _x in ("f32", "f64"):
     for _p in ("vanilla", "basket", "cva"):
         EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]
     EXPORTS.append(f"mc_normals_{_x}")
-    EXPORTS.append(f"mc_vanilla_greeks_run_{_x}")
+    EXPORTS += [f"mc_vanilla_greeks_run_{_x}", f"mc_vanilla_greeks_lr_run_{_x}", f"mc_basket_greeks_run_{_x}", f"mc_cva_greeks_run_{_x}"]
 
 
 def _declare(L: C.CDLL) -> C.CDLL:
@@ -114,6 +118,10 @@ def _declare(L: C.CDLL) -> C.CDLL:
             getattr(L, f"mc_{prod}_paths_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, RP]
         getattr(L, f"mc_normals_{X}").argtypes = [ctx, u64, C.c_uint32, u64, u64, C.c_uint32, RP]
         getattr(L, f"mc_vanilla_greeks_run_{X}").argtypes = [ctx, C.POINTER(OPTION[X]), u64, u64, u64, C.POINTER(Greeks)]
+        getattr(L, f"mc_vanilla_greeks_lr_run_{X}").argtypes = [ctx, C.POINTER(OPTION[X]), u64, u64, u64, C.POINTER(Greeks)]
+        getattr(L, f"mc_basket_greeks_run_{X}").argtypes = [ctx, C.POINTER(BASKET[X]), u64, u64, u64, C.POINTER(Result), C.POINTER(Result),
+                                                            C.POINTER(Result)]
+        getattr(L, f"mc_cva_greeks_run_{X}").argtypes = [ctx, C.POINTER(CVA[X]), u64, u64, u64, C.POINTER(CvaGreeks)]
     return L
 
 

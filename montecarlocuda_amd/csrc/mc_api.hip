@@ -67,7 +67,9 @@ struct mc_context {
     hipStream_t last_stream = nullptr;   // stream of the most recent call
     bool used = false;
     double *d_triple = nullptr;   // result slot of the synchronous runs
-    double *d_triple9 = nullptr;  // three result slots (price, delta, vega), allocated on first use
+    double2 *g_pairs = nullptr;   // multi-plane calls (Greeks): g_planes planes of 2 * blocks + 2 pairs, allocated on first use
+    double *g_triples = nullptr;  // one triple per plane
+    int g_planes = 0;
     double *h_triple = nullptr;   // pinned
     void *d_out = nullptr;        // per-path dump buffer (tests), grown on demand
     size_t d_out_bytes = 0;
@@ -198,7 +200,8 @@ extern "C" void mc_context_destroy(mc_context *c)
     (void)hipFree(c->tickets);
     if (c->last_use) (void)hipEventDestroy(c->last_use);
     (void)hipFree(c->d_triple);
-    (void)hipFree(c->d_triple9);
+    (void)hipFree(c->g_pairs);
+    (void)hipFree(c->g_triples);
     (void)hipHostFree(c->h_triple);
     (void)hipFree(c->d_out);
     (void)hipFree(c->d_table);
@@ -395,7 +398,8 @@ static Tail make_tail(const mc_context *c, int total, double scale1, double scal
     t.scale1 = scale1;
     t.scale2 = scale2;
     t.n_paths = (double)n;
-    t.slot_base = 0;
+    t.slot_base = t.ticket_base = 0;
+    t.pairs = (uint32_t)total;
     t.total = c->fused ? (uint32_t)total : 0u;
     t.planes = (uint32_t)planes;
     t.plane_stride = (uint32_t)plane_stride;
@@ -422,7 +426,7 @@ static int finish_call(mc_context *c, const Tail &t, int total, hipStream_t st)
 {
     if (!c->fused)
         for (uint32_t q = 0; q < t.planes; ++q)
-            finish_kernel<<<1, GROUP, 0, st>>>(c->partials + (size_t)q * t.plane_stride, total, t.scale1, t.scale2, t.n_paths,
+            finish_kernel<<<1, GROUP, 0, st>>>(t.partials + (size_t)q * t.plane_stride, total, t.scale1, t.scale2, t.n_paths,
                                                t.triple + 3 * q);
     HIPCHK(hipGetLastError());
     return MC_OK;
@@ -605,7 +609,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, first, end);
         const int g = grid_for(c, s.count);
-        t.slot_base = (uint32_t)slot;
+        t.slot_base = t.ticket_base = (uint32_t)slot;
         if (out)
             masked<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
         else
@@ -616,7 +620,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         if (!(e == 0 ? has_head : has_tail))
             continue;
         const Work w = make_work(seed, Segment{e == 0 ? head : tail_unit, 1u}, first, end);
-        t.slot_base = (uint32_t)slot;
+        t.slot_base = t.ticket_base = (uint32_t)slot;
         masked<<<1, GROUP, 0, st>>>(t, k, w, nullptr, (Real)1);
         slot += 1;
     }
@@ -634,6 +638,8 @@ static void greeks_prepare(const mc_option_f32 &o, GreeksF32 &k)
     k.spot = o.s, k.strike = o.k;
     k.sqrt_t = (float)std::sqrt((double)o.t);
     k.sigma_t = (float)((double)o.v * (double)o.t);
+    k.lr_delta = (float)(1.0 / ((double)o.s * (double)o.v * std::sqrt((double)o.t)));
+    k.inv_sigma = (float)(1.0 / (double)o.v);
 }
 static void greeks_prepare(const mc_option_f64 &o, GreeksF64 &k)
 {
@@ -642,15 +648,81 @@ static void greeks_prepare(const mc_option_f64 &o, GreeksF64 &k)
     k.spot = o.s, k.strike = o.k;
     k.sqrt_t = std::sqrt(o.t);
     k.sigma_t = o.v * o.t;
+    k.lr_delta = 1.0 / (o.s * o.v * std::sqrt(o.t));
+    k.inv_sigma = 1.0 / o.v;
 }
 
-template <class Real, class In, class Opt>
-static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first, uint64_t n, mc_vanilla_greeks *out)
+// Multi-plane calls (Greeks): `planes` (sum, sum2) pairs per workgroup in a buffer of their own, one triple per plane.
+// Synchronous: enqueue on the context stream, wait, close every plane with `discount`.
+static int ensure_planes(mc_context *c, int planes)
+{
+    if (planes <= c->g_planes)
+        return MC_OK;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->g_pairs) HIPCHK(hipFree(c->g_pairs));
+    if (c->g_triples) HIPCHK(hipFree(c->g_triples));
+    c->g_pairs = nullptr, c->g_triples = nullptr, c->g_planes = 0;
+    HIPCHK(hipMalloc(&c->g_pairs, sizeof(double2) * (size_t)planes * (2 * (size_t)c->blocks + 2)));
+    HIPCHK(hipMalloc(&c->g_triples, sizeof(double) * 3 * (size_t)planes));
+    c->g_planes = planes;
+    return MC_OK;
+}
+
+// launch(tail, segment index, segment, grid) enqueues one segment; grid_y = workgroups per x position (arrivals)
+template <class Launch>
+static int planes_run(mc_context *c, int planes, int grid_y, uint64_t unit0, uint64_t n_units, uint64_t n, double discount,
+                      mc_result **out, Launch launch)
 {
     const auto wall0 = std::chrono::steady_clock::now();
+    hipStream_t st = c->stream;
+    if (int rc = begin_call(c, st)) return rc;
+    if (int rc = ensure_planes(c, planes)) return rc;
+    std::vector<Segment> segs;
+    if (int rc = plan_segments(unit0, n_units, segs)) return rc;
+    if (segs.size() > 2)   // a plane holds the pairs of two full launches
+        return fail(MC_ERR_INVALID, "greeks: path range too large for one call; split it");
+    HIPCHK(hipEventRecord(c->ev0, st));
+    int pairs = 0;
+    for (const Segment &s : segs)
+        pairs += grid_for(c, s.count);
+    Tail t = make_tail(c, pairs, 1.0, 1.0, n, c->g_triples, planes, 2 * c->blocks + 2);
+    t.partials = c->g_pairs;
+    if (c->fused)
+        t.total = (uint32_t)(pairs * grid_y);
+    int slot = 0;
+    for (const Segment &s : segs) {
+        const int g = grid_for(c, s.count);
+        t.slot_base = (uint32_t)slot;
+        t.ticket_base = (uint32_t)(slot * grid_y);
+        launch(t, s, g, st);
+        slot += g;
+    }
+    if (int rc = finish_call(c, t, pairs, st)) return rc;
+    HIPCHK(hipEventRecord(c->ev1, st));
+    std::vector<double> h(3 * (size_t)planes);
+    HIPCHK(hipMemcpyAsync(h.data(), c->g_triples, sizeof(double) * h.size(), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    for (int q = 0; q < planes; ++q) {
+        mc_result *r = out[q];
+        r->sum = h[3 * q], r->sum2 = h[3 * q + 1], r->n = (uint64_t)h[3 * q + 2], r->kernel_ms = ms, r->wall_ms = wall;
+        if (r->n != n)
+            return fail(MC_ERR_HIP, "device returned n=%llu, expected %llu", (unsigned long long)r->n, (unsigned long long)n);
+        mc_closing(r->sum, r->sum2, r->n, discount, &r->expected, &r->confidence);
+    }
+    return MC_OK;
+}
+
+template <class Real, class In, class Opt, bool LR>
+static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first, uint64_t n, mc_vanilla_greeks *out)
+{
     if (int rc = check_common(c, o, first, n, out)) return rc;
     if (!finite_pos(o->s) || !finite_pos(o->k) || !(o->v >= 0) || !(o->t >= 0) || !std::isfinite((double)o->r))
         return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
+    if (LR && !((double)o->v > 0 && (double)o->t > 0))
+        return fail(MC_ERR_INVALID, "likelihood-ratio greeks: need v>0 and t>0 (the scores divide by sigma sqrt t)");
     if (c->antithetic)
         return fail(MC_ERR_UNSUPPORTED, "greeks: only the plain estimator is implemented");
     {   // the pricing paths' exponent-range guards (VanillaTraits<>::prepare): refuse inputs whose terminal spot
@@ -664,59 +736,35 @@ static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first,
             return fail(MC_ERR_INVALID, "greeks: (r - v^2/2) t and v sqrt(t) put the terminal spot outside the range of the simulation type");
     }
     constexpr uint64_t NPB = npb<Real>::value;
-    hipStream_t st = c->stream;
-    if (int rc = begin_call(c, st)) return rc;
     Opt k;
     greeks_prepare(*o, k);
     const uint64_t end = first + n, u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
-    std::vector<Segment> segs;
-    if (int rc = plan_segments(u0, u1 - u0, segs)) return rc;
-    if (segs.size() > 2)   // three pair-planes share the partial buffer
-        return fail(MC_ERR_INVALID, "greeks: path range too large for one call; split it");
-    const int plane = 2 * c->blocks + 2;   // pairs reserved per quantity
-    if (!c->d_triple9)
-        HIPCHK(hipMalloc(&c->d_triple9, 9 * sizeof(double)));
-    HIPCHK(hipEventRecord(c->ev0, st));
-    int total = 0;
-    for (const Segment &s : segs)
-        total += grid_for(c, s.count);
-    Tail t = make_tail(c, total, 1.0, 1.0, n, c->d_triple9, 3, plane);
-    int slot = 0;
-    for (const Segment &s : segs) {
-        const Work w = make_work(seed, s, first, end);
-        const int g = grid_for(c, s.count);
-        t.slot_base = (uint32_t)slot;
-        vanilla_greeks_kernel<Opt, Real><<<g, GROUP, 0, st>>>(t, k, w);
-        slot += g;
-    }
-    if (int rc = finish_call(c, t, total, st)) return rc;
-    HIPCHK(hipEventRecord(c->ev1, st));
-    double h[9];
-    HIPCHK(hipMemcpyAsync(h, c->d_triple9, sizeof h, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    const double disc = std::exp(-(double)o->r * (double)o->t);
     mc_result *r[3] = {&out->price, &out->delta, &out->vega};
-    for (int q = 0; q < 3; ++q) {
-        r[q]->sum = h[3 * q], r[q]->sum2 = h[3 * q + 1], r[q]->n = (uint64_t)h[3 * q + 2], r[q]->kernel_ms = ms;
-        mc_closing(r[q]->sum, r[q]->sum2, r[q]->n, disc, &r[q]->expected, &r[q]->confidence);
-    }
-    const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-    for (int q = 0; q < 3; ++q)
-        r[q]->wall_ms = wall;
-    return MC_OK;
+    return planes_run(c, 3, 1, u0, u1 - u0, n, std::exp(-(double)o->r * (double)o->t), r,
+                      [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
+                          vanilla_greeks_kernel<Opt, Real, LR><<<g, GROUP, 0, st>>>(t, k, make_work(seed, s, first, end));
+                      });
 }
 
 extern "C" int mc_vanilla_greeks_run_f32(mc_context *c, const mc_option_f32 *o, uint64_t seed, uint64_t first, uint64_t n,
                                          mc_vanilla_greeks *out)
 {
-    return greeks_run<float, mc_option_f32, GreeksF32>(c, o, seed, first, n, out);
+    return greeks_run<float, mc_option_f32, GreeksF32, false>(c, o, seed, first, n, out);
 }
 extern "C" int mc_vanilla_greeks_run_f64(mc_context *c, const mc_option_f64 *o, uint64_t seed, uint64_t first, uint64_t n,
                                          mc_vanilla_greeks *out)
 {
-    return greeks_run<double, mc_option_f64, GreeksF64>(c, o, seed, first, n, out);
+    return greeks_run<double, mc_option_f64, GreeksF64, false>(c, o, seed, first, n, out);
+}
+extern "C" int mc_vanilla_greeks_lr_run_f32(mc_context *c, const mc_option_f32 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                            mc_vanilla_greeks *out)
+{
+    return greeks_run<float, mc_option_f32, GreeksF32, true>(c, o, seed, first, n, out);
+}
+extern "C" int mc_vanilla_greeks_lr_run_f64(mc_context *c, const mc_option_f64 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                            mc_vanilla_greeks *out)
+{
+    return greeks_run<double, mc_option_f64, GreeksF64, true>(c, o, seed, first, n, out);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -823,7 +871,7 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
-        t.slot_base = (uint32_t)slot;
+        t.slot_base = t.ticket_base = (uint32_t)slot;
         basket_launch_kernel<NA>(prof, c->antithetic, k, w, t, out ? out + done : (Real *)nullptr, out_scale, g, st);
         slot += g;
         done += s.count;
@@ -957,7 +1005,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
-        tail.slot_base = (uint32_t)slot;
+        tail.slot_base = tail.ticket_base = (uint32_t)slot;
         launch_sim_lds(prof, kernel, g, lds, st, tail, k, w, out ? out + done : (Real *)nullptr);
         slot += g;
         done += s.count;
@@ -1058,12 +1106,10 @@ static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaS
     return MC_OK;
 }
 
+// Build (or reuse) the per-date table of a CVA call in the context's table buffer, ordered on `st`.
 template <class Real>
-static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint64_t seed, uint64_t first, uint64_t n,
-                       double *d_triple, hipStream_t st, Real *out)
+static int cva_table_ready(mc_context *c, const typename CvaIn<Real>::type *v, hipStream_t st, CvaArgs<Real> &args)
 {
-    if (int rc = begin_call(c, st)) return rc;
-    CvaArgs<Real> args;
     // the table depends only on the inputs: rebuild and re-upload only when they change
     const double key_vals[9] = {(double)v->defint, (double)v->lgd, (double)v->option.s, (double)v->option.k,
                                 (double)v->option.r, (double)v->option.v, (double)v->option.t,
@@ -1095,6 +1141,16 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         if (int rc = upload_table(c, st, key, tab.data(), bytes)) return rc;
     }
     args.steps = (const CvaStep<Real> *)c->d_table;
+    return MC_OK;
+}
+
+template <class Real>
+static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint64_t seed, uint64_t first, uint64_t n,
+                       double *d_triple, hipStream_t st, Real *out)
+{
+    if (int rc = begin_call(c, st)) return rc;
+    CvaArgs<Real> args;
+    if (int rc = cva_table_ready<Real>(c, v, st, args)) return rc;
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;
     int total = 0, slot = 0;
@@ -1106,7 +1162,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
-        t.slot_base = (uint32_t)slot;
+        t.slot_base = t.ticket_base = (uint32_t)slot;
         if (c->antithetic)
             launch_sim(prof, cva_kernel<Real, true>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
         else
@@ -1115,6 +1171,105 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         done += s.count;
     }
     return finish_call(c, t, total, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// Greeks of the basket call and of the CVA: secondary kernels, plain estimator, synchronous
+// ---------------------------------------------------------------------------------------
+template <class Real>
+static int basket_greeks_run(mc_context *c, const typename BasketIn<Real>::type *o, uint64_t seed, uint64_t first, uint64_t n,
+                             mc_result *price, mc_result *delta, mc_result *vega)
+{
+    if (int rc = check_common(c, o, first, n, price)) return rc;
+    if (!delta || !vega)
+        return fail(MC_ERR_INVALID, "basket greeks: NULL output array");
+    if (o->n < 1 || o->n > MC_MAX_ASSETS_GENERIC)
+        return fail(MC_ERR_UNSUPPORTED, "basket: n=%d outside the supported range 1..%d", o->n, MC_MAX_ASSETS_GENERIC);
+    if (!o->s || !o->v || !o->p || !o->d || !o->w)
+        return fail(MC_ERR_INVALID, "basket: NULL array");
+    if (!(o->t >= 0) || !std::isfinite((double)o->r) || !std::isfinite((double)o->k))
+        return fail(MC_ERR_INVALID, "basket: need t>=0 and finite r, k");
+    if (c->antithetic || c->control)
+        return fail(MC_ERR_UNSUPPORTED, "greeks: only the plain estimator is implemented");
+    const int na = o->n;
+    const double sqrt_t = std::sqrt((double)o->t);
+    // table: L[n*n] | d | mu | v | w | s | 1/s | v t      (the reference's unfolded constants, dp/MonteCarloKernel.cu:74-101)
+    std::vector<Real> host((size_t)na * na + 7 * (size_t)na, (Real)0);
+    Real *L = host.data(), *d = L + (size_t)na * na, *mu = d + na, *v = mu + na, *w = v + na, *s0 = w + na, *inv_s = s0 + na, *vt = inv_s + na;
+    for (int a = 0; a < na; ++a) {
+        if (!finite_pos((double)o->s[a]))
+            return fail(MC_ERR_INVALID, "basket greeks: need s[a] > 0 (delta is taken with respect to it)");
+        const double va = (double)o->v[a];
+        double bound = std::fabs(((double)o->r - 0.5 * va * va) * (double)o->t + va * sqrt_t * (double)o->d[a]);
+        for (int b = 0; b <= a; ++b) {
+            L[(size_t)a * na + b] = o->p[a * na + b];
+            bound += std::fabs(va * sqrt_t * (double)o->p[a * na + b]) * Z_MAX_F64;
+        }
+        if (!exponent_in_range(sizeof(Real) == 4 ? bound * 8 : bound))   // fp32: e^88 is the limit
+            return fail(MC_ERR_INVALID, "basket: asset %d's drift and volatility put its terminal price outside the range of the simulation type", a);
+        d[a] = o->d[a];
+        mu[a] = (Real)(((double)o->r - 0.5 * va * va) * (double)o->t);
+        v[a] = o->v[a], w[a] = o->w[a], s0[a] = o->s[a];
+        inv_s[a] = (Real)(1.0 / (double)o->s[a]);
+        vt[a] = (Real)(va * (double)o->t);
+    }
+    const size_t bytes = host.size() * sizeof(Real);
+    std::vector<char> key(bytes + 2);
+    memcpy(key.data(), host.data(), bytes);
+    key[bytes] = (char)sizeof(Real);
+    key[bytes + 1] = 'G';
+    if (int rc = begin_call(c, c->stream)) return rc;
+    if (int rc = upload_table(c, c->stream, key, host.data(), bytes)) return rc;
+    BasketGreeks<Real> k;
+    k.consts = (const Real *)c->d_table;
+    k.n = na;
+    k.strike = o->k;
+    k.sqrt_t = (Real)sqrt_t;
+    constexpr int NPB = npb<Real>::value;
+    const size_t lds = (size_t)((na + NPB - 1) / NPB * NPB) * GROUP * sizeof(Real);
+    HIPCHK(hipFuncSetAttribute((const void *)basket_greeks_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    std::vector<mc_result *> out(1 + 2 * (size_t)na);
+    out[0] = price;
+    for (int a = 0; a < na; ++a)
+        out[1 + a] = delta + a, out[1 + na + a] = vega + a;
+    return planes_run(c, 1 + 2 * na, na, first, n, n, std::exp(-(double)o->r * (double)o->t), out.data(),
+                      [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
+                          hipLaunchKernelGGL(basket_greeks_kernel<Real>, dim3(g, na), dim3(GROUP), lds, st, t, k, make_work(seed, s, 0, 0));
+                      });
+}
+extern "C" int mc_basket_greeks_run_f32(mc_context *c, const mc_basket_f32 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                        mc_result *price, mc_result *delta, mc_result *vega)
+{
+    return basket_greeks_run<float>(c, o, seed, first, n, price, delta, vega);
+}
+extern "C" int mc_basket_greeks_run_f64(mc_context *c, const mc_basket_f64 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                        mc_result *price, mc_result *delta, mc_result *vega)
+{
+    return basket_greeks_run<double>(c, o, seed, first, n, price, delta, vega);
+}
+
+template <class Real>
+static int cva_greeks_run(mc_context *c, const typename CvaIn<Real>::type *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
+{
+    if (int rc = check_common(c, v, first, n, out)) return rc;
+    if (c->antithetic)
+        return fail(MC_ERR_UNSUPPORTED, "greeks: only the plain estimator is implemented");
+    if (int rc = begin_call(c, c->stream)) return rc;
+    CvaArgs<Real> args;
+    if (int rc = cva_table_ready<Real>(c, v, c->stream, args)) return rc;
+    mc_result *r[2] = {&out->cva, &out->delta};
+    const Real inv_spot = (Real)(1.0 / (double)v->option.s);
+    return planes_run(c, 2, 1, first, n, n, 1.0, r, [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
+        cva_greeks_kernel<Real><<<g, GROUP, 0, st>>>(t, args, make_work(seed, s, 0, 0), inv_spot);
+    });
+}
+extern "C" int mc_cva_greeks_run_f32(mc_context *c, const mc_cva_f32 *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
+{
+    return cva_greeks_run<float>(c, v, seed, first, n, out);
+}
+extern "C" int mc_cva_greeks_run_f64(mc_context *c, const mc_cva_f64 *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
+{
+    return cva_greeks_run<double>(c, v, seed, first, n, out);
 }
 
 // ---------------------------------------------------------------------------------------

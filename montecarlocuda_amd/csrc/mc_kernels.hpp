@@ -232,13 +232,16 @@ __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Tail /* fir
 // Three (sum, sum2) pairs per workgroup, one per plane of the call's pair buffer: q = price, delta, vega.
 // Always honours the path window (no separate hot variant: a secondary kernel).
 // =========================================================================================
-struct GreeksF32 { float drift2, vol2, spot, strike, sqrt_t, sigma_t; };   // exponent in log2 units
-struct GreeksF64 { double drift, vol, spot, strike, sqrt_t, sigma_t; };
+// lr_delta = 1 / (S sigma sqrt T), inv_sigma = 1 / sigma: the scores of the likelihood-ratio estimators (LR = true):
+//     delta = payoff z / (S sigma sqrt T),   vega = payoff ((z^2 - 1) / sigma - z sqrt T)
+// (differentiate the lognormal density instead of the payoff: no indicator, so they also serve payoffs with jumps).
+struct GreeksF32 { float drift2, vol2, spot, strike, sqrt_t, sigma_t, lr_delta, inv_sigma; };   // exponent in log2 units
+struct GreeksF64 { double drift, vol, spot, strike, sqrt_t, sigma_t, lr_delta, inv_sigma; };
 
 __device__ __forceinline__ float greeks_spot(const GreeksF32 &o, float z) { return o.spot * __builtin_amdgcn_exp2f(__builtin_fmaf(o.vol2, z, o.drift2)); }
 __device__ __forceinline__ double greeks_spot(const GreeksF64 &o, double z) { return o.spot * exp_f64(__builtin_fma(o.vol, z, o.drift)); }
 
-template <class Opt, class Real>
+template <class Opt, class Real, bool LR>
 __global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w)
 {
     stage_tables<Real>();
@@ -255,9 +258,16 @@ __global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Tail /* fir
             if (path >= w.first_path && path < w.end_path) {
                 const Real st = greeks_spot(o, z[j]);
                 const bool itm = st > o.strike;
-                const double pay = itm ? (double)(st - o.strike) : 0.0;
-                const double dl = itm ? (double)(st / o.spot) : 0.0;
-                const double vg = itm ? (double)(st * (o.sqrt_t * z[j] - o.sigma_t)) : 0.0;
+                const Real payoff = itm ? st - o.strike : (Real)0;
+                const double pay = (double)payoff;
+                double dl, vg;
+                if (LR) {
+                    dl = (double)(payoff * z[j] * o.lr_delta);
+                    vg = (double)(payoff * ((z[j] * z[j] - (Real)1) * o.inv_sigma - z[j] * o.sqrt_t));
+                } else {
+                    dl = itm ? (double)(st / o.spot) : 0.0;
+                    vg = itm ? (double)(st * (o.sqrt_t * z[j] - o.sigma_t)) : 0.0;
+                }
                 acc[0] += pay, acc[1] = __builtin_fma(pay, pay, acc[1]);
                 acc[2] += dl, acc[3] = __builtin_fma(dl, dl, acc[3]);
                 acc[4] += vg, acc[5] = __builtin_fma(vg, vg, acc[5]);
@@ -1191,6 +1201,153 @@ __global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument
     }
     group_sum2(acc_s, acc_q);
     finish_group(acc_s, acc_q);
+}
+
+// =========================================================================================
+// Pathwise Greeks of the basket call (the reference prices only).  Per path, in the reference's own
+// (unfolded) device formulas dp/MonteCarloKernel.cu:74-101 on the pricing kernels' normals:
+//     bt_a = sum_{b<=a} L_ab g_b + d_a,   s_a = S_a exp(mu_a + v_a bt_a sqrt T),   B = sum_a w_a s_a,   I = [B > K]
+//     payoff = I (B - K),   d payoff / d S_a = I w_a s_a / S_a,   d payoff / d v_a = I w_a s_a (bt_a sqrt T - v_a T)
+// A secondary kernel: generic in n (normals in the lane's LDS column, constants through scalar loads), and the
+// grid's y index picks the asset whose two derivatives the workgroup accumulates -- the path is re-simulated once per
+// asset, which keeps the per-lane state at three (sum, sum2) pairs whatever n is.  Planes of the pair buffer:
+// 0 = price (published by y = 0 only), 1 + a = delta_a, 1 + n + a = vega_a.
+// Constant table (Real): L[n*n] row-major | d[n] | mu[n] | v[n] | w[n] | s[n] | inv_s[n] | vt[n] (= v_a T).
+// =========================================================================================
+template <class Real>
+struct BasketGreeks {
+    const Real *consts;
+    int n;
+    Real strike, sqrt_t;
+};
+
+__device__ __forceinline__ float exp_nat(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ double exp_nat(double x) { return exp_f64(x); }
+
+template <class Real>
+__global__ __launch_bounds__(GROUP) void basket_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketGreeks<Real> o, const Work w)
+{
+    stage_tables<Real>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
+    constexpr int NPB = npb<Real>::value;
+    const int n = o.n, nblk = (n + NPB - 1) / NPB, mine = blockIdx.y;
+    typedef const __attribute__((address_space(4))) Real *cptr;
+    const cptr L = (cptr)o.consts, d = L + n * n, mu = d + n, v = mu + n, wt = v + n, s0 = wt + n, inv_s = s0 + n, vt = inv_s + n;
+    const uint32_t stride = gridDim.x * GROUP;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
+        for (int b = 0; b < nblk; ++b) {
+            Real z[NPB];
+            block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
+#pragma unroll
+            for (int j = 0; j < NPB; ++j)
+                g[(b * NPB + j) * GROUP] = z[j];
+        }
+        Real basket = 0, term_a = 0, bt_a = 0;
+        for (int a = 0; a < n; ++a) {
+            Real bt = 0;
+            for (int b = 0; b <= a; ++b)
+                bt = fma_r(L[a * n + b], g[b * GROUP], bt);
+            bt += d[a];
+            const Real term = s0[a] * exp_nat(fma_r(v[a] * bt, o.sqrt_t, mu[a])) * wt[a];
+            basket += term;
+            if (a == mine) {   // workgroup-uniform
+                term_a = term;
+                bt_a = bt;
+            }
+        }
+        const bool itm = basket > o.strike;
+        const double pay = itm ? (double)(basket - o.strike) : 0.0;
+        const double dl = itm ? (double)(term_a * inv_s[mine]) : 0.0;
+        const double vg = itm ? (double)(term_a * (bt_a * o.sqrt_t - vt[mine])) : 0.0;
+        acc[0] += pay, acc[1] = __builtin_fma(pay, pay, acc[1]);
+        acc[2] += dl, acc[3] = __builtin_fma(dl, dl, acc[3]);
+        acc[4] += vg, acc[5] = __builtin_fma(vg, vg, acc[5]);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        group_sum2(acc[2 * q], acc[2 * q + 1]);
+    const tail_ptr t = late_tail(acc[0]);
+    if (mine == 0)
+        publish_pair(t, 0, acc[0], acc[1]);
+    publish_pair(t, 1 + mine, acc[2], acc[3]);
+    publish_pair(t, 1 + n + mine, acc[4], acc[5]);
+    arrive_and_finish(t);
+}
+
+// =========================================================================================
+// CVA with its pathwise delta.  CVA = LGD sum_j dp_j C(S_j, tau_j) and S_j is proportional to S_0, so
+//     d CVA / d S_0 = LGD sum_j dp_j Delta_j S_j / S_0,   Delta_j = cnd(d1_j)   (I[S_j > K] on an intrinsic-value date)
+// and S_j cnd(d1_j) is the first term of the exposure the pricing kernel computes anyway.  Plain estimator, one date
+// at a time (a secondary kernel); planes of the pair buffer: 0 = CVA, 1 = delta.
+// =========================================================================================
+__device__ __forceinline__ void bs_exposure_delta(float ln2_spot, float W, const CvaStep<float> &st, float &ee, float &s_delta)
+{
+    const float spot = __builtin_amdgcn_exp2f(ln2_spot);
+    const float d1 = __builtin_fmaf(W, st.g, st.e1), d2 = __builtin_fmaf(W, st.g, st.e2);
+    const float A = 0.3989422804014327f * __builtin_amdgcn_exp2f(__builtin_fmaf(d1 * -0.72134752044448170f, d1, ln2_spot));
+    const float k1 = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2316419f, fabsf(d1), 1.0f));
+    const float k2 = __builtin_amdgcn_rcpf(__builtin_fmaf(0.2316419f, fabsf(d2), 1.0f));
+    const float t1 = A * (k1 * (0.31938153f + k1 * (-0.356563782f + k1 * (1.781477937f + k1 * (-1.821255978f + k1 * 1.330274429f)))));
+    const float t2 = A * (k2 * (0.31938153f + k2 * (-0.356563782f + k2 * (1.781477937f + k2 * (-1.821255978f + k2 * 1.330274429f)))));
+    s_delta = d1 > 0 ? spot - t1 : t1;            // S cnd(d1)
+    ee = s_delta - (d2 > 0 ? st.disc - t2 : t2);  // - K e^{-r tau} cnd(d2)
+}
+__device__ __forceinline__ void bs_exposure_delta(double ln_spot, double W, const CvaStep<double> &st, double &ee, double &s_delta)
+{
+    const double spot = exp_f64(ln_spot);
+    const double d1 = __builtin_fma(W, st.g, st.e1), d2 = __builtin_fma(W, st.g, st.e2);
+    const double A = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1, d1, ln_spot), -800.0));
+    double k1, k2;
+    recip2_pos(__builtin_fma(0.2316419, fabs(d1), 1.0), __builtin_fma(0.2316419, fabs(d2), 1.0), k1, k2);
+    const double t1 = A * hastings_poly(k1), t2 = A * hastings_poly(k2);
+    s_delta = d1 > 0 ? spot - t1 : t1;
+    ee = s_delta - (d2 > 0 ? st.disc - t2 : t2);
+}
+
+template <class Real>
+__global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real inv_spot)
+{
+    stage_tables<Real>();
+    constexpr int NPB = npb<Real>::value;
+    const uint32_t stride = gridDim.x * GROUP;
+    const int n_dates = o.n_bs + o.last_intrinsic;
+    double acc[4] = {0, 0, 0, 0};
+    for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
+        Real W = 0, cva = 0, delta = 0, z[NPB];
+        for (int j = 0; j < n_dates; ++j) {   // wave-uniform: table rows through scalar loads
+            if (j % NPB == 0)
+                block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)(j / NPB), 3u /*MC_DOMAIN_CVA*/, w.seed_lo, w.seed_hi, z);
+            const CvaStep<Real> st = o.steps[j];
+            Real zz = z[0];
+#pragma unroll
+            for (int q = 1; q < NPB; ++q)
+                zz = (j % NPB == q) ? z[q] : zz;
+            W += zz;
+            const Real ln_spot = fma_r(W, o.bx, st.xk);
+            Real ee, sd;
+            if (j < o.n_bs) {
+                bs_exposure_delta(ln_spot, W, st, ee, sd);
+            } else {   // residual maturity exactly 0: intrinsic value, derivative I[S > K] S
+                const Real spot = exp_model(ln_spot);
+                const bool itm = spot > o.strike;
+                ee = itm ? spot - o.strike : (Real)0;
+                sd = itm ? spot : (Real)0;
+            }
+            cva = fma_r(st.dp, ee, cva);
+            delta = fma_r(st.dp, sd, delta);
+        }
+        const double c = (double)(cva * o.lgd), dl = (double)(delta * o.lgd * inv_spot);
+        acc[0] += c, acc[1] = __builtin_fma(c, c, acc[1]);
+        acc[2] += dl, acc[3] = __builtin_fma(dl, dl, acc[3]);
+    }
+    group_sum2(acc[0], acc[1]);
+    group_sum2(acc[2], acc[3]);
+    const tail_ptr t = late_tail(acc[0]);
+    publish_pair(t, 0, acc[0], acc[1]);
+    publish_pair(t, 1, acc[2], acc[3]);
+    arrive_and_finish(t);
 }
 
 // =========================================================================================

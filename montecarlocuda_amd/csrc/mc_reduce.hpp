@@ -102,9 +102,13 @@ struct Tail {
     uint32_t *tickets;       // TICKET_WORDS words, all zero between calls
     double *triple;          // 3 doubles per plane: {scale1 sum, scale2 sum2, n_paths}
     double scale1, scale2, n_paths;
-    uint32_t slot_base;      // index of this launch's first pair
-    uint32_t total;          // pairs of the whole call; 0 = two-launch form (plain store, finish_kernel follows)
+    uint32_t slot_base;      // index (within a plane) of this launch's first pair; workgroup (x, y) owns pair slot_base + x
+    uint32_t pairs;          // pairs per plane of the whole call (what the last arriver adds up)
     uint32_t planes, plane_stride;
+    // arrivals: every workgroup of every launch of the call draws one ticket; workgroup (x, y) of this launch is
+    // arrival number ticket_base + y * gridDim.x + x of `total`.  One-dimensional grids: ticket_base == slot_base,
+    // total == pairs.  total == 0 selects the two-launch form (plain store, finish_kernel follows).
+    uint32_t ticket_base, total;
 };
 
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
@@ -147,7 +151,7 @@ __device__ __forceinline__ void arrive_and_finish(tail_ptr t)
     __shared__ uint32_t lds_is_last;
     if (threadIdx.x == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the pair stores have left before the ticket is drawn
-        const uint32_t idx = t->slot_base + blockIdx.x;
+        const uint32_t idx = t->ticket_base + blockIdx.y * gridDim.x + blockIdx.x;
         const uint32_t shard = idx % TICKET_SHARDS;
         const uint32_t in_shard = (t->total - shard + TICKET_SHARDS - 1) / TICKET_SHARDS;   // indices < total in this shard
         uint32_t last = 0;
@@ -168,7 +172,7 @@ __device__ __forceinline__ void arrive_and_finish(tail_ptr t)
     for (uint32_t plane = 0; plane < t->planes; ++plane) {
         const double2 *pairs = t->partials + (size_t)plane * t->plane_stride;
         double s = 0.0, q = 0.0;
-        for (uint32_t i = threadIdx.x; i < t->total; i += blockDim.x) {
+        for (uint32_t i = threadIdx.x; i < t->pairs; i += blockDim.x) {
             const double2 p = pairs[i];
             s += p.x;
             q += p.y;

@@ -177,6 +177,29 @@ class Engine:
                                                                     first_path, n_paths, C.byref(g)))
         return _estimate(g.price), _estimate(g.delta), _estimate(g.vega)
 
+    def vanilla_greeks_lr(self, opt, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
+        """(price, delta, vega) Estimates by the likelihood-ratio method (score of the density x payoff)."""
+        g = _lib.Greeks()
+        check(getattr(lib(), f"mc_vanilla_greeks_lr_run_{precision}")(self._ctx, C.byref(_as_option(precision, opt)), seed,
+                                                                       first_path, n_paths, C.byref(g)))
+        return _estimate(g.price), _estimate(g.delta), _estimate(g.vega)
+
+    def basket_greeks(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
+        """(price, [delta per asset], [vega per asset]) Estimates (pathwise derivatives)."""
+        h = _BasketHolder(precision, b)
+        price = _lib.Result()
+        delta, vega = (_lib.Result * h.n)(), (_lib.Result * h.n)()
+        check(getattr(lib(), f"mc_basket_greeks_run_{precision}")(self._ctx, C.byref(h.struct), seed, first_path, n_paths,
+                                                                   C.byref(price), delta, vega))
+        return _estimate(price), [_estimate(x) for x in delta], [_estimate(x) for x in vega]
+
+    def cva_greeks(self, c, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
+        """(cva, delta) Estimates: the CVA and its pathwise derivative with respect to the spot."""
+        g = _lib.CvaGreeks()
+        check(getattr(lib(), f"mc_cva_greeks_run_{precision}")(self._ctx, C.byref(_as_cva(precision, c)), seed, first_path,
+                                                                n_paths, C.byref(g)))
+        return _estimate(g.cva), _estimate(g.delta)
+
     def basket(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:
         h = _BasketHolder(precision, b)
         return self._run("basket", precision, h.struct, seed, first_path, n_paths)

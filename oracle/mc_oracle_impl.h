@@ -353,6 +353,77 @@ void FN(orc_dev_vanilla_greeks)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t
         FN(dev_finish)(acc[2 * q], acc[2 * q + 1], n_paths, exp(-(double)r * (double)t), out + q);
 }
 
+/* Likelihood-ratio Greeks of the vanilla call (not in the reference): the score of the lognormal density
+ * times the payoff.  delta = payoff z / (S sigma sqrt T),  vega = payoff ((z^2 - 1) / sigma - z sqrt T).
+ * out[0..2] = price, delta, vega (each discounted). */
+void FN(orc_dev_vanilla_greeks_lr)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed, uint64_t first_path,
+                                   uint64_t n_paths, orc_result *out)
+{
+    const REAL drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)t);
+    const REAL vol = (REAL)((double)v * sqrt((double)t));
+    const REAL sqrt_t = (REAL)sqrt((double)t);
+    const REAL lr_delta = (REAL)(1.0 / ((double)s * (double)v * sqrt((double)t))), inv_sigma = (REAL)(1.0 / (double)v);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    REAL z[ORC_NPB];
+    uint64_t have = (uint64_t)-1;
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t p = first_path + i, unit = p / ORC_NPB;
+        if (unit != have) {
+            FN(orc_dev_normals)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
+            have = unit;
+        }
+        REAL zz = z[p % ORC_NPB];
+        REAL st = s * EXP_R(drift + vol * zz);
+        REAL payoff = st > k ? st - k : 0;
+        double pay = (double)payoff, dl = (double)(payoff * zz * lr_delta);
+        double vg = (double)(payoff * ((zz * zz - (REAL)1) * inv_sigma - zz * sqrt_t));
+        acc[0] += pay, acc[1] += pay * pay, acc[2] += dl, acc[3] += dl * dl, acc[4] += vg, acc[5] += vg * vg;
+    }
+    for (int q = 0; q < 3; q++)
+        FN(dev_finish)(acc[2 * q], acc[2 * q + 1], n_paths, exp(-(double)r * (double)t), out + q);
+}
+
+/* Pathwise Greeks of the basket call, reference device formulas dp/MonteCarloKernel.cu:74-101:
+ * B = sum_a w_a s_a, I = [B > K]; delta_a = I w_a s_a / S_a, vega_a = I w_a s_a (bt_a sqrt T - v_a T).
+ * out[0] = price, out[1 + a] = delta_a, out[1 + n + a] = vega_a (each discounted). */
+void FN(orc_dev_basket_greeks)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d, const REAL *w, REAL k,
+                               REAL t, REAL r, uint64_t seed, uint64_t first_path, uint64_t n_paths, orc_result *out)
+{
+    int nblk = (n + ORC_NPB - 1) / ORC_NPB;
+    REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)(nblk * ORC_NPB));
+    REAL *term = (REAL *)malloc(sizeof(REAL) * (size_t)n), *bts = (REAL *)malloc(sizeof(REAL) * (size_t)n);
+    double *acc = (double *)calloc((size_t)(2 * (1 + 2 * n)), sizeof(double));
+    const REAL sqrt_t = (REAL)sqrt((double)t);
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t path = first_path + i;
+        for (int b = 0; b < nblk; b++)
+            FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
+        REAL basket = 0;
+        for (int a = 0; a < n; a++) {
+            REAL bt = 0;
+            for (int b = 0; b <= a; b++)
+                bt += p[a * n + b] * g[b];
+            bt += d[a];
+            REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
+            term[a] = s[a] * EXP_R(mu + v[a] * bt * sqrt_t) * w[a];
+            bts[a] = bt;
+            basket += term[a];
+        }
+        int itm = basket > k;
+        double pay = itm ? (double)(basket - k) : 0.0;
+        acc[0] += pay, acc[1] += pay * pay;
+        for (int a = 0; a < n; a++) {
+            double dl = itm ? (double)(term[a] * (REAL)(1.0 / (double)s[a])) : 0.0;
+            double vg = itm ? (double)(term[a] * (bts[a] * sqrt_t - (REAL)((double)v[a] * (double)t))) : 0.0;
+            acc[2 * (1 + a)] += dl, acc[2 * (1 + a) + 1] += dl * dl;
+            acc[2 * (1 + n + a)] += vg, acc[2 * (1 + n + a) + 1] += vg * vg;
+        }
+    }
+    for (int q = 0; q < 1 + 2 * n; q++)
+        FN(dev_finish)(acc[2 * q], acc[2 * q + 1], n_paths, exp(-(double)r * (double)t), out + q);
+    free(g), free(term), free(bts), free(acc);
+}
+
 /* Closed-form mean of the geometric-basket control (not in the reference):
  *   G = W prod_a S_a(T)^(w_a / W),  W = sum_a w_a > 0,  is lognormal: ln G ~ N(m, sd^2) with
  *   m = ln W + sum_a wh_a (ln S_a + (r - v_a^2/2) T + v_a sqrt(T) d_a),  wh = w / W,
@@ -495,6 +566,51 @@ void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL
         sum2 += (double)acc * (double)acc;
     }
     FN(dev_finish)(sum, sum2, n_paths, 1.0, out);
+}
+
+/* CVA with its pathwise delta: the loop of orc_dev_cva (plain estimator) carrying
+ * d CVA / d S_0 = LGD sum_j dp_j Delta_j S_j / S_0, Delta_j = cnd(d1_j) of the reference's closed form
+ * (dp/MonteCarloKernel.cu:110-129), I[S_j > K] on a date with residual maturity exactly 0.  out[0] = CVA, out[1] = delta. */
+void FN(orc_dev_cva_greeks)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid, uint64_t seed,
+                            uint64_t first_path, uint64_t n_paths, orc_result *out)
+{
+    const REAL dt = t0 / n_grid;
+    const REAL step_drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)dt);
+    const REAL step_vol = (REAL)((double)v * sqrt((double)dt));
+    double acc[4] = {0, 0, 0, 0};
+    REAL z[ORC_NPB];
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t path = first_path + i;
+        REAL spot = s0, ttm = t0, cva = 0, delta = 0;
+        for (int j = 1; j <= n_grid; j++) {
+            double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
+            REAL dpd = (REAL)(-exp(-(double)defint * t_prev) * expm1(-(double)defint * (t_now - t_prev)));
+            ttm -= dt;
+            if (!(ttm >= 0))
+                continue;
+            int idx = j - 1;
+            if (idx % ORC_NPB == 0)
+                FN(orc_dev_normals)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
+            spot = spot * EXP_R(step_drift + step_vol * z[idx % ORC_NPB]);
+            REAL ee, sd;
+            if (ttm == 0) {
+                ee = spot > k ? spot - k : 0;
+                sd = spot > k ? spot : 0;
+            } else {
+                REAL sqrt_t = SQRT_R(ttm);
+                double num = (double)LOG_R(spot / k) + ((double)r + 0.5 * (double)v * (double)v) * (double)ttm;
+                REAL d1 = (REAL)(num / (double)(v * sqrt_t));
+                ee = FN(orc_bs_call)(spot, k, r, v, ttm);
+                sd = spot * FN(orc_cnd)(d1);
+            }
+            cva += dpd * ee;
+            delta += dpd * sd;
+        }
+        double c = (double)(cva * lgd), dl = (double)(delta * lgd * (REAL)(1.0 / (double)s0));
+        acc[0] += c, acc[1] += c * c, acc[2] += dl, acc[3] += dl * dl;
+    }
+    FN(dev_finish)(acc[0], acc[1], n_paths, 1.0, out);
+    FN(dev_finish)(acc[2], acc[3], n_paths, 1.0, out + 1);
 }
 
 #undef FN

@@ -226,6 +226,40 @@ def dev_vanilla_greeks(X, opt, seed, first, n):
     return [x.as_dict() for x in r]
 
 
+def dev_vanilla_greeks_lr(X, opt, seed, first, n):
+    """(price, delta, vega) result dicts of the likelihood-ratio twin."""
+    r = (OrcResult * 3)()
+    f = getattr(lib(), f"orc_dev_vanilla_greeks_lr_{X}")
+    f.argtypes = [CT[X]] * 5 + [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcResult * 3)]
+    f.restype = None
+    f(opt["s"], opt["k"], opt["r"], opt["v"], opt["t"], seed, first, n, C.byref(r))
+    return [x.as_dict() for x in r]
+
+
+def dev_basket_greeks(X, b, seed, first, n):
+    """(price, [delta_a], [vega_a]) result dicts of the pathwise basket-Greeks twin."""
+    nn = len(b["s"])
+    keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
+    r = (OrcResult * (1 + 2 * nn))()
+    f = getattr(lib(), f"orc_dev_basket_greeks_{X}")
+    RP = C.POINTER(CT[X])
+    f.argtypes = [C.c_int, RP, RP, RP, RP, RP, CT[X], CT[X], CT[X], C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
+    f.restype = None
+    f(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], seed, first, n, C.cast(r, C.c_void_p))
+    out = [x.as_dict() for x in r]
+    return out[0], out[1:1 + nn], out[1 + nn:]
+
+
+def dev_cva_greeks(X, c, seed, first, n):
+    """(cva, delta) result dicts of the CVA-delta twin."""
+    r = (OrcResult * 2)()
+    f = getattr(lib(), f"orc_dev_cva_greeks_{X}")
+    f.argtypes = [CT[X]] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcResult * 2)]
+    f.restype = None
+    f(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"], c["lgd"], c["n_grid"], seed, first, n, C.byref(r))
+    return [x.as_dict() for x in r]
+
+
 def basket_control_mean(X, b):
     keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
     return getattr(lib(), f"orc_basket_control_mean_{X}")(len(b["s"]), *[p for _, p in keep], b["k"], b["t"], b["r"])
