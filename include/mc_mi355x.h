@@ -120,6 +120,23 @@ int mc_context_set_antithetic(mc_context *ctx, int on);
  * variance reduction on the BASELINE baskets: ~150x (x2.5 more with antithetic). */
 int mc_context_set_control_variate(mc_context *ctx, int on);
 
+/* Generator switch.  MC_RNG_PHILOX (default): Philox4x32-10, counter-based -- a path's normals depend
+ * only on (seed, global path index).  MC_RNG_XORWOW: the reference's generator (cuRAND XORWOW, dp/MonteCarloKernel.cu:
+ * 285-290 curand_init, :68,78,250 curand_normal), hand-written for gfx950, with rocRAND's seeding and subsequence
+ * layout: lane l of a launch starts at rocrand_init(seed, subsequence_base + l, 0) -- one sequence per lane, as the
+ * reference keeps one curandState per thread -- and draws four words per block of normals.  Word for word rocRAND's
+ * sequence (tests); cuRAND 7.5's own seeding is not in the reference tree, so the reference's exact stream stays
+ * "parity unpinned".  Consequences of a per-lane stream: the sample depends on (seed, subsequence_base, grid size,
+ * position in the range) instead of the global path index, first_path only places the range; a call must fit one
+ * launch (<= 2^31 units); ranks of a multi-GPU job need disjoint subsequence bases (mc_multi_* sets them); the generic
+ * kernels run (about half the Philox paths' speed); Greeks are Philox-only.  Subsequence numbers stay below 2^48. */
+enum { MC_RNG_PHILOX = 0, MC_RNG_XORWOW = 1 };
+int mc_context_set_generator(mc_context *ctx, int generator, uint64_t subsequence_base);
+/* The generator alone (tests): words_each consecutive 32-bit outputs of each of the XORWOW subsequences
+ * first_subsequence .. first_subsequence + n_subsequences - 1 for `seed`, subsequence-major, to the HOST array h_out. */
+int mc_xorwow_words(mc_context *ctx, uint64_t seed, uint64_t first_subsequence, uint32_t n_subsequences,
+                    uint32_t words_each, uint32_t *h_out);
+
 /* Where a call's per-workgroup (sum, sum2) pairs are added up (replaces the reference's D2H copy and host loop
  * over blocks, dp/MonteCarloKernel.cu:405,416-419).  fused != 0 (default): inside the simulation kernel, by the
  * last workgroup to arrive -- one launch per call.  fused == 0: by a second, one-workgroup launch (the A/B

@@ -52,6 +52,9 @@ mc_context *mc_multi_context(mc_multi *m, int i);
 /* estimator switches, applied to every device (mc_context_set_antithetic / _control_variate) */
 int mc_multi_set_antithetic(mc_multi *m, int on);
 int mc_multi_set_control_variate(mc_multi *m, int on);
+/* generator of every device (mc_context_set_generator); under MC_RNG_XORWOW device g's lanes run the subsequences
+ * subsequence_base + (lanes of devices 0..g-1) + lane, so that no two lanes of the job share a sequence */
+int mc_multi_set_generator(mc_multi *m, int generator, uint64_t subsequence_base);
 /* MC_REDUCE_RCCL (default; MC_MULTI_REDUCE=host in the environment selects the other) or MC_REDUCE_HOST */
 int mc_multi_set_reduce(mc_multi *m, int mode);
 /* Text of the last failure of an mc_multi_* call on this thread ("" if none). */

@@ -20,6 +20,7 @@
  * Environment: MC_DEVICE (default 0), MC_SEED (default MC_DEFAULT_SEED), MC_VERBOSE,
  * MC_DEVICES="0,1,2,3" or "all" (every call is sharded over these GPUs of the node and closed by one RCCL
  * all-reduce of the triple: include/mc_multi.h; libmc_multi.so -- and with it RCCL -- is loaded only then),
+ * MC_RNG=xorwow (the reference's generator instead of Philox: mc_context_set_generator),
  * MC_ANTITHETIC=1 (antithetic-variates estimator instead of the reference's plain one),
  * MC_CONTROL_VARIATE=1 (dev_basketOpt only: geometric-basket control variate).
  */
@@ -103,6 +104,7 @@ static mc_multi *multi(void)
     int (*create)(const int *, int, int, mc_multi **) = (int (*)(const int *, int, int, mc_multi **))multi_symbol(lib, "mc_multi_create");
     int (*set_anti)(mc_multi *, int) = (int (*)(mc_multi *, int))multi_symbol(lib, "mc_multi_set_antithetic");
     int (*set_cv)(mc_multi *, int) = (int (*)(mc_multi *, int))multi_symbol(lib, "mc_multi_set_control_variate");
+    int (*set_rng)(mc_multi *, int, uint64_t) = (int (*)(mc_multi *, int, uint64_t))multi_symbol(lib, "mc_multi_set_generator");
     multi_last_error = (const char *(*)(void))multi_symbol(lib, "mc_multi_last_error");
     multi_destroy = (void (*)(mc_multi *))multi_symbol(lib, "mc_multi_destroy");
 #ifdef MC_SINGLE_PRECISION
@@ -133,6 +135,8 @@ static mc_multi *multi(void)
         set_anti(g_multi, 1);
     if (getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE")))
         set_cv(g_multi, 1);
+    if (getenv("MC_RNG") && !strcmp(getenv("MC_RNG"), "xorwow"))
+        set_rng(g_multi, MC_RNG_XORWOW, 0);
     atexit(drop_multi);
     return g_multi;
 }
@@ -153,6 +157,8 @@ static mc_context *context(void)
             mc_context_set_antithetic(g_ctx, 1);
         if (getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE")))
             mc_context_set_control_variate(g_ctx, 1);
+        if (getenv("MC_RNG") && !strcmp(getenv("MC_RNG"), "xorwow"))
+            mc_context_set_generator(g_ctx, MC_RNG_XORWOW, 0);
         atexit(drop_context);
     }
     return g_ctx;

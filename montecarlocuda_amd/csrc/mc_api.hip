@@ -80,6 +80,13 @@ struct mc_context {
     hipEvent_t table_copied = nullptr;
     hipStream_t table_stream = nullptr;  // stream the cached table was uploaded on
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // generator: Philox (counter-based, stateless) or XORWOW (one sequence per lane: mc_rng.hpp RngXorwow)
+    int rng = MC_RNG_PHILOX;
+    uint64_t xorwow_base = 0;            // lane l of a launch runs subsequence xorwow_base + l
+    uint32_t *d_xorwow = nullptr;        // start states of lanes [0, blocks * GROUP): 6 words each
+    uint32_t *d_xorwow_jump = nullptr;   // jump matrices A^(2^67 2^i), i < XORWOW_JUMP_BITS
+    bool xorwow_valid = false;           // d_xorwow holds the states of (xorwow_seed, xorwow_state_base)
+    uint64_t xorwow_seed = 0, xorwow_state_base = 0;
     bool antithetic = false;      // estimator: plain (reference) or antithetic variates
     bool control = false;         // baskets: geometric-basket control variate
     // sampled device timing of the simulation kernels (mc_context_profile)
@@ -198,6 +205,8 @@ extern "C" void mc_context_destroy(mc_context *c)
         (void)hipStreamSynchronize(c->stream);
     (void)hipFree(c->partials);
     (void)hipFree(c->tickets);
+    (void)hipFree(c->d_xorwow);
+    (void)hipFree(c->d_xorwow_jump);
     if (c->last_use) (void)hipEventDestroy(c->last_use);
     (void)hipFree(c->d_triple);
     (void)hipFree(c->g_pairs);
@@ -375,6 +384,7 @@ static Work make_work(uint64_t seed, const Segment &s, uint64_t first_path, uint
     w.n_units = s.count;
     w.first_path = first_path;
     w.end_path = end_path;
+    w.xorwow = nullptr;
     return w;
 }
 
@@ -430,6 +440,132 @@ static int finish_call(mc_context *c, const Tail &t, int total, hipStream_t st)
                                                t.triple + 3 * q);
     HIPCHK(hipGetLastError());
     return MC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// XORWOW: jump matrices and per-lane start states (device side: mc_rng.hpp)
+// ---------------------------------------------------------------------------------------
+// The xorshift part of XORWOW is a linear map A on 160 bits; jumping a lane to its own subsequence (2^67 words further
+// per subsequence number, rocRAND's layout) is a product of matrices A^(2^67 2^i).  They are computed here, once per
+// process, by squaring the one-step matrix 67 + XORWOW_JUMP_BITS - 1 times (about 20 ms) -- nothing is taken from
+// rocRAND's precomputed tables; tests/test_rocrand_xcheck.py compares the resulting words with rocRAND's own engine.
+namespace {
+struct XwVec { uint32_t w[5]; };
+struct XwMat { XwVec col[160]; };   // column c = image of state bit c (word c / 32, bit c % 32)
+XwVec xw_step(XwVec v)
+{
+    const uint32_t t = v.w[0] ^ (v.w[0] >> 2);
+    return {{v.w[1], v.w[2], v.w[3], v.w[4], (v.w[4] ^ (v.w[4] << 4)) ^ (t ^ (t << 1))}};
+}
+XwVec xw_apply(const XwMat &m, const XwVec &v)
+{
+    XwVec r = {{0, 0, 0, 0, 0}};
+    for (int c = 0; c < 160; ++c)
+        if ((v.w[c >> 5] >> (c & 31)) & 1u)
+            for (int k = 0; k < 5; ++k)
+                r.w[k] ^= m.col[c].w[k];
+    return r;
+}
+void xw_square(XwMat &m)
+{
+    XwMat r;
+    for (int c = 0; c < 160; ++c)
+        r.col[c] = xw_apply(m, m.col[c]);
+    m = r;
+}
+const std::vector<uint32_t> &xorwow_jump_table()
+{
+    static const std::vector<uint32_t> table = [] {
+        XwMat a;
+        for (int c = 0; c < 160; ++c) {
+            XwVec e = {{0, 0, 0, 0, 0}};
+            e.w[c >> 5] = 1u << (c & 31);
+            a.col[c] = xw_step(e);
+        }
+        for (int i = 0; i < 67; ++i)
+            xw_square(a);
+        std::vector<uint32_t> t((size_t)XORWOW_JUMP_BITS * 160 * 5);
+        for (int i = 0; i < XORWOW_JUMP_BITS; ++i) {
+            for (int c = 0; c < 160; ++c)
+                for (int k = 0; k < 5; ++k)
+                    t[((size_t)i * 160 + c) * 5 + k] = a.col[c].w[k];
+            xw_square(a);
+        }
+        return t;
+    }();
+    return table;
+}
+}  // namespace
+
+// Start states of `lanes` XORWOW lanes for (seed, base) into `states` (device), enqueued on st.
+static int xorwow_fill(mc_context *c, uint64_t seed, uint64_t base, uint32_t lanes, uint32_t *states, hipStream_t st)
+{
+    if (base + lanes > (1ull << XORWOW_JUMP_BITS) || base + lanes < base)
+        return fail(MC_ERR_INVALID, "XORWOW: subsequence numbers must stay below 2^%d", XORWOW_JUMP_BITS);
+    if (!c->d_xorwow_jump) {
+        const std::vector<uint32_t> &t = xorwow_jump_table();
+        HIPCHK(hipMalloc(&c->d_xorwow_jump, t.size() * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(c->d_xorwow_jump, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    // rocRAND's seeding (rocrand_xorwow.h, xorwow_engine constructor): fixed start words scrambled with the seed halves
+    uint32_t x[5] = {123456789u, 362436069u, 521288629u, 88675123u, 5783321u}, d = 6615241u;
+    const uint32_t s0 = (uint32_t)seed ^ 0x2c7f967fu, s1 = (uint32_t)(seed >> 32) ^ 0xa03697cbu;
+    const uint32_t t0 = 1228688033u * s0, t1 = 2073658381u * s1;
+    x[0] += t0, x[1] ^= t0, x[2] += t1, x[3] ^= t1, x[4] += t0, d += t1 + t0;
+    xorwow_init_kernel<<<(lanes + 255) / 256, 256, 0, st>>>(c->d_xorwow_jump, x[0], x[1], x[2], x[3], x[4], d, base, lanes, states);
+    HIPCHK(hipGetLastError());
+    return MC_OK;
+}
+
+// The context's lane states for this call's seed (all blocks * GROUP lanes: a smaller grid uses a prefix)
+static int xorwow_ready(mc_context *c, uint64_t seed, hipStream_t st)
+{
+    const uint32_t lanes = (uint32_t)c->blocks * GROUP;
+    if (!c->d_xorwow)
+        HIPCHK(hipMalloc(&c->d_xorwow, sizeof(uint32_t) * 6 * (size_t)lanes));
+    if (!c->xorwow_valid || c->xorwow_seed != seed || c->xorwow_state_base != c->xorwow_base) {
+        if (int rc = xorwow_fill(c, seed, c->xorwow_base, lanes, c->d_xorwow, st)) return rc;
+        c->xorwow_valid = true, c->xorwow_seed = seed, c->xorwow_state_base = c->xorwow_base;
+    }
+    return MC_OK;
+}
+
+static int xorwow_one_segment(const std::vector<Segment> &segs)
+{
+    if (segs.size() != 1)
+        return fail(MC_ERR_UNSUPPORTED, "XORWOW generator: one call is one launch (at most 2^31 units, not across a multiple of "
+                                        "2^32): a lane's sequence restarts with every launch");
+    return MC_OK;
+}
+
+extern "C" int mc_context_set_generator(mc_context *c, int generator, uint64_t subsequence_base)
+{
+    if (!c || (generator != MC_RNG_PHILOX && generator != MC_RNG_XORWOW))
+        return fail(MC_ERR_INVALID, "mc_context_set_generator: bad argument");
+    c->rng = generator;
+    c->xorwow_base = subsequence_base;
+    return MC_OK;
+}
+
+extern "C" int mc_xorwow_words(mc_context *c, uint64_t seed, uint64_t first_subsequence, uint32_t n_subsequences,
+                               uint32_t words_each, uint32_t *h_out)
+{
+    if (!c || !h_out || n_subsequences == 0 || words_each == 0 || (uint64_t)n_subsequences * words_each > (1u << 26))
+        return fail(MC_ERR_INVALID, "mc_xorwow_words: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    uint32_t *states = nullptr, *out = nullptr;
+    HIPCHK(hipMalloc(&states, sizeof(uint32_t) * 6 * (size_t)n_subsequences));
+    HIPCHK(hipMalloc(&out, sizeof(uint32_t) * (size_t)n_subsequences * words_each));
+    int rc = xorwow_fill(c, seed, first_subsequence, n_subsequences, states, c->stream);
+    if (rc == MC_OK) {
+        xorwow_words_kernel<<<(n_subsequences + 255) / 256, 256, 0, c->stream>>>(states, n_subsequences, words_each, out);
+        if (hipMemcpyAsync(h_out, out, sizeof(uint32_t) * (size_t)n_subsequences * words_each, hipMemcpyDeviceToHost, c->stream) != hipSuccess ||
+            hipStreamSynchronize(c->stream) != hipSuccess)
+            rc = fail(MC_ERR_HIP, "mc_xorwow_words: copy failed");
+    }
+    (void)hipFree(states);
+    (void)hipFree(out);
+    return rc;
 }
 
 // NULL is the HIP null stream, as in every HIP API (the context's own stream: mc_context_stream)
@@ -585,6 +721,22 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     const auto masked = anti ? vanilla_masked_kernel<typename T::Opt, Real, true> : vanilla_masked_kernel<typename T::Opt, Real, false>;
     if (int rc = begin_call(c, st)) return rc;
     const uint64_t end = first + n;
+    if (c->rng == MC_RNG_XORWOW) {
+        // one masked launch over every unit the range touches (no separate edge launches: a lane's sequence would
+        // restart in them); the masked kernel is the generic form, the only one compiled for both generators
+        const auto xw = anti ? vanilla_masked_kernel<typename T::Opt, Real, true, RngXorwow> : vanilla_masked_kernel<typename T::Opt, Real, false, RngXorwow>;
+        std::vector<Segment> one;
+        const uint64_t u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
+        if (int rc = plan_segments(u0, u1 - u0, one)) return rc;
+        if (int rc = xorwow_one_segment(one)) return rc;
+        if (int rc = xorwow_ready(c, seed, st)) return rc;
+        Work w = make_work(seed, one[0], first, end);
+        w.xorwow = c->d_xorwow;
+        const int g = grid_for(c, one[0].count);
+        Tail t = make_tail(c, g, scale1, scale2, n, d_triple);
+        xw<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
+        return finish_call(c, t, g, st);
+    }
     std::vector<Segment> segs;
     ProfileScope prof(c);
     // plan first: the launches of the call and their grids (every launch needs the call's total pair count)
@@ -675,6 +827,8 @@ static int planes_run(mc_context *c, int planes, int grid_y, uint64_t unit0, uin
 {
     const auto wall0 = std::chrono::steady_clock::now();
     hipStream_t st = c->stream;
+    if (c->rng != MC_RNG_PHILOX)
+        return fail(MC_ERR_UNSUPPORTED, "greeks: implemented for the Philox generator only");
     if (int rc = begin_call(c, st)) return rc;
     if (int rc = ensure_planes(c, planes)) return rc;
     std::vector<Segment> segs;
@@ -971,7 +1125,10 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     size_t lds = (size_t)np * GROUP * sizeof(Real);
     auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
     bool pairs = false;  // two paths per lane
-    if constexpr (sizeof(Real) == 4) {
+    const bool xorwow = c->rng == MC_RNG_XORWOW;
+    if (xorwow) {   // one path per lane, normals in the lane's LDS column, any n
+        kernel = c->antithetic ? basket_dyn_kernel<Real, true, RngXorwow> : basket_dyn_kernel<Real, false, RngXorwow>;
+    } else if constexpr (sizeof(Real) == 4) {
         pairs = true;
         if (n >= 13 && n >= basket_tiled_min() && n <= 32) {  // normals in registers, no dynamic LDS
             lds = 0;
@@ -984,7 +1141,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
             kernel = c->antithetic ? basket_dyn_f32_kernel<true> : basket_dyn_f32_kernel<false>;
             lds *= 2;  // the lane's column holds packed pairs
         }
-    } else if (n >= basket_tiled_min() && n <= 32) {  // fp64: normals in registers, no dynamic LDS
+    } else if (sizeof(Real) == 8 && n >= basket_tiled_min() && n <= 32) {  // fp64: normals in registers, no dynamic LDS
         lds = 0;
         // 9..16 assets: one kernel per size; 17..32: one per multiple of 4 (the buffer is zero-padded to whole tiles,
         // padded rows carry coef = 0 and padded columns multiply real normals by 0)
@@ -1003,7 +1160,9 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     Tail tail = make_tail(c, total, 1.0, 1.0, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
-        const Work w = make_work(seed, s, 0, 0);
+        Work w = make_work(seed, s, 0, 0);
+        if (xorwow)
+            w.xorwow = c->d_xorwow;
         const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
         tail.slot_base = tail.ticket_base = (uint32_t)slot;
         launch_sim_lds(prof, kernel, g, lds, st, tail, k, w, out ? out + done : (Real *)nullptr);
@@ -1028,6 +1187,11 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
     if (int rc = plan_segments(first, n, segs)) return rc;
     int rc = MC_OK;
     ProfileScope prof(c);
+    if (c->rng == MC_RNG_XORWOW) {   // the generic kernel is the one compiled for both generators
+        if (int rc2 = xorwow_one_segment(segs)) return rc2;
+        if (int rc2 = xorwow_ready(c, seed, st)) return rc2;
+        return basket_launch_dyn<Real>(c, prof, *o, seed, segs, st, out, n, d_triple);
+    }
     switch (o->n <= basket_static_max<Real>() ? o->n : 0) {
 #define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, n, d_triple); break;
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
@@ -1159,11 +1323,22 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     Tail t = make_tail(c, total, 1.0, 1.0, n, d_triple);
     uint64_t done = 0;
     ProfileScope prof(c);
+    const bool xorwow = c->rng == MC_RNG_XORWOW;
+    if (xorwow) {
+        if (int rc = xorwow_one_segment(segs)) return rc;
+        if (int rc = xorwow_ready(c, seed, st)) return rc;
+    }
     for (const Segment &s : segs) {
-        const Work w = make_work(seed, s, 0, 0);
+        Work w = make_work(seed, s, 0, 0);
         const int g = grid_for(c, s.count);
         t.slot_base = t.ticket_base = (uint32_t)slot;
-        if (c->antithetic)
+        if (xorwow) {
+            w.xorwow = c->d_xorwow;
+            if (c->antithetic)
+                launch_sim(prof, cva_kernel<Real, true, RngXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
+            else
+                launch_sim(prof, cva_kernel<Real, false, RngXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
+        } else if (c->antithetic)
             launch_sim(prof, cva_kernel<Real, true>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
         else
             launch_sim(prof, cva_kernel<Real, false>, g, st, t, args, w, out ? out + done : (Real *)nullptr);

@@ -40,6 +40,7 @@ struct Work {
     // path window for masked launches (vanilla edges, per-path dumps): a path is live iff
     // first_path <= p < end_path.  Ignored by the unmasked kernels.
     uint64_t first_path, end_path;
+    const uint32_t *xorwow;     // XORWOW mode only: start states of the launch's lanes, 6 words each (mc_rng.hpp: RngXorwow)
 };
 
 // =========================================================================================
@@ -74,10 +75,10 @@ __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f),
 // ANTI = antithetic variates (not in the reference): every normal z also prices the
 // mirrored path -z; the sample is the mean of the two payoffs (here their sum: the 1/2 rides on the
 // finishing kernel's scale).  Costs one more fma + exponential + clamp-subtract per path.
-template <bool ANTI>
-__device__ __forceinline__ void vanilla_unit_pk(const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)
+template <bool ANTI, class Rng = RngPhilox>
+__device__ __forceinline__ void vanilla_unit_pk(Rng &rng, const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)
 {
-    const u32x4 r = philox_unit(c0, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi);
+    const u32x4 r = rng.draw(w, c0, 0u, 1u /*MC_DOMAIN_VANILLA*/);
     const f2 scale = {0x1p-32f, 0x1p-32f}, half = {0x1p-33f, 0x1p-33f};
     const f2 ua = __builtin_elementwise_fma((f2){(float)r.x, (float)r.z}, scale, half);  // radius uniforms
     const f2 ub = {angle_f32(r.y), angle_f32(r.w)};  // angle uniforms (revolutions, in [1, 2))
@@ -103,21 +104,21 @@ __device__ __forceinline__ void vanilla_unit_pk(const VanillaF32 &o, const Work 
 }
 
 // path order inside the unit: 4q+0 = cos A, 4q+1 = sin A, 4q+2 = cos B, 4q+3 = sin B
-template <bool ANTI>
-__device__ __forceinline__ void vanilla_unit(const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
+template <bool ANTI, class Rng>
+__device__ __forceinline__ void vanilla_unit(Rng &rng, const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
 {
     f2 pc, ps;
-    vanilla_unit_pk<ANTI>(o, w, c0, pc, ps);
+    vanilla_unit_pk<ANTI>(rng, o, w, c0, pc, ps);
     p[0] = pc.x;
     p[1] = ps.x;
     p[2] = pc.y;
     p[3] = ps.y;
 }
-template <bool ANTI>
-__device__ __forceinline__ void vanilla_unit(const VanillaF64 &o, const Work &w, uint32_t c0, double (&p)[2])
+template <bool ANTI, class Rng>
+__device__ __forceinline__ void vanilla_unit(Rng &rng, const VanillaF64 &o, const Work &w, uint32_t c0, double (&p)[2])
 {
     double z[2];
-    block_normals(c0, w.unit_hi, 0u, 1u, w.seed_lo, w.seed_hi, z);
+    block_normals(rng, w, c0, 0u, 1u /*MC_DOMAIN_VANILLA*/, z);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         p[j] = fmax(o.spot * exp_f64(o.drift + o.vol * z[j]) - o.strike, 0.0);
@@ -143,9 +144,10 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first 
     double acc_s = 0.0, acc_q = 0.0;
     f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
     uint32_t c0 = w.unit_lo + gtid;
+    RngPhilox rng(w);   // stateless
     for (uint32_t trip = 0; trip < full_trips; ++trip, c0 += stride) {
         f2 pc, ps;
-        vanilla_unit_pk<ANTI>(o, w, c0, pc, ps);
+        vanilla_unit_pk<ANTI>(rng, o, w, c0, pc, ps);
         s2 += pc;
         s2 += ps;
         q2 = __builtin_elementwise_fma(pc, pc, q2);
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first 
     }
     if (full_trips * stride + gtid < w.n_units) {  // the partial last trip
         f2 pc, ps;
-        vanilla_unit_pk<ANTI>(o, w, c0, pc, ps);
+        vanilla_unit_pk<ANTI>(rng, o, w, c0, pc, ps);
         s2 += pc + ps;
         q2 += pc * pc + ps * ps;
     }
@@ -178,9 +180,10 @@ __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Tail /* first argu
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
+    RngPhilox rng(w);   // stateless
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p[NPB];
-        vanilla_unit<ANTI>(o, w, w.unit_lo + i, p);
+        vanilla_unit<ANTI>(rng, o, w, w.unit_lo + i, p);
         Real s = p[0], q = p[0] * p[0];
 #pragma unroll
         for (int j = 1; j < NPB; ++j) {
@@ -197,7 +200,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Tail /* first argu
 // Masked kernel: honours the path window (partial first/last units) and optionally stores
 // every per-path payoff (currency units) to `out[p - first_path]`.  Used for range edges and
 // by the parity tests; never on the hot path.
-template <class Opt, class Real, bool ANTI>
+template <class Opt, class Real, bool ANTI, class Rng = RngPhilox>
 __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w,
                                                                Real *__restrict__ out, Real out_scale)
 {
@@ -206,9 +209,10 @@ __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Tail /* fir
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
+    Rng rng(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p[NPB];
-        vanilla_unit<ANTI>(o, w, w.unit_lo + i, p);
+        vanilla_unit<ANTI>(rng, o, w, w.unit_lo + i, p);
         const uint64_t unit = ((uint64_t)w.unit_hi << 32) | (uint32_t)(w.unit_lo + i);
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
@@ -604,7 +608,7 @@ struct BasketDyn {
     int cv;
 };
 
-template <class Real, bool ANTI>
+template <class Real, bool ANTI, class Rng = RngPhilox>
 __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
@@ -618,10 +622,11 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const Tail /* first a
     const cptr tiles = (cptr)o.consts, base = tiles + 8 * nb * (nb + 1), coef = base + np, wg = coef + np;
     const uint32_t stride = gridDim.x * GROUP;
     double acc_s = 0.0, acc_q = 0.0;
+    Rng rng(w);
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
         for (int b = 0; b < nblk; ++b) {
             Real z[NPB];
-            block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
+            block_normals(rng, w, w.unit_lo + i, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, z);
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
                 g[(b * NPB + j) * GROUP] = z[j];
@@ -1109,8 +1114,8 @@ __device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaS
 #endif
 }
 
-template <class Real, bool ANTI>
-__device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, uint32_t c0)
+template <class Real, bool ANTI, class Rng>
+__device__ __forceinline__ Real cva_path(Rng &rng, const CvaArgs<Real> &o, const Work &w, uint32_t c0)
 {
     constexpr int NPB = npb<Real>::value;
     Real W = 0, acc = 0;
@@ -1118,7 +1123,7 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
     Real z[NPB];
     const int n_dates = o.n_bs + o.last_intrinsic;
     for (int j0 = 0; j0 < n_dates; j0 += NPB) {
-        block_normals(c0, w.unit_hi, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, w.seed_lo, w.seed_hi, z);
+        block_normals(rng, w, c0, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, z);
         if constexpr (sizeof(Real) == 4) {
 #ifndef MC_AB_CVA_F32_PER_DATE
             if (j0 + 3 < o.n_bs) {  // wave-uniform: all four dates of this block have a closed-form exposure
@@ -1185,15 +1190,16 @@ __device__ __forceinline__ Real cva_path(const CvaArgs<Real> &o, const Work &w, 
     return acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);
 }
 
-template <class Real, bool ANTI>
+template <class Real, bool ANTI, class Rng = RngPhilox>
 __global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
+    Rng rng(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
-        const Real p = cva_path<Real, ANTI>(o, w, w.unit_lo + i);
+        const Real p = cva_path<Real, ANTI>(rng, o, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests

@@ -68,6 +68,101 @@ __device__ __forceinline__ u32x4 philox_unit(uint32_t unit_lo, uint32_t unit_hi,
     return philox4x32_10(unit_hi, unit_lo, block, domain, k0, k1);
 }
 
+// ---- where a kernel's random words come from -------------------------------------------------------
+// `Work` (mc_kernels.hpp) is known to the kernels only; the generator policies take what they need from it.
+//
+// RngPhilox: the engine's generator.  Stateless: block (unit, block, domain) is a pure function of the counter.
+//
+// RngXorwow: the reference's generator (cuRAND XORWOW, dp/MonteCarloKernel.cu:285-290 curand_init, :68,78,250
+// curand_normal) as a SECOND, selectable generator (mc_context_set_generator).  Marsaglia's xorwow:
+// 160 bits of xorshift state + a Weyl word, ~9 integer instructions per 32-bit word.  One sequence per LANE of the
+// launch, exactly like the reference's one curandState per thread: lane l starts from rocRAND's
+// rocrand_init(seed, subsequence = base + l, offset 0) -- the subsequences are 2^67 words apart -- and draws four
+// words whenever a kernel asks for a "block", in the order it asks (the counter arguments are ignored).  The start
+// states come from a context-owned array in HBM (24 B per lane, read once per launch: the reference reads 48 B per
+// thread, :189), filled by xorwow_init_kernel below when (seed, base) change; nothing is written back, so a call is
+// reproducible -- but, unlike Philox, WHICH normals a path gets depends on the launch geometry.
+struct RngPhilox {
+    template <class W> __device__ __forceinline__ explicit RngPhilox(const W &) {}
+    template <class W>
+    __device__ __forceinline__ u32x4 draw(const W &w, uint32_t unit_lo, uint32_t block, uint32_t domain)
+    {
+        return philox_unit(unit_lo, w.unit_hi, block, domain, w.seed_lo, w.seed_hi);
+    }
+};
+
+struct RngXorwow {
+    uint32_t x0, x1, x2, x3, x4, d;
+    template <class W> __device__ __forceinline__ explicit RngXorwow(const W &w)
+    {
+        const uint32_t *p = w.xorwow + 6u * (blockIdx.x * blockDim.x + threadIdx.x);
+        x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], d = p[5];
+    }
+    __device__ __forceinline__ uint32_t next()
+    {
+        const uint32_t t = x0 ^ (x0 >> 2);
+        x0 = x1, x1 = x2, x2 = x3, x3 = x4;
+        x4 = xor3(x4, x4 << 4, t ^ (t << 1));
+        d += 362437u;
+        return d + x4;
+    }
+    template <class W> __device__ __forceinline__ u32x4 draw(const W &, uint32_t, uint32_t, uint32_t)
+    {
+        u32x4 r;
+        r.x = next(), r.y = next(), r.z = next(), r.w = next();
+        return r;
+    }
+};
+
+// Start states of XORWOW lanes [0, lanes): the seeded state (5 xorshift words + Weyl word, prepared on the host)
+// jumped ahead by (base + lane) * 2^67 steps.  jump[i] = A^(2^67 * 2^i) over GF(2), A = one xorshift step, as 160
+// columns of 5 words (column c = image of state bit c); the host computes them by repeated squaring (mc_api.hip).
+// A jump is one conditional xor of a column per set state bit, per set bit of the subsequence number.
+constexpr int XORWOW_JUMP_BITS = 48;   // subsequence numbers below 2^48
+__global__ __launch_bounds__(256) void xorwow_init_kernel(const uint32_t *__restrict__ jump, uint32_t s0, uint32_t s1, uint32_t s2,
+                                                          uint32_t s3, uint32_t s4, uint32_t weyl, uint64_t base, uint32_t lanes,
+                                                          uint32_t *__restrict__ states)
+{
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= lanes)
+        return;
+    uint32_t v[5] = {s0, s1, s2, s3, s4};
+    const uint64_t sub = base + lane;
+    for (int i = 0; i < XORWOW_JUMP_BITS; ++i) {
+        if (!((sub >> i) & 1u))
+            continue;
+        const uint32_t *m = jump + (size_t)i * 160 * 5;
+        uint32_t r[5] = {0, 0, 0, 0, 0};
+        for (int c = 0; c < 160; ++c) {
+            const uint32_t mask = 0u - ((v[c >> 5] >> (c & 31)) & 1u);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                r[k] ^= mask & m[c * 5 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            v[k] = r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        states[6 * (size_t)lane + k] = v[k];
+    states[6 * (size_t)lane + 5] = weyl;
+}
+
+// `count` consecutive words of each of XORWOW lanes [0, lanes): the generator alone, for the word-for-word
+// comparison with rocRAND's engine (tests).  out[lane * count + k].
+__global__ __launch_bounds__(256) void xorwow_words_kernel(const uint32_t *__restrict__ states, uint32_t lanes, uint32_t count,
+                                                           uint32_t *__restrict__ out)
+{
+    struct { const uint32_t *xorwow; } w = {states};
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= lanes)
+        return;
+    RngXorwow rng(w);
+    for (uint32_t k = 0; k < count; ++k)
+        out[(size_t)lane * count + k] = rng.next();
+}
+
 // ---- f32 ---------------------------------------------------------------------------------
 // u = x * 2^-32 + 2^-33  in (0, 1]   (one v_cvt_f32_u32 + one v_fma_f32)
 __device__ __forceinline__ float u01_f32(uint32_t x)
@@ -144,19 +239,29 @@ template <class Real> struct npb;           // normals per Philox block
 template <> struct npb<float> { static constexpr int value = 4; };
 template <> struct npb<double> { static constexpr int value = 2; };
 
-// All normals of one Philox block, precision-generic: out[0..npb)
+// All normals of one block of four words, precision-generic: out[0..npb)
+__device__ __forceinline__ void words_to_normals(const u32x4 r, float (&out)[4])
+{
+    box_muller_f32(r.x, r.y, NEG_2LN2_F32, out[0], out[1]);
+    box_muller_f32(r.z, r.w, NEG_2LN2_F32, out[2], out[3]);
+}
+__device__ __forceinline__ void words_to_normals(const u32x4 r, double (&out)[2]) { box_muller_f64(r, out[0], out[1]); }
+
 __device__ __forceinline__ void block_normals(uint32_t unit_lo, uint32_t unit_hi, uint32_t block, uint32_t domain,
                                               uint32_t k0, uint32_t k1, float (&out)[4])
 {
-    const u32x4 r = philox_unit(unit_lo, unit_hi, block, domain, k0, k1);
-    box_muller_f32(r.x, r.y, NEG_2LN2_F32, out[0], out[1]);
-    box_muller_f32(r.z, r.w, NEG_2LN2_F32, out[2], out[3]);
+    words_to_normals(philox_unit(unit_lo, unit_hi, block, domain, k0, k1), out);
 }
 __device__ __forceinline__ void block_normals(uint32_t unit_lo, uint32_t unit_hi, uint32_t block, uint32_t domain,
                                               uint32_t k0, uint32_t k1, double (&out)[2])
 {
-    const u32x4 r = philox_unit(unit_lo, unit_hi, block, domain, k0, k1);
-    box_muller_f64(r, out[0], out[1]);
+    words_to_normals(philox_unit(unit_lo, unit_hi, block, domain, k0, k1), out);
+}
+// the same through a generator policy (RngPhilox: identical to the above; RngXorwow: the lane's next four words)
+template <class Rng, class W, class Real, int NPB>
+__device__ __forceinline__ void block_normals(Rng &rng, const W &w, uint32_t unit_lo, uint32_t block, uint32_t domain, Real (&out)[NPB])
+{
+    words_to_normals(rng.draw(w, unit_lo, block, domain), out);
 }
 
 }  // namespace mc

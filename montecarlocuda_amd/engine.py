@@ -151,6 +151,16 @@ class Engine:
         """Final reduction inside the simulation kernel (default) or as a second launch (A/B baseline)."""
         check(lib().mc_context_set_finish(self._ctx, 1 if fused else 0))
 
+    def set_generator(self, name: str, subsequence_base: int = 0):
+        """'philox' (default; counter-based) or 'xorwow' (the reference's generator, one sequence per lane)."""
+        check(lib().mc_context_set_generator(self._ctx, {"philox": 0, "xorwow": 1}[name], subsequence_base))
+
+    def xorwow_words(self, seed, first_subsequence, n_subsequences, words_each):
+        out = np.empty((n_subsequences, words_each), dtype=np.uint32)
+        check(lib().mc_xorwow_words(self._ctx, seed, first_subsequence, n_subsequences, words_each,
+                                    out.ctypes.data_as(C.POINTER(C.c_uint32))))
+        return out
+
     def profile(self, every: int):
         """Sample the simulation kernel's device time on every `every`-th launch (0 = off)."""
         check(lib().mc_context_profile(self._ctx, every))

@@ -50,6 +50,15 @@ typedef struct {
 /* Philox4x32-10 (Salmon et al., SC'11; same generator rocRAND/cuRAND ship). */
 void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
+/* XORWOW (the reference's cuRAND generator, dp/MonteCarloKernel.cu:285-290), rocRAND's seeding and subsequence layout:
+ * state[0..4] = xorshift words, state[5] = Weyl word.  orc_xorwow_begin/_end switch the orc_dev_* family to
+ * one-XORWOW-sequence-per-lane normals (see mc_oracle.c). */
+void orc_xorwow_init(uint64_t seed, uint64_t subsequence, uint32_t state[6]);
+uint32_t orc_xorwow_next(uint32_t state[6]);
+void orc_xorwow_jump_column(int i, int c, uint32_t out[5]);
+void orc_xorwow_begin(uint64_t seed, uint64_t subsequence_base, uint32_t lanes, uint64_t unit0);
+void orc_xorwow_end(void);
+
 /* Closing formulas shared by every estimator: reference MonteCarloHost.c:220-228 /
  * MonteCarloKernel.cu:420-423 (discount = exp(-rT) for prices, 1 for CVA :466). fp64. */
 void orc_closing(double sum, double sum2, long long n, double discount,

@@ -247,10 +247,8 @@ void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REA
  * The f32 radius is written with log2 (the HIP kernel's v_log_f32 is a base-2 log). */
 void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
 {
-    uint32_t ctr[4] = {(uint32_t)(unit >> 32), (uint32_t)unit, block, domain};
-    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
     uint32_t x[4];
-    orc_philox4x32_10(ctr, key, x);
+    orc_block_words(seed, domain, unit, block, x);   /* Philox(counter, key), or the owning lane's XORWOW sequence */
 #if ORC_IS_F32
     for (int h = 0; h < 2; h++) {
         float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f);
@@ -475,6 +473,11 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
         uint64_t path = first_path + i;
         for (int b = 0; b < nblk; b++)
             FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
+        if (orc_xorwow_active()) { /* the generic kernel pads n to a multiple of 4 normals: the lane's sequence moves on */
+            REAL skip[ORC_NPB];
+            for (int b = nblk; b < 4 * ((n + 3) / 4) / ORC_NPB; b++)
+                FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, skip);
+        }
         REAL payoff = 0;
         for (int sign = 1; sign >= (antithetic ? -1 : 1); sign -= 2) {
             REAL basket = 0, lg = (REAL)log(wsum);

@@ -116,6 +116,37 @@ def philox(ctr, key):
     return [int(v) for v in o]
 
 
+def xorwow_words(seed, subsequence, count):
+    """First `count` 32-bit outputs of XORWOW(seed, subsequence) -- rocRAND's seeding and subsequence layout."""
+    L = lib()
+    L.orc_xorwow_init.argtypes = [C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    L.orc_xorwow_init.restype = None
+    L.orc_xorwow_next.argtypes = [C.POINTER(C.c_uint32)]
+    L.orc_xorwow_next.restype = C.c_uint32
+    st = (C.c_uint32 * 6)()
+    L.orc_xorwow_init(seed, subsequence, st)
+    return [int(L.orc_xorwow_next(st)) for _ in range(count)]
+
+
+class xorwow_mode:
+    """Context manager: inside it the dev_* functions draw their normals from one XORWOW sequence per lane
+    (lane l = subsequence base + l prices units unit0 + l, unit0 + l + lanes, ...), like the product's XORWOW mode."""
+
+    def __init__(self, seed, subsequence_base, lanes, unit0):
+        self.args = (seed, subsequence_base, lanes, unit0)
+
+    def __enter__(self):
+        L = lib()
+        L.orc_xorwow_begin.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint64]
+        L.orc_xorwow_begin.restype = None
+        L.orc_xorwow_end.restype = None
+        L.orc_xorwow_begin(*self.args)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_xorwow_end()
+
+
 def closing(s, s2, n, discount=1.0):
     e, c = C.c_double(), C.c_double()
     lib().orc_closing(s, s2, n, discount, C.byref(e), C.byref(c))

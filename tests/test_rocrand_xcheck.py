@@ -40,3 +40,26 @@ def test_oracle_philox_equals_rocrand_engine(po, tmp_path):
         if ua < 1:
             r2 = float(z[0]) ** 2 + float(z[1]) ** 2
             assert r2 == pytest.approx(-2.0 * np.log(float(ua)), rel=2e-5), (s, u, b, d)
+
+
+def test_oracle_xorwow_equals_rocrand_engine(po, tmp_path):
+    """XORWOW, the reference's generator (curand_init / curand_normal, dp/MonteCarloKernel.cu:285-290,68): the oracle's
+    words -- seeding by rocRAND's rule, subsequence jump by GF(2) matrices the oracle computes itself -- equal those of
+    rocRAND's own host-callable engine, rocrand_init(seed, subsequence, 0) + rocrand(), for small and huge subsequence
+    numbers.  The HIP engine's XORWOW is compared with the oracle on the GPU (tests/test_gpu_xorwow.py)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/include/rocrand/rocrand_xorwow.h"):
+        pytest.skip("rocRAND headers / hipcc not available")
+    exe = tmp_path / "rocrand_xorwow_xcheck"
+    subprocess.check_call([hipcc, "-O1", "-w", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "cpp", "rocrand_xorwow_xcheck.cpp"),
+                           "-o", str(exe)])
+    rng = np.random.default_rng(11)
+    cases = [(0, 0, 8), (0x4D435F4D49333535, 0, 8), (0x4D435F4D49333535, 1, 8), (1, 255, 4), (1, 256, 4), (12345, 524287, 4),
+             (2 ** 64 - 1, 2 ** 32 - 1, 4), (7, 2 ** 48 - 1, 4)]
+    for _ in range(200):
+        cases.append((int(rng.integers(0, 2 ** 63)) * 2 + int(rng.integers(0, 2)), int(rng.integers(0, 2 ** 47)), 3))
+    text = "".join(f"{s} {sub} {c}\n" for s, sub, c in cases)
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(cases)
+    for (s, sub, c), line in zip(cases, out):
+        assert po.xorwow_words(s, sub, c) == [int(x, 16) for x in line.split()], (s, sub)
