@@ -135,7 +135,7 @@ def cpu_all_cores(seconds=2.0):
             "sample": f"{n} paths in {dt:.2f} s", "price": float(v.Expected)}
 
 
-def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, backend, barrier, reps):
+def strong_scaling_block(mc, torch, dist, eng, launch_stream, stream, rank, world, grouped, backend, barrier, reps):
     """BASELINE.json's strong-scaling target, measured on this N: ONE pricing call of configs[3] (C4: basket, 16 assets,
     1e9 paths, fp64) and of configs[4] (C5: CVA, 256 dates x 1e7 paths, fp64) -- and of 10x those sizes --
     sharded over the N ranks (mc_shard_range), timed wall-clock from the first launch to the all-reduced triple on the
@@ -157,7 +157,8 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
             barrier()
             t0 = time.perf_counter()
             if count:
-                eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), stream.cuda_stream)
+                eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), launch_stream)
+                eng.order(stream.cuda_stream)     # torch's current stream (RCCL, the read-back) behind the launch
             else:
                 out.zero_()
             if grouped and backend == "nccl":
@@ -253,6 +254,10 @@ def main():
     ap.add_argument("--c-multi-seconds", type=int, default=240,
                     help="N=1 only: time limit of the child process drivers/multiBench (the C library's own multi-GPU path over "
                          "1, 2, 4, 8 ... of the visible GPUs); 0 = skip")
+    ap.add_argument("--poll", type=int, default=0,
+                    help="1: the host polls the launch streams (mc_context_idle) before the closing synchronize of the timed "
+                         "region instead of sleeping in it; 0 (default): blocking synchronize only -- measured equal within noise "
+                         "(profiles/r02_short_run_variance.log)")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
@@ -283,15 +288,17 @@ def main():
     K, W = args.steps, args.warmup
     struct, keep = eng.prepared(prod, X, inputs)
     seed = mc.MC_DEFAULT_SEED
-    # Explicit non-default streams, one per context; the first is made torch's CURRENT stream so that
-    # torch's copies and RCCL's waits are ordered behind the launches.
-    if args.stream_source == "context":   # every context's own non-blocking stream (mc_context_stream)
-        streams = [torch.cuda.ExternalStream(e.stream, device=local) for e in engines]
-    else:
-        streams = [torch.cuda.Stream(device=local) for _ in engines]
-    stream = streams[0]
+    # Launch streams: each context's own non-blocking stream (raw hipStream_t handles; torch never sees them) or
+    # streams of torch's pool.  `stream` = torch's CURRENT stream, always one of torch's own: torch's copies and RCCL's
+    # waits are ordered on it, and it is ordered behind the launch streams in flush_bucket (mc_context_order).
+    stream = torch.cuda.Stream(device=local)
     torch.cuda.set_stream(stream)
-    assert all(s_.cuda_stream != 0 for s_ in streams)
+    if args.stream_source == "context":
+        launch_streams = [e.stream for e in engines]
+    else:
+        pool = [stream] + [torch.cuda.Stream(device=local) for _ in engines[1:]]
+        launch_streams = [s_.cuda_stream for s_ in pool]
+    assert all(h != 0 for h in launch_streams) and stream.cuda_stream != 0
     structs = [e.prepared(prod, X, inputs) for e in engines]
     triples = torch.zeros((K + W, 3), dtype=torch.float64, device="cuda")
     works = []
@@ -301,8 +308,9 @@ def main():
     def flush_bucket():
         # one RCCL all-reduce for the triples of steps [pending[0], pending[1]): the rows are
         # contiguous, so a bucket is a single (bucket x 3) fp64 message, asynchronous to compute
-        for s_ in streams[1:]:
-            stream.wait_stream(s_)          # the bucket's triples come from every stream
+        if grouped:
+            for e_ in engines:
+                e_.order(stream.cuda_stream)    # the bucket's triples come from every launch stream
         if grouped and pending[1] > pending[0]:
             rows = triples[pending[0]:pending[1]]
             if args.backend == "nccl":
@@ -323,7 +331,7 @@ def main():
     def step(i):
         first = i * step_total + shard_first
         e = i % len(engines)
-        engines[e].launch(prod, X, structs[e][0], seed, first, shard_count, triples[i].data_ptr(), streams[e].cuda_stream)
+        engines[e].launch(prod, X, structs[e][0], seed, first, shard_count, triples[i].data_ptr(), launch_streams[e])
         pending[1] = i + 1
         if pending[1] - pending[0] >= max(1, args.bucket):
             flush_bucket()
@@ -333,6 +341,10 @@ def main():
         for w in works:
             w.wait()
         works.clear()
+        if args.poll:
+            # poll the launch streams (and torch's) from user space until the work is done, THEN synchronise
+            while not (all(e_.idle() for e_ in engines) and stream.query()):
+                pass
         torch.cuda.synchronize()
 
     def barrier():
@@ -350,7 +362,7 @@ def main():
             for _ in range(64):
                 e = j % len(engines)
                 engines[e].launch(prod, X, structs[e][0], seed, (1 << 50) + j * shard_count, shard_count, scratch[e].data_ptr(),
-                                  streams[e].cuda_stream)
+                                  launch_streams[e])
                 j += 1
             torch.cuda.synchronize()
         preheat_ms = (time.perf_counter() - t_pre) * 1e3
@@ -381,7 +393,7 @@ def main():
         eng.profile(1)
         for i in range(n_ex):
             eng.launch(prod, X, structs[0][0], seed, (W + K + i) * step_total + shard_first, shard_count, solo[i].data_ptr(),
-                       streams[0].cuda_stream)
+                       launch_streams[0])
         torch.cuda.synchronize()
         ex_samples, ex_ms = eng.profile_read()
         eng.profile(0)
@@ -398,15 +410,15 @@ def main():
         def step64(i):
             e = i % len(engines)
             engines[e].launch("vanilla", "f64", s64[e], seed, i * step_total + shard_first, shard_count, side[i].data_ptr(),
-                              streams[e].cuda_stream)
+                              launch_streams[e])
         for i in range(5):
             step64(i)
         barrier()
         t1 = time.perf_counter()
         for i in range(5, 5 + args.fp64_steps):
             step64(i)
-        for s_ in streams[1:]:
-            stream.wait_stream(s_)
+        for e_ in engines:
+            e_.order(stream.cuda_stream)
         if grouped:
             if args.backend == "nccl":
                 dist.all_reduce(side[5:], op=dist.ReduceOp.SUM)
@@ -425,7 +437,8 @@ def main():
 
     strong = None
     if args.strong_reps > 0 and args.workload == "vanilla_f32":
-        strong = strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, args.backend, barrier, args.strong_reps)
+        strong = strong_scaling_block(mc, torch, dist, eng, launch_streams[0], stream, rank, world, grouped, args.backend, barrier,
+                                      args.strong_reps)
 
     if rank == 0:
         tot = triples[W:].sum(dim=0).cpu().tolist()           # every step's triple is already all-reduced

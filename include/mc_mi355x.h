@@ -173,6 +173,15 @@ int mc_cva_launch_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
 int mc_cva_launch_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
                       uint64_t first_path, uint64_t n_paths, double *d_triple, void *stream);
 
+/* Order `stream` behind everything `ctx` has enqueued so far (event on the stream of its last call, wait on `stream`):
+ * how a consumer of d_triple on ANOTHER stream -- a copy, an RCCL all-reduce -- is sequenced after the launch without
+ * a host synchronisation.  A no-op when `stream` is the stream of the last call. */
+int mc_context_order(mc_context *ctx, void *stream);
+
+/* 1 when everything `ctx` has enqueued has completed, 0 while some of it is pending, -1 on error (hipStreamQuery of the
+ * stream of its last call): a host may poll this from user space instead of sleeping in a synchronize. */
+int mc_context_idle(mc_context *ctx);
+
 /* ---- synchronous runs (launch + wait + closing formulas) --------------------------------
  * Replace dev_vanillaOpt / dev_basketOpt / dev_cvaEquityOption (dp/MonteCarloKernel.cu:
  * 500,483,517) with an explicit seed, a 64-bit path range and a status code. */

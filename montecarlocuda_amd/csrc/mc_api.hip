@@ -432,6 +432,34 @@ static int begin_call(mc_context *c, hipStream_t st)
     return MC_OK;
 }
 
+// Make `stream` wait for everything this context has enqueued so far (on whatever stream its last call used): the
+// hand-over from a launch stream to the stream of a consumer of the triple (a copy, an RCCL call).
+extern "C" int mc_context_order(mc_context *c, void *stream)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    HIPCHK(hipSetDevice(c->device));
+    if (c->used && (hipStream_t)stream != c->last_stream) {
+        HIPCHK(hipEventRecord(c->last_use, c->last_stream));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->last_use, 0));
+    }
+    return MC_OK;
+}
+
+// 1 when everything this context has enqueued has completed, 0 while work is pending, -1 on error: hipStreamQuery
+// of the stream its last call used -- lets a host poll from user space instead of sleeping in a synchronize.
+extern "C" int mc_context_idle(mc_context *c)
+{
+    if (!c)
+        return -1;
+    if (!c->used)
+        return 1;
+    if (hipSetDevice(c->device) != hipSuccess)
+        return -1;
+    const hipError_t e = hipStreamQuery(c->last_stream);
+    return e == hipSuccess ? 1 : (e == hipErrorNotReady ? 0 : -1);
+}
+
 static int finish_call(mc_context *c, const Tail &t, int total, hipStream_t st)
 {
     if (!c->fused)

@@ -147,6 +147,17 @@ class Engine:
         """Baskets: simulate payoff(arithmetic) - payoff(geometric) and add the geometric closed form back."""
         check(lib().mc_context_set_control_variate(self._ctx, 1 if on else 0))
 
+    def order(self, stream: int):
+        """Make `stream` (a hipStream_t handle) wait for everything this context has enqueued so far."""
+        check(lib().mc_context_order(self._ctx, C.c_void_p(stream)))
+
+    def idle(self) -> bool:
+        """True when everything this context has enqueued has completed (a user-space poll, no sleeping)."""
+        r = lib().mc_context_idle(self._ctx)
+        if r < 0:
+            raise _lib.McError("mc_context_idle failed")
+        return r == 1
+
     def set_finish(self, fused: bool):
         """Final reduction inside the simulation kernel (default) or as a second launch (A/B baseline)."""
         check(lib().mc_context_set_finish(self._ctx, 1 if fused else 0))
