@@ -120,6 +120,14 @@ int mc_context_set_antithetic(mc_context *ctx, int on);
  * variance reduction on the BASELINE baskets: ~150x (x2.5 more with antithetic). */
 int mc_context_set_control_variate(mc_context *ctx, int on);
 
+/* Device timing of the synchronous *_run_* calls.  on != 0 (default): the call's kernels are bracketed by two HIP
+ * events and mc_result.kernel_ms reports them (replaces the reference's cudaEvent pairs, dp/MonteCarloKernel.cu:380-386),
+ * the result comes back through a 24-byte copy and a stream synchronize.  on == 0: no events; the last workgroup of the
+ * call writes the result straight into pinned host memory and the calling thread polls for it from user space --
+ * about 10 us less host time per call (profiles/r02_call_latency.log); kernel_ms is then 0.  The legacy symbols run
+ * with timing off unless MC_VERBOSE is set. */
+int mc_context_set_timing(mc_context *ctx, int on);
+
 /* Generator switch.  MC_RNG_PHILOX (default): Philox4x32-10, counter-based -- a path's normals depend
  * only on (seed, global path index).  MC_RNG_XORWOW: the reference's generator (cuRAND XORWOW, dp/MonteCarloKernel.cu:
  * 285-290 curand_init, :68,78,250 curand_normal), hand-written for gfx950, with rocRAND's seeding and subsequence

@@ -71,6 +71,10 @@ struct mc_context {
     double *g_triples = nullptr;  // one triple per plane
     int g_planes = 0;
     double *h_triple = nullptr;   // pinned
+    double *h_direct = nullptr;   // pinned + host-coherent: the kernel writes the triple of a synchronous call straight here
+    double *d_direct = nullptr;   // device address of h_direct
+    double *direct_target = nullptr;   // what the Tail of the call being enqueued carries (set by run_sync around its enqueue)
+    bool timing = true;           // synchronous calls bracket their kernels with HIP events (mc_result.kernel_ms)
     void *d_out = nullptr;        // per-path dump buffer (tests), grown on demand
     size_t d_out_bytes = 0;
     void *d_table = nullptr;      // CVA per-date table
@@ -153,6 +157,8 @@ static int context_allocate(mc_context *c)
     HIPCHK(hipMemset(c->tickets, 0, sizeof(uint32_t) * TICKET_WORDS));
     HIPCHK(hipMalloc(&c->d_triple, 3 * sizeof(double)));
     HIPCHK(hipHostMalloc(&c->h_triple, 3 * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(&c->h_direct, 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void **)&c->d_direct, c->h_direct, 0));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
     HIPCHK(hipEventCreateWithFlags(&c->table_copied, hipEventDisableTiming));
@@ -213,6 +219,7 @@ extern "C" void mc_context_destroy(mc_context *c)
     (void)hipFree(c->g_pairs);
     (void)hipFree(c->g_triples);
     (void)hipHostFree(c->h_triple);
+    (void)hipHostFree(c->h_direct);
     (void)hipFree(c->d_out);
     (void)hipFree(c->d_table);
     (void)hipHostFree(c->h_table);
@@ -252,6 +259,14 @@ extern "C" int mc_context_set_finish(mc_context *c, int fused)
     if (!c)
         return fail(MC_ERR_INVALID, "NULL context");
     c->fused = fused != 0;
+    return MC_OK;
+}
+
+extern "C" int mc_context_set_timing(mc_context *c, int on)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    c->timing = on != 0;
     return MC_OK;
 }
 
@@ -414,6 +429,7 @@ static Tail make_tail(const mc_context *c, int total, double scale1, double scal
     t.total = c->fused ? (uint32_t)total : 0u;
     t.planes = (uint32_t)planes;
     t.plane_stride = (uint32_t)plane_stride;
+    t.host_triple = c->fused ? c->direct_target : nullptr;
     return t;
 }
 
@@ -1564,22 +1580,55 @@ static int factor_from_cov(int n, const Real *cov, Real *v, Real *p)
 extern "C" int mc_factor_from_cov_f32(int n, const float *cov, float *v, float *p) { return factor_from_cov<float>(n, cov, v, p); }
 extern "C" int mc_factor_from_cov_f64(int n, const double *cov, double *v, double *p) { return factor_from_cov<double>(n, cov, v, p); }
 
-// run = enqueue on the context stream between two events, wait, read 24 bytes, close
+// run = enqueue on the context stream, wait, read 24 bytes, close.
+//   timing on (default): two HIP events around the kernels (mc_result.kernel_ms), a 24-byte D2H copy, a stream
+//     synchronize -- about 20 us of host time around the kernel.
+//   timing off (mc_context_set_timing(ctx, 0); the legacy symbols unless MC_VERBOSE is set): the last workgroup of the
+//     call writes the triple straight into pinned host memory (Tail.host_triple) and this thread polls the n word from
+//     user space: no event records, no copy command, no sleeping wait.  kernel_ms is reported as 0.
+static constexpr double DIRECT_SENTINEL = -1.0;   // n_paths is never negative
+
 template <class Enq>
 static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, Enq enqueue)
 {
     const auto wall0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipEventRecord(c->ev0, c->stream));
-    if (int rc = enqueue(c->stream, c->d_triple)) return rc;
-    HIPCHK(hipEventRecord(c->ev1, c->stream));
-    HIPCHK(hipMemcpyAsync(c->h_triple, c->d_triple, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
     float ms = 0;
-    HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    out->sum = c->h_triple[0];
-    out->sum2 = c->h_triple[1];
-    out->n = (uint64_t)c->h_triple[2];
+    const double *h = c->h_triple;
+    if (!c->timing && c->fused) {
+        volatile double *flag = c->h_direct + 2;
+        *flag = DIRECT_SENTINEL;
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        c->direct_target = c->d_direct;
+        const int rc = enqueue(c->stream, c->d_triple);
+        c->direct_target = nullptr;
+        if (rc) return rc;
+        // poll for up to ~2 s of spinning, then fall back to a blocking wait (a kernel that failed never writes)
+        bool seen = false;
+        for (uint64_t spin = 0; spin < (1ull << 31); ++spin) {
+            if (__atomic_load_n((const uint64_t *)(c->h_direct + 2), __ATOMIC_ACQUIRE) != __builtin_bit_cast(uint64_t, DIRECT_SENTINEL)) {
+                seen = true;
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        if (!seen) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (*flag == DIRECT_SENTINEL)
+                return fail(MC_ERR_HIP, "the device never delivered the result of a synchronous call");
+        }
+        h = c->h_direct;
+    } else {
+        if (c->timing) HIPCHK(hipEventRecord(c->ev0, c->stream));
+        if (int rc = enqueue(c->stream, c->d_triple)) return rc;
+        if (c->timing) HIPCHK(hipEventRecord(c->ev1, c->stream));
+        HIPCHK(hipMemcpyAsync(c->h_triple, c->d_triple, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->timing) HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    }
+    out->sum = h[0];
+    out->sum2 = h[1];
+    out->n = (uint64_t)h[2];
     out->kernel_ms = ms;
     if (out->n != n)
         return fail(MC_ERR_HIP, "device returned n=%llu, expected %llu", (unsigned long long)out->n,

@@ -109,6 +109,11 @@ struct Tail {
     // arrival number ticket_base + y * gridDim.x + x of `total`.  One-dimensional grids: ticket_base == slot_base,
     // total == pairs.  total == 0 selects the two-launch form (plain store, finish_kernel follows).
     uint32_t ticket_base, total;
+    // synchronous calls: pinned, host-coherent copy of plane 0's triple (device address of host memory), or nullptr.
+    // The last arriver stores {sum, sum2} there and then n_paths with system-scope release semantics: the host, which
+    // preset that word to a sentinel, polls it from user space and has the result ~1 us after the last workgroup is
+    // done -- no D2H copy command, no sleeping synchronize (mc_api.hip: run_sync).
+    double *host_triple;
 };
 
 typedef __attribute__((address_space(1))) unsigned long long gu64_t;
@@ -182,6 +187,12 @@ __device__ __forceinline__ void arrive_and_finish(tail_ptr t)
             t->triple[3 * plane + 0] = t->scale1 * s;
             t->triple[3 * plane + 1] = t->scale2 * q;
             t->triple[3 * plane + 2] = t->n_paths;
+            if (plane == 0 && t->host_triple) {
+                gu64_t *h = (gu64_t *)t->host_triple;
+                __hip_atomic_store(h, (unsigned long long)__double_as_longlong(t->scale1 * s), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(h + 1, (unsigned long long)__double_as_longlong(t->scale2 * q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(h + 2, (unsigned long long)__double_as_longlong(t->n_paths), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
     if (threadIdx.x <= TICKET_SHARDS)   // ready for the next call

@@ -218,3 +218,25 @@ def test_result_carries_kernel_and_wall_time(mc):
         e.vanilla(VAN, 10 ** 6, SEED, 0, "f32")
         r = e.vanilla(VAN, 10 ** 8, SEED, 0, "f32")
         assert 0.03 < r.kernel_ms < 0.2 and r.kernel_ms < r.wall_ms < 5.0
+
+
+def test_timing_off_returns_the_same_bits_through_pinned_memory(mc):
+    """mc_context_set_timing(ctx, 0): the last workgroup writes the triple straight into pinned host memory and the host
+    polls for it (no events, no copy command, no sleeping synchronize).  Same numbers, bit for bit, for every product,
+    multi-segment ranges and back-to-back calls; kernel_ms is 0; the call is not slower."""
+    with mc.Engine(0) as timed, mc.Engine(0) as direct, mc.Engine(0, blocks=3) as small:
+        direct.set_timing(False)
+        for prod, X, inp in _all_products(mc):
+            for first, n in ((0, 2), (5, 1000), (3, 2_000_003), ((1 << 32) - 70_000, 200_001)):   # (n = 1 has a NaN half-width)
+                a, b = getattr(timed, prod)(inp, n, SEED, first, X), getattr(direct, prod)(inp, n, SEED, first, X)
+                assert (a.sum, a.sum2, a.n, a.expected, a.confidence) == (b.sum, b.sum2, b.n, b.expected, b.confidence), (prod, X, first, n)
+                assert b.kernel_ms == 0.0 and b.wall_ms > 0
+        small.set_timing(False)
+        first = [small.vanilla(VAN, 100_000 + i, SEED, i, "f32").sum for i in range(200)]      # 200 calls back to back
+        small.set_timing(True)
+        assert first == [small.vanilla(VAN, 100_000 + i, SEED, i, "f32").sum for i in range(200)]
+        for e in (timed, direct):
+            e.vanilla(VAN, 10 ** 6, SEED, 0, "f32")
+        t = sorted(timed.vanilla(VAN, 10 ** 6, SEED, 0, "f32").wall_ms for _ in range(200))[100]
+        d = sorted(direct.vanilla(VAN, 10 ** 6, SEED, 0, "f32").wall_ms for _ in range(200))[100]
+        assert d < t * 1.05, (d, t)

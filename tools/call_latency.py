@@ -48,7 +48,7 @@ def child():
             for _ in range(20):
                 L.dev_vanillaOpt(C.byref(o), 512, 128, sims)
                 eng.vanilla(VAN, sims, precision=X)
-            legacy, native_wall, native_kernel = [], [], []
+            legacy, native_wall, native_kernel, direct_wall = [], [], [], []
             for _ in range(300):
                 t0 = time.perf_counter()
                 v = L.dev_vanillaOpt(C.byref(o), 512, 128, sims)
@@ -56,8 +56,12 @@ def child():
                 e = eng.vanilla(VAN, sims, precision=X)
                 native_wall.append(e.wall_ms * 1e3)
                 native_kernel.append(e.kernel_ms * 1e3)
+                eng.set_timing(False)
+                direct_wall.append(eng.vanilla(VAN, sims, precision=X).wall_ms * 1e3)
+                eng.set_timing(True)
             out[f"{X} k={k}"] = {"paths": sims, "dev_vanillaOpt_wall_us": statistics.median(legacy),
                                  "mc_vanilla_run_wall_us": statistics.median(native_wall),
+                                 "mc_vanilla_run_untimed_wall_us": statistics.median(direct_wall),
                                  "kernel_us": statistics.median(native_kernel), "price": float(v.Expected)}
     print(json.dumps(out))
 
@@ -76,11 +80,14 @@ def main():
     print("# tools/call_latency.py: dev_vanillaOpt(&opt, 512, 128, k * 131072), one MI355X; medians of 300 calls, two passes per form")
     print("# context creation + first call (once per process): " +
           ", ".join(f"{form} {statistics.mean(r['context_create_and_first_call_ms'] for r in runs):.0f} ms" for form, runs in res.items()))
-    print(f"{'call':12s} {'paths':>11s} | {'form':10s} {'dev_vanillaOpt wall us':>23s} {'mc_vanilla_run wall us':>23s} {'kernel us':>10s}")
+    print("# dev_vanillaOpt (legacy symbol) and the 'untimed' column run with mc_context_set_timing(ctx, 0): no HIP events, the result")
+    print("# written by the last workgroup into pinned host memory and polled (fused form only; the two-launch form copies and synchronises).")
+    print(f"{'call':12s} {'paths':>11s} | {'form':10s} {'dev_vanillaOpt wall us':>23s} {'mc_vanilla_run wall us':>23s} {'untimed wall us':>16s} {'kernel us':>10s}")
     for key in [k for k in res["fused"][0] if "k=" in k]:
         for form, runs in res.items():
             f = lambda name: min(r[key][name] for r in runs)   # noqa: E731  (best of the two passes)
-            print(f"{key:12s} {runs[0][key]['paths']:11d} | {form:10s} {f('dev_vanillaOpt_wall_us'):23.1f} {f('mc_vanilla_run_wall_us'):23.1f} {f('kernel_us'):10.1f}")
+            print(f"{key:12s} {runs[0][key]['paths']:11d} | {form:10s} {f('dev_vanillaOpt_wall_us'):23.1f} {f('mc_vanilla_run_wall_us'):23.1f} "
+                  f"{f('mc_vanilla_run_untimed_wall_us'):16.1f} {f('kernel_us'):10.1f}")
 
 
 if __name__ == "__main__":
