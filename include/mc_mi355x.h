@@ -15,10 +15,16 @@
  *     the 24-byte payload of the multi-GPU all-reduce.  No host synchronisation;
  *   - *_run_* are the synchronous forms: launch, wait, close the estimator on the host;
  *   - *_paths_* return per-path values for a (small) path range: used by the parity tests.
+ * One launch per call: the last workgroup to arrive adds the per-workgroup (sum, sum2) pairs and writes the triple.
+ * Contract of a context: it owns one pair buffer, one ticket block and one constant table, so its calls execute one
+ * after the other; calls on one stream are ordered by the stream, a call on a DIFFERENT stream than the context's
+ * previous call is ordered behind it by the library (event + wait).  For overlap use one context per stream.  A context
+ * is not thread-safe: one host thread per context.  Several GPUs from one process: include/mc_multi.h.
  *
  * Random numbers: Philox4x32-10, key = 64-bit seed, counter = {unit_hi, unit_lo, block,
- * domain} (unit = 64-bit index of a path or of a Philox block of vanilla paths).  A path's normals depend only on (seed, global path index), never on the launch
- * geometry or on how a range is split over GPUs.  Layout per product: DESIGN.md "RNG".
+ * domain} (unit = 64-bit index of a path or of a Philox block of vanilla paths).  A path's normals depend only on
+ * (seed, global path index), never on the launch geometry or on how a range is split over GPUs.  Layout per product:
+ * DESIGN.md "RNG".  XORWOW, the reference's generator, is selectable: mc_context_set_generator.
  *
  * Precision suffix: _f32 simulates in float (sums are still accumulated in double),
  * _f64 simulates in double.  Struct layouts equal the reference's of that precision.

@@ -1,9 +1,12 @@
 // mc_reduce.hpp -- (sum, sum2) reduction for gfx950: DPP inside the 64-lane wave, LDS across
-// the waves of a workgroup, one 16-byte store per workgroup, and a small finishing kernel that
-// adds the per-workgroup pairs in a fixed order (bitwise reproducible for a given grid).
+// the waves of a workgroup, one 16-byte store per workgroup, and the LAST workgroup of a pricing call to
+// arrive adds the per-workgroup pairs in a fixed order (bitwise reproducible for a given grid) and writes
+// the call's {sum, sum2, n} -- to HBM and, for synchronous calls, straight into pinned host memory.
+// finish_kernel is the same final step as a second launch (the selectable two-launch form / A/B baseline).
 //
 // Replaces the reference's shared-memory tree (dp/MonteCarloKernel.cu:157-176, log2(T)
-// __syncthreads rounds over 2*T reals) and its host loop over blocks (:416-419, :462-465).
+// __syncthreads rounds over 2*T reals), its D2H copy of the per-block pairs (:405) and its host loop over
+// blocks (:416-419, :462-465).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
