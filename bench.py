@@ -6,24 +6,29 @@
            --master-port P bench.py --gpus N --steps K --warmup W
 
 A STEP is one pass of the hot path over one batch: one pricing call of the workload's path count
-on every GPU (simulation kernel + on-device reduction -> {sum, sum2, n} in HBM) and, for N > 1,
+on every GPU (ONE kernel: simulation + in-kernel final reduction -> {sum, sum2, n} in HBM) and, for N > 1,
 the RCCL all-reduce of that 24-byte triple.  Default workload = BASELINE.json configs[1]:
 European vanilla call, 1 asset, 1e8 paths, fp32 simulation (fp64 accumulation), per GPU.
 
 Scaling is WEAK: every GPU simulates `paths` paths per step, rank g taking the contiguous global
 range [(step*N + g) * paths, +paths) of one Philox stream (no data-path collective besides the
 triple).  Steps rotate over `--streams` (default 2) independent context/stream pairs so that one
-pricing call's launch gap and finishing kernel overlap the next call's simulation kernel -- fixed
-per-call costs (~11 us of a ~61 us step) are hidden, each call is still one full launch.
+pricing call's launch gap, ramp and tail overlap the next call's kernel -- fixed per-call costs
+(~7 us of a ~57 us lone call) are hidden, each call is still one full launch.
 The triples of `--bucket` consecutive steps are all-reduced as ONE message (fewer, larger
 collectives: a 24-byte all-reduce is pure latency), asynchronously on RCCL's stream while the
-compute stream keeps simulating; every bucket is waited for inside the timed region.
+launch streams keep simulating; every bucket is waited for inside the timed region.
+Before the W warm-up steps the same kernel runs untimed for --preheat-ms (clock ramp; reported).
 
 Reported besides the contract fields:
-  roofline      dominant kernel (the simulation kernel) timed with HIP events on its launch stream
-                for every 8th step inside the timed region; achieved = algorithmic flop per launch
-                (15.5 flop/path vanilla, n^2+12.5n+6 basket, 60/path-step CVA) / that
-                duration; the bound is VALU issue, not HBM or MFMA (DESIGN.md "Roofline")
+  roofline      dominant kernel (the simulation kernel): achieved = algorithmic flop per launch (SURVEY 8d:
+                15.5 flop/path vanilla, n^2+12.5n+6 basket, 60/path-step CVA) / its launch duration, measured live
+                with HIP events bound to the dispatch over 50 launches one at a time right after the timed region
+                (launches inside the region are co-resident: in_region); effective = per step period; issue_frac =
+                issue-slot model from the committed PMC instruction counts; traffic / hbm_gbps from the committed
+                PMC passes (tagged as such); the bound is VALU issue, not HBM or MFMA
+  strong        every N: ONE call of C4 / C5 (and 10x) sharded over the N ranks, wall-clock to the all-reduced result
+  c_multi       N = 1: the same rows through the C library alone (drivers/multiBench, libmc_multi.so + RCCL), child process
   cpu_baseline  the reference's own CPU path (oracle/_ref, compiled from MonteCarloHost.c) or, when
                 that build is absent, the oracle port; one host core; rank 0 at N=1 only
 """
@@ -484,6 +489,10 @@ def main():
             "roofline": {"bound": "valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": (ach / peak) if ach else None,
                          "traffic": committed.get("hbm_bytes_per_launch"),
+                         "hbm_gbps": (committed["hbm_bytes_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
+                                      / kernel_s / 1e9) if committed.get("hbm_bytes_per_launch") and kernel_s else None,
+                         "hbm_frac_of_8TBps": (committed["hbm_bytes_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
+                                               / kernel_s / 8e12) if committed.get("hbm_bytes_per_launch") and kernel_s else None,
                          "traffic_source": (committed.get("source", "") + " (committed PMC profile, not measured in this run)")
                          if committed else None,
                          "kernel": kernel_name(prod, X, inputs), "flop_per_path": flop_per_path,
