@@ -29,13 +29,14 @@ static int cmp_double(const void *a, const void *b)
 
 int main(int argc, char **argv)
 {
-    int reps = 5, max_devices = 64, small = 0;
+    int reps = 5, max_devices = 64, small = 0, timing = 1;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-devices") && i + 1 < argc) max_devices = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--small")) small = 1;
+        else if (!strcmp(argv[i], "--no-events")) timing = 0;   /* mc_multi_set_timing(m, 0): kernel_ms reads 0 */
         else {
-            fprintf(stderr, "usage: %s [--reps R] [--max-devices G] [--small]\n", argv[0]);
+            fprintf(stderr, "usage: %s [--reps R] [--max-devices G] [--small] [--no-events]\n", argv[0]);
             return 1;
         }
     }
@@ -66,6 +67,7 @@ int main(int argc, char **argv)
         mc_multi *m;
         const double t_create0 = now_s();
         CHECK(mc_multi_create(NULL, G, 0, &m));
+        CHECK(mc_multi_set_timing(m, timing));
         mc_result r;
         CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, 0, 1000, &r));   /* creates the RCCL communicators */
         const double create_s = now_s() - t_create0;

@@ -55,6 +55,9 @@ int mc_multi_set_control_variate(mc_multi *m, int on);
 /* generator of every device (mc_context_set_generator); under MC_RNG_XORWOW device g's lanes run the subsequences
  * subsequence_base + (lanes of devices 0..g-1) + lane, so that no two lanes of the job share a sequence */
 int mc_multi_set_generator(mc_multi *m, int generator, uint64_t subsequence_base);
+/* on != 0 (default): two HIP events per device and call, kernel_ms reported; 0: none, kernel_ms = 0 (the launching thread
+ * reaches the next device sooner; what the legacy symbols use unless MC_VERBOSE is set) */
+int mc_multi_set_timing(mc_multi *m, int on);
 /* MC_REDUCE_RCCL (default; MC_MULTI_REDUCE=host in the environment selects the other) or MC_REDUCE_HOST */
 int mc_multi_set_reduce(mc_multi *m, int mode);
 /* Text of the last failure of an mc_multi_* call on this thread ("" if none). */

@@ -105,6 +105,7 @@ static mc_multi *multi(void)
     int (*set_anti)(mc_multi *, int) = (int (*)(mc_multi *, int))multi_symbol(lib, "mc_multi_set_antithetic");
     int (*set_cv)(mc_multi *, int) = (int (*)(mc_multi *, int))multi_symbol(lib, "mc_multi_set_control_variate");
     int (*set_rng)(mc_multi *, int, uint64_t) = (int (*)(mc_multi *, int, uint64_t))multi_symbol(lib, "mc_multi_set_generator");
+    int (*set_timing)(mc_multi *, int) = (int (*)(mc_multi *, int))multi_symbol(lib, "mc_multi_set_timing");
     multi_last_error = (const char *(*)(void))multi_symbol(lib, "mc_multi_last_error");
     multi_destroy = (void (*)(mc_multi *))multi_symbol(lib, "mc_multi_destroy");
 #ifdef MC_SINGLE_PRECISION
@@ -137,6 +138,8 @@ static mc_multi *multi(void)
         set_cv(g_multi, 1);
     if (getenv("MC_RNG") && !strcmp(getenv("MC_RNG"), "xorwow"))
         set_rng(g_multi, MC_RNG_XORWOW, 0);
+    if (!getenv("MC_VERBOSE"))
+        set_timing(g_multi, 0);
     atexit(drop_multi);
     return g_multi;
 }
