@@ -240,10 +240,12 @@ int mc_basket_greeks_run_f32(mc_context *ctx, const mc_basket_f32 *opt, uint64_t
 int mc_basket_greeks_run_f64(mc_context *ctx, const mc_basket_f64 *opt, uint64_t seed, uint64_t first_path,
                              uint64_t n_paths, mc_result *price, mc_result *delta, mc_result *vega);
 
-/* ---- CVA with its pathwise delta ---------------------------------------------------------
- * d CVA / d S_0 = LGD sum_j dp_j cnd(d1_j) S_j / S_0 on the CVA kernel's stream (reference loop
- * dp/MonteCarloKernel.cu:241-262); not discounted, like the CVA itself (:466).  Plain estimator. */
-typedef struct { mc_result cva, delta; } mc_cva_greeks;
+/* ---- CVA with its pathwise delta and vega -------------------------------------------------
+ * On the CVA kernel's stream (reference loop dp/MonteCarloKernel.cu:241-262), not discounted, like the CVA itself (:466):
+ *   d CVA / d S_0   = LGD sum_j dp_j cnd(d1_j) S_j / S_0
+ *   d CVA / d sigma = LGD sum_j dp_j [ S_j phi(d1_j) sqrt(tau_j) + S_j cnd(d1_j) (W_j - sigma t_j) ],  W_j the Brownian
+ *                     motion at date j (closed-form vega of the exposure + the path's own sensitivity).  Plain estimator. */
+typedef struct { mc_result cva, delta, vega; } mc_cva_greeks;
 int mc_cva_greeks_run_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed, uint64_t first_path,
                           uint64_t n_paths, mc_cva_greeks *out);
 int mc_cva_greeks_run_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed, uint64_t first_path,

@@ -65,7 +65,7 @@ class Greeks(C.Structure):
 
 
 class CvaGreeks(C.Structure):
-    _fields_ = [("cva", Result), ("delta", Result)]
+    _fields_ = [("cva", Result), ("delta", Result), ("vega", Result)]
 
 
 OPTION = {"f32": OptionF32, "f64": OptionF64}

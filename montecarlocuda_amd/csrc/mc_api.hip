@@ -1260,7 +1260,8 @@ template <> struct CvaIn<double> { using type = mc_cva_f64; };
 // reference's rule: t -= dt in Real arithmetic, dates with t < 0 contribute nothing
 // (dp/MonteCarloKernel.cu:234,249-256).
 template <class Real>
-static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaStep<Real>> &tab, CvaArgs<Real> &args)
+static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaStep<Real>> &tab, std::vector<Real> &extra,
+                           CvaArgs<Real> &args)
 {
     const auto &o = v.option;
     if (!finite_pos(o.s) || !finite_pos(o.k) || !finite_pos(o.v) || !finite_pos(o.t) || !std::isfinite((double)o.r))
@@ -1276,6 +1277,8 @@ static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaS
     const double ln_s0 = std::log((double)o.s), ln_k = std::log((double)o.k);
     const double lam = (double)v.defint;
     tab.clear();
+    extra.clear();   // first sqrt(tau_j) of every date, then sigma t_j of every date (the Greeks kernel's extra columns)
+    std::vector<Real> sig_t;
     args.n_bs = 0;
     args.last_intrinsic = 0;
     Real ttm = o.t;
@@ -1302,9 +1305,12 @@ static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaS
             args.last_intrinsic = 1;
         }
         tab.push_back(s);
+        extra.push_back((Real)std::sqrt(tau));
+        sig_t.push_back((Real)((double)o.v * t_now));
         if (tau == 0)
             break;
     }
+    extra.insert(extra.end(), sig_t.begin(), sig_t.end());
     args.bx = (Real)((double)step_vol * sc);
     args.lgd = v.lgd;
     args.strike = o.k;
@@ -1330,29 +1336,29 @@ static int cva_table_ready(mc_context *c, const typename CvaIn<Real>::type *v, h
         return upload_table(c, st, key, nullptr, 0);                  // (orders `st` behind the upload if it is another stream)
     }
     static thread_local std::vector<CvaStep<Real>> tab;
-    if (int rc = build_cva_table<Real>(*v, tab, args)) return rc;
-    const size_t step_bytes = tab.size() * sizeof(CvaStep<Real>);
-    size_t bytes = step_bytes;
-    args.pairs = nullptr;
+    static thread_local std::vector<Real> extra, blob;
+    if (int rc = build_cva_table<Real>(*v, tab, extra, args)) return rc;
+    // one blob: the per-date rows | fp32 only: the rows of date pairs, field by field | the Greeks kernel's extra columns
+    const size_t step_reals = tab.size() * (sizeof(CvaStep<Real>) / sizeof(Real));
+    const size_t pair_reals = sizeof(Real) == 4 ? (size_t)12 * (args.n_bs / 2) : 0;
+    blob.resize(step_reals + pair_reals + extra.size());
+    memcpy(blob.data(), tab.data(), step_reals * sizeof(Real));
     if constexpr (sizeof(Real) == 4) {
-        // fp32: the closed-form rows once more, two dates per row and field by field, so that a date pair's
+        // the closed-form rows once more, two dates per row and field by field, so that a date pair's
         // {g, g'} ... {dp, dp'} are adjacent scalars = ready-made operands of the packed instructions
-        static thread_local std::vector<float> blob;
-        const int n_pairs = args.n_bs / 2;
-        blob.resize(step_bytes / sizeof(float) + (size_t)12 * n_pairs);
-        memcpy(blob.data(), tab.data(), step_bytes);
-        float *row = blob.data() + step_bytes / sizeof(float);
-        for (int q = 0; q < n_pairs; ++q, row += 12) {
+        float *row = blob.data() + step_reals;
+        for (int q = 0; q < args.n_bs / 2; ++q, row += 12) {
             const CvaStep<float> &a = tab[2 * q], &b = tab[2 * q + 1];
             const float vals[12] = {a.g, b.g, a.e1, b.e1, a.e2, b.e2, a.xk, b.xk, a.disc, b.disc, a.dp, b.dp};
             memcpy(row, vals, sizeof vals);
         }
-        bytes = blob.size() * sizeof(float);
-        if (int rc = upload_table(c, st, key, blob.data(), bytes)) return rc;
-        args.pairs = (const float *)((const char *)c->d_table + step_bytes);
-    } else {
-        if (int rc = upload_table(c, st, key, tab.data(), bytes)) return rc;
     }
+    memcpy(blob.data() + step_reals + pair_reals, extra.data(), extra.size() * sizeof(Real));
+    if (int rc = upload_table(c, st, key, blob.data(), blob.size() * sizeof(Real))) return rc;
+    args.pairs = nullptr;
+    if constexpr (sizeof(Real) == 4)
+        args.pairs = (const float *)c->d_table + step_reals;
+    args.extra = (const Real *)c->d_table + step_reals + pair_reals;
     args.steps = (const CvaStep<Real> *)c->d_table;
     c->cva_args.assign((const char *)&args, (const char *)&args + sizeof args);
     return MC_OK;
@@ -1482,10 +1488,12 @@ static int cva_greeks_run(mc_context *c, const typename CvaIn<Real>::type *v, ui
     if (int rc = begin_call(c, c->stream)) return rc;
     CvaArgs<Real> args;
     if (int rc = cva_table_ready<Real>(c, v, c->stream, args)) return rc;
-    mc_result *r[2] = {&out->cva, &out->delta};
+    mc_result *r[3] = {&out->cva, &out->delta, &out->vega};
     const Real inv_spot = (Real)(1.0 / (double)v->option.s);
-    return planes_run(c, 2, 1, first, n, n, 1.0, r, [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
-        cva_greeks_kernel<Real><<<g, GROUP, 0, st>>>(t, args, make_work(seed, s, 0, 0), inv_spot);
+    const Real dt = v->option.t / v->n_grid;   // the table's own dt (build_cva_table)
+    const Real sqrt_dt = (Real)std::sqrt((double)dt);
+    return planes_run(c, 3, 1, first, n, n, 1.0, r, [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
+        cva_greeks_kernel<Real><<<g, GROUP, 0, st>>>(t, args, make_work(seed, s, 0, 0), inv_spot, sqrt_dt);
     });
 }
 extern "C" int mc_cva_greeks_run_f32(mc_context *c, const mc_cva_f32 *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)

@@ -1008,6 +1008,7 @@ struct CvaArgs {
     int last_intrinsic;          // 1: one more date, residual maturity == 0
     Real bx;                     // v sqrt(dt) (times log2 e in f32)
     Real lgd, strike;
+    const Real *extra;           // Greeks only: sqrt(tau_j) for every date, then sigma t_j for every date (2 (n_bs + last_intrinsic) reals)
 };
 
 // Black-Scholes exposure at one date, from the lane's state W and the date's table row.
@@ -1285,10 +1286,13 @@ __global__ __launch_bounds__(GROUP) void basket_greeks_kernel(const Tail /* firs
 // =========================================================================================
 // CVA with its pathwise delta.  CVA = LGD sum_j dp_j C(S_j, tau_j) and S_j is proportional to S_0, so
 //     d CVA / d S_0 = LGD sum_j dp_j Delta_j S_j / S_0,   Delta_j = cnd(d1_j)   (I[S_j > K] on an intrinsic-value date)
-// and S_j cnd(d1_j) is the first term of the exposure the pricing kernel computes anyway.  Plain estimator, one date
-// at a time (a secondary kernel); planes of the pair buffer: 0 = CVA, 1 = delta.
+// and S_j cnd(d1_j) is the first term of the exposure the pricing kernel computes anyway.  Vega: sigma moves the closed
+// form (Black-Scholes vega S phi(d1) sqrt(tau) = A sqrt(tau), A being the shared exponential of bs_exposure) and the
+// path (d S_j / d sigma = S_j (W_j sqrt(dt) - sigma t_j)):
+//     d CVA / d sigma = LGD sum_j dp_j [ A_j sqrt(tau_j) + S_j cnd(d1_j) (W_j sqrt(dt) - sigma t_j) ]
+// Plain estimator, one date at a time (a secondary kernel); planes of the pair buffer: 0 = CVA, 1 = delta, 2 = vega.
 // =========================================================================================
-__device__ __forceinline__ void bs_exposure_delta(float ln2_spot, float W, const CvaStep<float> &st, float &ee, float &s_delta)
+__device__ __forceinline__ void bs_exposure_delta(float ln2_spot, float W, const CvaStep<float> &st, float &ee, float &s_delta, float &s_phi)
 {
     const float spot = __builtin_amdgcn_exp2f(ln2_spot);
     const float d1 = __builtin_fmaf(W, st.g, st.e1), d2 = __builtin_fmaf(W, st.g, st.e2);
@@ -1299,8 +1303,9 @@ __device__ __forceinline__ void bs_exposure_delta(float ln2_spot, float W, const
     const float t2 = A * (k2 * (0.31938153f + k2 * (-0.356563782f + k2 * (1.781477937f + k2 * (-1.821255978f + k2 * 1.330274429f)))));
     s_delta = d1 > 0 ? spot - t1 : t1;            // S cnd(d1)
     ee = s_delta - (d2 > 0 ? st.disc - t2 : t2);  // - K e^{-r tau} cnd(d2)
+    s_phi = A;                                    // S phi(d1)
 }
-__device__ __forceinline__ void bs_exposure_delta(double ln_spot, double W, const CvaStep<double> &st, double &ee, double &s_delta)
+__device__ __forceinline__ void bs_exposure_delta(double ln_spot, double W, const CvaStep<double> &st, double &ee, double &s_delta, double &s_phi)
 {
     const double spot = exp_f64(ln_spot);
     const double d1 = __builtin_fma(W, st.g, st.e1), d2 = __builtin_fma(W, st.g, st.e2);
@@ -1310,18 +1315,22 @@ __device__ __forceinline__ void bs_exposure_delta(double ln_spot, double W, cons
     const double t1 = A * hastings_poly(k1), t2 = A * hastings_poly(k2);
     s_delta = d1 > 0 ? spot - t1 : t1;
     ee = s_delta - (d2 > 0 ? st.disc - t2 : t2);
+    s_phi = A;
 }
 
 template <class Real>
-__global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real inv_spot)
+__global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real inv_spot,
+                                                           Real sqrt_dt)
 {
     stage_tables<Real>();
     constexpr int NPB = npb<Real>::value;
     const uint32_t stride = gridDim.x * GROUP;
     const int n_dates = o.n_bs + o.last_intrinsic;
-    double acc[4] = {0, 0, 0, 0};
+    typedef const __attribute__((address_space(4))) Real *cptr;
+    const cptr sqrt_tau = (cptr)o.extra, sig_t = sqrt_tau + n_dates;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
-        Real W = 0, cva = 0, delta = 0, z[NPB];
+        Real W = 0, cva = 0, delta = 0, vega = 0, z[NPB];
         for (int j = 0; j < n_dates; ++j) {   // wave-uniform: table rows through scalar loads
             if (j % NPB == 0)
                 block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)(j / NPB), 3u /*MC_DOMAIN_CVA*/, w.seed_lo, w.seed_hi, z);
@@ -1332,27 +1341,32 @@ __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first a
                 zz = (j % NPB == q) ? z[q] : zz;
             W += zz;
             const Real ln_spot = fma_r(W, o.bx, st.xk);
-            Real ee, sd;
+            Real ee, sd, sphi;
             if (j < o.n_bs) {
-                bs_exposure_delta(ln_spot, W, st, ee, sd);
-            } else {   // residual maturity exactly 0: intrinsic value, derivative I[S > K] S
+                bs_exposure_delta(ln_spot, W, st, ee, sd, sphi);
+            } else {   // residual maturity exactly 0: intrinsic value, derivative I[S > K] S, no closed-form vega
                 const Real spot = exp_model(ln_spot);
                 const bool itm = spot > o.strike;
                 ee = itm ? spot - o.strike : (Real)0;
                 sd = itm ? spot : (Real)0;
+                sphi = 0;
             }
             cva = fma_r(st.dp, ee, cva);
             delta = fma_r(st.dp, sd, delta);
+            vega = fma_r(st.dp, fma_r(sphi, sqrt_tau[j], sd * fma_r(W, sqrt_dt, -sig_t[j])), vega);
         }
-        const double c = (double)(cva * o.lgd), dl = (double)(delta * o.lgd * inv_spot);
+        const double c = (double)(cva * o.lgd), dl = (double)(delta * o.lgd * inv_spot), vg = (double)(vega * o.lgd);
         acc[0] += c, acc[1] = __builtin_fma(c, c, acc[1]);
         acc[2] += dl, acc[3] = __builtin_fma(dl, dl, acc[3]);
+        acc[4] += vg, acc[5] = __builtin_fma(vg, vg, acc[5]);
     }
-    group_sum2(acc[0], acc[1]);
-    group_sum2(acc[2], acc[3]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        group_sum2(acc[2 * q], acc[2 * q + 1]);
     const tail_ptr t = late_tail(acc[0]);
-    publish_pair(t, 0, acc[0], acc[1]);
-    publish_pair(t, 1, acc[2], acc[3]);
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        publish_pair(t, q, acc[2 * q], acc[2 * q + 1]);
     arrive_and_finish(t);
 }
 

@@ -220,11 +220,11 @@ class Engine:
         return _estimate(price), [_estimate(x) for x in delta], [_estimate(x) for x in vega]
 
     def cva_greeks(self, c, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
-        """(cva, delta) Estimates: the CVA and its pathwise derivative with respect to the spot."""
+        """(cva, delta, vega) Estimates: the CVA and its pathwise derivatives with respect to spot and volatility."""
         g = _lib.CvaGreeks()
         check(getattr(lib(), f"mc_cva_greeks_run_{precision}")(self._ctx, C.byref(_as_cva(precision, c)), seed, first_path,
                                                                 n_paths, C.byref(g)))
-        return _estimate(g.cva), _estimate(g.delta)
+        return _estimate(g.cva), _estimate(g.delta), _estimate(g.vega)
 
     def basket(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:
         h = _BasketHolder(precision, b)

@@ -571,20 +571,24 @@ void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL
     FN(dev_finish)(sum, sum2, n_paths, 1.0, out);
 }
 
-/* CVA with its pathwise delta: the loop of orc_dev_cva (plain estimator) carrying
- * d CVA / d S_0 = LGD sum_j dp_j Delta_j S_j / S_0, Delta_j = cnd(d1_j) of the reference's closed form
- * (dp/MonteCarloKernel.cu:110-129), I[S_j > K] on a date with residual maturity exactly 0.  out[0] = CVA, out[1] = delta. */
+/* CVA with its pathwise delta and vega: the loop of orc_dev_cva (plain estimator) carrying
+ *   d CVA / d S_0   = LGD sum_j dp_j Delta_j S_j / S_0,   Delta_j = cnd(d1_j) of the reference's closed form
+ *                     (dp/MonteCarloKernel.cu:110-129), I[S_j > K] on a date with residual maturity exactly 0;
+ *   d CVA / d sigma = LGD sum_j dp_j [ S_j phi(d1_j) sqrt(tau_j) + Delta_j S_j (W_j sqrt(dt) - sigma t_j) ],
+ *                     W_j = z_1 + ... + z_j (the closed form's vega + the path's own sensitivity to sigma).
+ * out[0] = CVA, out[1] = delta, out[2] = vega. */
 void FN(orc_dev_cva_greeks)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid, uint64_t seed,
                             uint64_t first_path, uint64_t n_paths, orc_result *out)
 {
     const REAL dt = t0 / n_grid;
     const REAL step_drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)dt);
     const REAL step_vol = (REAL)((double)v * sqrt((double)dt));
-    double acc[4] = {0, 0, 0, 0};
+    const REAL sqrt_dt = (REAL)sqrt((double)dt);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
     REAL z[ORC_NPB];
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t path = first_path + i;
-        REAL spot = s0, ttm = t0, cva = 0, delta = 0;
+        REAL spot = s0, ttm = t0, cva = 0, delta = 0, vega = 0, wsum = 0;
         for (int j = 1; j <= n_grid; j++) {
             double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
             REAL dpd = (REAL)(-exp(-(double)defint * t_prev) * expm1(-(double)defint * (t_now - t_prev)));
@@ -595,7 +599,8 @@ void FN(orc_dev_cva_greeks)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defin
             if (idx % ORC_NPB == 0)
                 FN(orc_dev_normals)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
             spot = spot * EXP_R(step_drift + step_vol * z[idx % ORC_NPB]);
-            REAL ee, sd;
+            wsum += z[idx % ORC_NPB];
+            REAL ee, sd, sphi = 0;
             if (ttm == 0) {
                 ee = spot > k ? spot - k : 0;
                 sd = spot > k ? spot : 0;
@@ -605,15 +610,18 @@ void FN(orc_dev_cva_greeks)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defin
                 REAL d1 = (REAL)(num / (double)(v * sqrt_t));
                 ee = FN(orc_bs_call)(spot, k, r, v, ttm);
                 sd = spot * FN(orc_cnd)(d1);
+                sphi = spot * (REAL)0.39894228040143267793994605993438 * EXP_R((REAL)(-0.5 * (double)d1 * (double)d1));
             }
             cva += dpd * ee;
             delta += dpd * sd;
+            vega += dpd * (sphi * SQRT_R(ttm) + sd * (wsum * sqrt_dt - (REAL)((double)v * t_now)));
         }
-        double c = (double)(cva * lgd), dl = (double)(delta * lgd * (REAL)(1.0 / (double)s0));
-        acc[0] += c, acc[1] += c * c, acc[2] += dl, acc[3] += dl * dl;
+        double c = (double)(cva * lgd), dl = (double)(delta * lgd * (REAL)(1.0 / (double)s0)), vg = (double)(vega * lgd);
+        acc[0] += c, acc[1] += c * c, acc[2] += dl, acc[3] += dl * dl, acc[4] += vg, acc[5] += vg * vg;
     }
     FN(dev_finish)(acc[0], acc[1], n_paths, 1.0, out);
     FN(dev_finish)(acc[2], acc[3], n_paths, 1.0, out + 1);
+    FN(dev_finish)(acc[4], acc[5], n_paths, 1.0, out + 2);
 }
 
 #undef FN

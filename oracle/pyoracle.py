@@ -282,10 +282,10 @@ def dev_basket_greeks(X, b, seed, first, n):
 
 
 def dev_cva_greeks(X, c, seed, first, n):
-    """(cva, delta) result dicts of the CVA-delta twin."""
-    r = (OrcResult * 2)()
+    """(cva, delta, vega) result dicts of the CVA-Greeks twin."""
+    r = (OrcResult * 3)()
     f = getattr(lib(), f"orc_dev_cva_greeks_{X}")
-    f.argtypes = [CT[X]] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcResult * 2)]
+    f.argtypes = [CT[X]] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcResult * 3)]
     f.restype = None
     f(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"], c["lgd"], c["n_grid"], seed, first, n, C.byref(r))
     return [x.as_dict() for x in r]

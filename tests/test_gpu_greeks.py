@@ -110,18 +110,21 @@ def test_basket_greeks_vs_closed_form_and_finite_differences(mc, eng):
 def test_cva_delta_matches_oracle(mc, eng, po, X, n_grid):
     c = dict(CVA0, n_grid=n_grid)
     n = 5001
-    cva, delta = eng.cva_greeks(c, n, SEED, 11, X)
-    oc, od = po.dev_cva_greeks(X, c, SEED, 11, n)
+    cva, delta, vega = eng.cva_greeks(c, n, SEED, 11, X)
+    oc, od, ov = po.dev_cva_greeks(X, c, SEED, 11, n)
     rel = 4 * TOL[X]["rel"]
     same(cva, oc, rel)
     same(delta, od, rel)
+    # the path term of the vega changes sign from path to path: sums of comparable magnitudes cancel
+    assert vega.n == ov["n"] and vega.sum == pytest.approx(ov["sum"], rel=40 * rel, abs=n * 20 * TOL[X]["cva"])
+    assert vega.sum2 == pytest.approx(ov["sum2"], rel=40 * rel)
     assert cva.sum == pytest.approx(eng.cva(c, n, SEED, 11, X).sum, rel=rel)     # the pricing kernel's CVA
 
 
 def test_cva_delta_vs_analytic_and_finite_differences(mc, eng):
     c = dict(CVA0, n_grid=64)
     n = 2 * 10 ** 6
-    cva, delta = eng.cva_greeks(c, n, SEED, 0, "f64")
+    cva, delta, vega = eng.cva_greeks(c, n, SEED, 0, "f64")
     # E[CVA] = LGD C0(S0) sum_j dp_j e^{r t_j}  =>  d/dS0 = LGD N(d1) sum_j dp_j e^{r t_j}
     dt = c["t"] / c["n_grid"]
     weight = sum((math.exp(-c["defint"] * dt * (j - 1)) - math.exp(-c["defint"] * dt * j)) * math.exp(c["r"] * dt * j)
@@ -132,6 +135,14 @@ def test_cva_delta_vs_analytic_and_finite_differences(mc, eng):
     h = 0.05
     fd = (eng.cva(dict(c, s=c["s"] + h), n, SEED, 0, "f64").expected - eng.cva(dict(c, s=c["s"] - h), n, SEED, 0, "f64").expected) / (2 * h)
     assert abs(fd - delta.expected) < 4 / 1.96 * delta.confidence + 1e-6
+    # vega: d/dsigma of LGD C0(sigma) sum_j dp_j e^{r t_j} = LGD S sqrt(T) phi(d1) sum_j ..., and central differences in sigma
+    want_v = c["lgd"] * bs_greeks(c)[1] * weight
+    assert abs(vega.expected - want_v) < 3.5 / 1.96 * vega.confidence + 1e-5, (vega.expected, want_v)
+    hv = 1e-3
+    fd = (eng.cva(dict(c, v=c["v"] + hv), n, SEED, 0, "f64").expected - eng.cva(dict(c, v=c["v"] - hv), n, SEED, 0, "f64").expected) / (2 * hv)
+    assert abs(fd - vega.expected) < 4 / 1.96 * vega.confidence + 2e-4, (fd, vega.expected)
+    f32 = eng.cva_greeks(c, n, SEED, 0, "f32")
+    assert abs(f32[2].expected - want_v) < 3.5 / 1.96 * f32[2].confidence + 1e-4
 
 
 def test_greeks_run_the_same_through_both_finish_forms(mc):
