@@ -240,3 +240,40 @@ def test_timing_off_returns_the_same_bits_through_pinned_memory(mc):
         t = sorted(timed.vanilla(VAN, 10 ** 6, SEED, 0, "f32").wall_ms for _ in range(200))[100]
         d = sorted(direct.vanilla(VAN, 10 ** 6, SEED, 0, "f32").wall_ms for _ in range(200))[100]
         assert d < t * 1.05, (d, t)
+
+
+def test_mixed_call_sequence_keeps_the_tickets_consistent(mc):
+    """Every kind of call shares the context's ticket block (one-dimensional grids, the Greeks' multi-plane and
+    two-dimensional grids, multi-segment ranges, XORWOW launches, timed and untimed returns).  A long mixed sequence on
+    ONE context must give, call by call, the bits of the two-launch form on another context: a ticket left non-zero or
+    a stale pair would show at once."""
+    b5 = basket_inputs(mc, 5, "f64", rho=0.3)
+    b20 = basket_inputs(mc, 20, "f32", rho=0.3)
+    c = dict(CVA0, n_grid=40)
+
+    def sequence(e):
+        out = []
+        for rep in range(12):
+            n = 50_000 + 977 * rep
+            out.append(e.vanilla(VAN, n, SEED, rep, "f32").sum)
+            out += [g.sum for g in e.vanilla_greeks_lr(VAN, n, SEED, rep, "f64")]
+            pr, dl, vg = e.basket_greeks(b5, n // 5, SEED, rep, "f64")
+            out += [pr.sum] + [g.sum for g in dl + vg]
+            out.append(e.cva(c, n // 8, SEED, (1 << 32) - 1000 * rep - 7, "f64").sum)      # two launches
+            e.set_timing(rep % 2 == 0)
+            out.append(e.basket(b20, n // 4, SEED, rep, "f32").sum)
+            out += [g.sum for g in e.cva_greeks(c, n // 8, SEED, rep, "f32")]
+            e.set_generator("xorwow", 7)
+            out.append(e.vanilla(VAN, n, SEED, rep, "f64").sum)
+            out.append(e.cva(c, n // 8, SEED, rep, "f32").sum)
+            e.set_generator("philox")
+            e.set_antithetic(rep % 3 == 0)
+            out.append(e.vanilla(VAN, n, SEED, 3 * rep + 1, "f64").sum)
+            e.set_antithetic(False)
+        e.set_timing(True)
+        return out
+    with mc.Engine(0, blocks=37) as fused, mc.Engine(0, blocks=37) as two:
+        two.set_finish(False)
+        a, b = sequence(fused), sequence(two)
+        assert len(a) == len(b) > 200 and a == b
+        assert sequence(fused) == a
