@@ -109,10 +109,17 @@ def cpu_baseline(prod, X, inputs, seconds):
     t0 = time.perf_counter(); run(n); dt = time.perf_counter() - t0   # calibration pass
     n = int(min(2 ** 31 - 1, max(n, n * seconds / max(dt, 1e-3))))
     t0 = time.perf_counter(); run(n); dt = time.perf_counter() - t0
-    return {"value": n * per_unit / dt, "unit": unit, "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": f"{n} paths of the same workload in {dt:.1f} s, single thread (the reference is single-threaded: "
-                      f"MonteCarloHost.c:185-229), gcc -O2 -ffp-contract=off",
-            "host_cores_available": len(os.sched_getaffinity(0))}
+    out = {"value": n * per_unit / dt, "unit": unit, "cores": 1, "kind": "reference" if use_ref else "port",
+           "sample": f"{n} paths of the same workload in {dt:.1f} s, single thread (the reference is single-threaded: "
+                     f"MonteCarloHost.c:185-229), gcc -O2 -ffp-contract=off",
+           "host_cores_available": len(os.sched_getaffinity(0))}
+    if prod == "vanilla" and po.ref_available(X, 3, "_O0"):
+        # footnote: the reference's own Makefile compiles the host file without -O (Makefile:157,252-253)
+        n0 = max(1000, int(n * min(1.0, 3.0 / max(dt, 1e-3))))
+        t0 = time.perf_counter(); po.Ref(X, 3, "_O0").vanilla(inputs, n0, 12345); dt0 = time.perf_counter() - t0
+        out["value_at_O0"] = n0 / dt0
+        out["O0_note"] = f"the same object built with gcc -O0, {n0} paths in {dt0:.1f} s (the reference Makefile's optimisation level)"
+    return out
 
 
 def cpu_all_cores(seconds=2.0):

@@ -308,8 +308,8 @@ def dev_cva(X, c, seed, first, n, want_paths=True, antithetic=False):
 # ------------------------------------------------------------------------------------------
 # compiled reference (oracle/_ref)
 # ------------------------------------------------------------------------------------------
-def ref_available(X="f64", n=3) -> bool:
-    return os.path.exists(os.path.join(REF_DIR, f"libref_{X}_n{n}.so"))
+def ref_available(X="f64", n=3, opt="") -> bool:
+    return os.path.exists(os.path.join(REF_DIR, f"libref_{X}_n{n}{opt}.so"))
 
 
 def ref_types(X, n):
@@ -336,9 +336,10 @@ def ref_types(X, n):
 class Ref:
     """The unmodified reference host object for one (precision, N), with time() pinned."""
 
-    def __init__(self, X="f64", n=3):
+    def __init__(self, X="f64", n=3, opt=""):
+        """opt = "" (the -O2 build) or "_O0" (the reference Makefile's own optimisation level; N = 3 only)."""
         self.X, self.n = X, n
-        self.L = C.CDLL(os.path.join(REF_DIR, f"libref_{X}_n{n}.so"))
+        self.L = C.CDLL(os.path.join(REF_DIR, f"libref_{X}_n{n}{opt}.so"))
         self.OptionData, self.MultiOptionData, self.OptionValue, self.CVA = ref_types(X, n)
         R = CT[X]
         self.L.mcref_set_seed.argtypes = [C.c_uint]

@@ -142,3 +142,15 @@ def test_factor_from_cov_bitwise(po):
             g = rng.standard_normal((4, 9)) * 0.2
             v, corr, a, bad = po.factor_from_cov(X, g @ g.T)
             assert (po.Ref(X, 4).chol(corr.tolist()) == a).all() and bad == 0
+
+
+def test_reference_at_O0_gives_the_same_bits(po):
+    """The reference's own Makefile builds the host file without -O (Makefile:157,252-253); the goldens were produced at
+    -O2 -ffp-contract=off.  Where the compiled reference is present, its -O0 build must return the same bits (SURVEY 8c
+    "Determinism") -- bench.py times that build as the -O0 footnote of the CPU baseline."""
+    if not po.ref_available("f64", 3, "_O0"):
+        pytest.skip("oracle/_ref -O0 build not present")
+    for c in load_golden("ref_mc.json")["cases"]:
+        if c["kind"] == "vanilla" and c["paths"] <= 100000:
+            e, ci = po.Ref(c["X"], 3, "_O0").vanilla(c["opt"], c["paths"], c["seed"])
+            assert (e, ci) == (fromhex(c["expected"]), fromhex(c["confidence"])), c
