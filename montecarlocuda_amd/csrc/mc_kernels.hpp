@@ -67,6 +67,25 @@ typedef float f2 __attribute__((ext_vector_type(2)));  // one VGPR pair: v_pk_{f
 
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
+// clamp(a + b, 0, 1) for BOTH halves of a packed pair in ONE instruction: v_pk_add_f32 with the output clamp.  hipcc
+// never selects it (a packed min/max pair becomes two v_pk ops plus two scalar v_max ... clamp), hence the asm.  The
+// fp32 vanilla payoffs max(2^x - kappa, 0) of two paths cost one issue slot this way instead of two v_sub_f32 ... clamp
+// (63 -> 61 VALU instructions per Philox block).  Not used in the basket kernels: there the "v" operands push wave-uniform
+// constants out of the scalar registers and cost more v_readlane than the packing saves (145 -> 152 at n = 4).
+__device__ __forceinline__ f2 pk_add_clamp01(f2 a, f2 b)
+{
+#ifdef MC_AB_SCALAR_CLAMP
+    return (f2){clamp01(a.x + b.x), clamp01(a.y + b.y)};
+#else
+    // s_nop 0: gfx950 needs one wait state between a transcendental (the v_exp_f32 that produced `a`) and a VALU
+    // instruction reading its result; hipcc inserts it for its own instructions but does not look inside an asm
+    // (without it the antithetic kernel read a stale exponential: caught by test_vanilla_many_trips_vs_oracle)
+    f2 r;
+    asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+
 // The 4 scaled payoffs of one Philox block.  Box-Muller pair A = words (x, y), pair B = words
 // (z, w); values are kept as {A, B} register pairs so the uniform scaling, the radius scaling and
 // the exponent fma issue as packed-f32 instructions (2 results per 4-cycle issue slot):
@@ -89,17 +108,14 @@ __device__ __forceinline__ void vanilla_unit_pk(Rng &rng, const VanillaF32 &o, c
     const f2 a = {o.a2k, o.a2k};
     const f2 yc = __builtin_elementwise_fma(c, rad, a);
     const f2 ys = __builtin_elementwise_fma(s, rad, a);
-    pc.x = clamp01(__builtin_amdgcn_exp2f(yc.x) - o.kappa_k);
-    pc.y = clamp01(__builtin_amdgcn_exp2f(yc.y) - o.kappa_k);
-    ps.x = clamp01(__builtin_amdgcn_exp2f(ys.x) - o.kappa_k);
-    ps.y = clamp01(__builtin_amdgcn_exp2f(ys.y) - o.kappa_k);
+    const f2 neg_kappa = {-o.kappa_k, -o.kappa_k};
+    pc = pk_add_clamp01((f2){__builtin_amdgcn_exp2f(yc.x), __builtin_amdgcn_exp2f(yc.y)}, neg_kappa);
+    ps = pk_add_clamp01((f2){__builtin_amdgcn_exp2f(ys.x), __builtin_amdgcn_exp2f(ys.y)}, neg_kappa);
     if (ANTI) {
         const f2 mc_ = __builtin_elementwise_fma(-c, rad, a);
         const f2 ms_ = __builtin_elementwise_fma(-s, rad, a);
-        pc.x += clamp01(__builtin_amdgcn_exp2f(mc_.x) - o.kappa_k);
-        pc.y += clamp01(__builtin_amdgcn_exp2f(mc_.y) - o.kappa_k);
-        ps.x += clamp01(__builtin_amdgcn_exp2f(ms_.x) - o.kappa_k);
-        ps.y += clamp01(__builtin_amdgcn_exp2f(ms_.y) - o.kappa_k);
+        pc += pk_add_clamp01((f2){__builtin_amdgcn_exp2f(mc_.x), __builtin_amdgcn_exp2f(mc_.y)}, neg_kappa);
+        ps += pk_add_clamp01((f2){__builtin_amdgcn_exp2f(ms_.x), __builtin_amdgcn_exp2f(ms_.y)}, neg_kappa);
     }
 }
 
