@@ -142,8 +142,8 @@ int mc_context_set_timing(mc_context *ctx, int on);
  * sequence (tests); cuRAND 7.5's own seeding is not in the reference tree, so the reference's exact stream stays
  * "parity unpinned".  Consequences of a per-lane stream: the sample depends on (seed, subsequence_base, grid size,
  * position in the range) instead of the global path index, first_path only places the range; a call must fit one
- * launch (<= 2^31 units); ranks of a multi-GPU job need disjoint subsequence bases (mc_multi_* sets them); the generic
- * kernels run (about half the Philox paths' speed); Greeks are Philox-only.  Subsequence numbers stay below 2^48. */
+ * launch (<= 2^31 units); ranks of a multi-GPU job need disjoint subsequence bases (mc_multi_* sets them); vanilla
+ * calls run at Philox speed, baskets on the generic kernel; Greeks are Philox-only.  Subsequence numbers stay below 2^48. */
 enum { MC_RNG_PHILOX = 0, MC_RNG_XORWOW = 1 };
 int mc_context_set_generator(mc_context *ctx, int generator, uint64_t subsequence_base);
 /* The generator alone (tests): words_each consecutive 32-bit outputs of each of the XORWOW subsequences

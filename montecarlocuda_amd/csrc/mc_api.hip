@@ -692,7 +692,12 @@ template <> struct VanillaTraits<float> {
     static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
                            hipStream_t st)
     {
-        if (anti)
+        if (w.xorwow) {
+            if (anti)
+                launch_sim(prof, vanilla_f32_kernel<true, RngXorwow>, grid, st, tail, k, w);
+            else
+                launch_sim(prof, vanilla_f32_kernel<false, RngXorwow>, grid, st, tail, k, w);
+        } else if (anti)
             launch_sim(prof, vanilla_f32_kernel<true>, grid, st, tail, k, w);
         else
             launch_sim(prof, vanilla_f32_kernel<false>, grid, st, tail, k, w);
@@ -726,7 +731,12 @@ template <> struct VanillaTraits<double> {
     static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
                            hipStream_t st)
     {
-        if (anti)
+        if (w.xorwow) {
+            if (anti)
+                launch_sim(prof, vanilla_kernel<Opt, double, true, RngXorwow>, grid, st, tail, k, w);
+            else
+                launch_sim(prof, vanilla_kernel<Opt, double, false, RngXorwow>, grid, st, tail, k, w);
+        } else if (anti)
             launch_sim(prof, vanilla_kernel<Opt, double, true>, grid, st, tail, k, w);
         else
             launch_sim(prof, vanilla_kernel<Opt, double, false>, grid, st, tail, k, w);
@@ -779,7 +789,11 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         w.xorwow = c->d_xorwow;
         const int g = grid_for(c, one[0].count);
         Tail t = make_tail(c, g, scale1, scale2, n, d_triple);
-        xw<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
+        if (!out && first % NPB == 0 && end % NPB == 0) {   // whole units only (what the legacy symbols ask for): the hot kernel,
+            ProfileScope prof(c);                           // same lanes, same draws, same sums up to fp32 partial-sum order
+            T::launch_hot(prof, anti, k, w, t, g, st);
+        } else
+            xw<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
         return finish_call(c, t, g, st);
     }
     std::vector<Segment> segs;

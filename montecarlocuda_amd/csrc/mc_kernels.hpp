@@ -151,7 +151,7 @@ __device__ __forceinline__ void vanilla_unit(Rng &rng, const VanillaF64 &o, cons
 // trip at the end is peeled.
 constexpr uint32_t VANILLA_F32_FLUSH = 8;
 
-template <bool ANTI>
+template <bool ANTI, class Rng = RngPhilox>
 __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const VanillaF32 o, const Work w)
 {
     const uint32_t stride = gridDim.x * GROUP;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first 
     double acc_s = 0.0, acc_q = 0.0;
     f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
     uint32_t c0 = w.unit_lo + gtid;
-    RngPhilox rng(w);   // stateless
+    Rng rng(w);   // Philox: stateless; XORWOW: the lane's sequence (units ascending, as the masked kernel draws them)
     for (uint32_t trip = 0; trip < full_trips; ++trip, c0 += stride) {
         f2 pc, ps;
         vanilla_unit_pk<ANTI>(rng, o, w, c0, pc, ps);
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first 
 }
 
 // f64 (and the generic form): each unit's payoffs go straight into the fp64 accumulators.
-template <class Opt, class Real, bool ANTI>
+template <class Opt, class Real, bool ANTI, class Rng = RngPhilox>
 __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w)
 {
     stage_tables<Real>();
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Tail /* first argu
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
-    RngPhilox rng(w);   // stateless
+    Rng rng(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p[NPB];
         vanilla_unit<ANTI>(rng, o, w, w.unit_lo + i, p);

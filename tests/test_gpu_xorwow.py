@@ -123,3 +123,22 @@ def test_xorwow_contract(mc):
         with pytest.raises(mc.McError):
             e.set_generator("xorwow", 2 ** 48)
             e.vanilla(VAN, 1000, SEED, 0, "f64")
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_xorwow_aligned_ranges_run_the_hot_kernels(mc, po, X):
+    """Whole-unit ranges (what the legacy symbols ask for) run the hot vanilla kernels in XORWOW mode too: same lanes and
+    draws as the masked form, so the sums agree with the oracle's XORWOW twin and with an unaligned neighbour range."""
+    with mc.Engine(0, blocks=2) as e:
+        e.set_generator("xorwow", 3)
+        for anti in (False, True):
+            e.set_antithetic(anti)
+            n = 400_000
+            est = e.vanilla(VAN, n, SEED, 0, X)
+            with po.xorwow_mode(SEED, 3, 512, 0):
+                _, o = po.dev_vanilla(X, VAN, SEED, 0, n, want_paths=False, antithetic=anti)
+            assert est.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"]) and est.sum2 == pytest.approx(o["sum2"], rel=TOL[X]["rel"])
+            paths = e.vanilla_paths(VAN, 4000, SEED, 0, X).astype(np.float64)       # the masked form, same start
+            with po.xorwow_mode(SEED, 3, lanes_of(e, 4000 // NPB[X]), 0):
+                want, _ = po.dev_vanilla(X, VAN, SEED, 0, 4000, antithetic=anti)
+            assert np.abs(paths - want.astype(np.float64)).max() <= TOL[X]["pay"] * VAN["s"]
