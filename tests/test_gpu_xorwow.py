@@ -142,3 +142,26 @@ def test_xorwow_aligned_ranges_run_the_hot_kernels(mc, po, X):
             with po.xorwow_mode(SEED, 3, lanes_of(e, 4000 // NPB[X]), 0):
                 want, _ = po.dev_vanilla(X, VAN, SEED, 0, 4000, antithetic=anti)
             assert np.abs(paths - want.astype(np.float64)).max() <= TOL[X]["pay"] * VAN["s"]
+
+
+def test_legacy_symbols_switch_generator_through_MC_RNG():
+    """MC_RNG=xorwow reaches dev_vanillaOpt / dev_cvaEquityOption (legacy_abi.c): another sample than Philox's, the same
+    one on every run (the reference's fixed seed, dp/MonteCarloKernel.cu:289), also through the multi-device path."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "drivers", "vanillaOpt_f32")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe)], stdout=subprocess.DEVNULL)
+
+    def gpu_price(env):
+        out = subprocess.run([exe, "80", "--no-cpu"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+        assert out.returncode == 0, out.stdout + out.stderr
+        nums = [float(x) for x in re.findall(r"^-?\d+\.\d+", out.stdout, flags=re.M)]
+        return nums[0], nums[1]
+    philox, xorwow, again = gpu_price({}), gpu_price({"MC_RNG": "xorwow"}), gpu_price({"MC_RNG": "xorwow"})
+    assert xorwow == again and xorwow != philox
+    assert abs(xorwow[0] - BS_EXACT) < 3.5 / 1.96 * xorwow[1] and abs(xorwow[0] - philox[0]) < 5 / 1.96 * xorwow[1]
+    multi = gpu_price({"MC_RNG": "xorwow", "MC_DEVICES": "0"})
+    assert multi == xorwow
