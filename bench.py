@@ -348,11 +348,13 @@ def main():
         if pending[1] - pending[0] >= max(1, args.bucket):
             flush_bucket()
 
-    def drain():
+    def drain(host_sync=True):
         flush_bucket()
         for w in works:
-            w.wait()
+            w.wait()          # stream-level: torch's stream waits for RCCL's
         works.clear()
+        if not host_sync:     # the caller's barrier() follows at once and synchronises (one host wake-up instead of two)
+            return
         if args.poll:
             # poll the launch streams (and torch's) from user space until the work is done, THEN synchronise
             while not (all(e_.idle() for e_ in engines) and stream.query()):
@@ -386,7 +388,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(W, W + K):
         step(i)
-    drain()
+    drain(host_sync=not grouped)   # N > 1: RCCL's barrier queues right behind the last bucket's all-reduce
     barrier()
     elapsed = time.perf_counter() - t0
     samples, kernel_ms_total = eng.profile_read()
