@@ -1102,6 +1102,9 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
 //                      LDS-staged form wins; 17..32: one kernel per multiple of 4 on the zero-padded buffer,
 //                      +19...+39 % over the generic kernel
 //   33..64 assets      generic tiled kernel, normals in LDS (basket_dyn_kernel, basket_dyn_f32_kernel)
+//   MC_BASKET_MFMA=1   fp64, 13..16 assets: the mat-vec as v_mfma_f64_16x16x4_f64 (basket_mfma_f64_kernel).  Off by
+//                      default: 5-6 % slower than the tiled kernel, the f64 matrix instruction does not run beside
+//                      the vector pipe on gfx950 (profiles/r02_mfma_basket.log)
 // MC_BASKET_STATIC_MAX_F32 / _F64 and MC_BASKET_TILED_MIN (read once per process) move the limits for
 // experiments and for the tests that compare the families.
 static int env_int(const char *name, int fallback, int lo, int hi)
@@ -1116,6 +1119,14 @@ static int basket_static_max()
     static const int limit = sizeof(Real) == 4 ? env_int("MC_BASKET_STATIC_MAX_F32", 12, 0, MC_MAX_ASSETS)
                                                : env_int("MC_BASKET_STATIC_MAX_F64", 8, 0, MC_MAX_ASSETS);
     return limit;
+}
+static bool basket_mfma()
+{
+#ifndef MC_AB_MFMA_DEFAULT
+#define MC_AB_MFMA_DEFAULT 0
+#endif
+    static const int on = env_int("MC_BASKET_MFMA", MC_AB_MFMA_DEFAULT, 0, 1);
+    return on != 0;
 }
 static int basket_tiled_min()
 {
@@ -1137,7 +1148,17 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     const size_t n_tiles = (size_t)8 * nb * (nb + 1);
     const double sc = exp_scale<Real>();
     const double sqrt_t = std::sqrt((double)o.t);
-    std::vector<Real> host(n_tiles + 3 * (size_t)np, (Real)0);
+    // fp64, 13..16 assets: the same matrix once more as the A operands of the matrix-core kernel (basket_mfma_f64_kernel:
+    // a4[s][lane] = M[lane & 15][k(s, lane >> 4)], k(s, q) = 2 q + (s & 1) + 8 (s >> 1))
+    const bool with_a4 = sizeof(Real) == 8 && np == 16;
+    std::vector<Real> host(n_tiles + 3 * (size_t)np + (with_a4 ? 256 : 0), (Real)0);
+    if (with_a4)
+        for (int s4 = 0; s4 < 4; ++s4)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int a = lane & 15, b = 2 * (lane >> 4) + (s4 & 1) + 8 * (s4 >> 1);
+                if (a < n && b <= a)
+                    host[n_tiles + 3 * (size_t)np + 64 * s4 + lane] = (Real)((double)o.v[a] * sqrt_t * (double)o.p[a * n + b] * sc);
+            }
     size_t t = 0;
     for (int A = 0; A < nb; ++A)
         for (int c4 = 0; c4 <= A; ++c4, t += 16)
@@ -1200,6 +1221,10 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
             kernel = c->antithetic ? basket_dyn_f32_kernel<true> : basket_dyn_f32_kernel<false>;
             lds *= 2;  // the lane's column holds packed pairs
         }
+    } else if (sizeof(Real) == 8 && with_a4 && basket_mfma()) {  // fp64, 13..16 assets: the mat-vec on the matrix cores
+        lds = 0;
+        if constexpr (sizeof(Real) == 8)
+            kernel = c->antithetic ? basket_mfma_f64_kernel<true> : basket_mfma_f64_kernel<false>;
     } else if (sizeof(Real) == 8 && n >= basket_tiled_min() && n <= 32) {  // fp64: normals in registers, no dynamic LDS
         lds = 0;
         // 9..16 assets: one kernel per size; 17..32: one per multiple of 4 (the buffer is zero-padded to whole tiles,
@@ -1625,13 +1650,16 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         const int rc = enqueue(c->stream, c->d_triple);
         c->direct_target = nullptr;
         if (rc) return rc;
-        // poll for up to ~2 s of spinning, then fall back to a blocking wait (a kernel that failed never writes)
+        // poll from user space for the first 2 ms (the calls that care about 20 us are shorter than that), then hand the
+        // core back and wait in the runtime (also the way out when a kernel failed and never writes)
         bool seen = false;
-        for (uint64_t spin = 0; spin < (1ull << 31); ++spin) {
+        for (uint32_t spin = 0;; ++spin) {
             if (__atomic_load_n((const uint64_t *)(c->h_direct + 2), __ATOMIC_ACQUIRE) != __builtin_bit_cast(uint64_t, DIRECT_SENTINEL)) {
                 seen = true;
                 break;
             }
+            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - wall0 > std::chrono::milliseconds(2))
+                break;
             __builtin_ia32_pause();
         }
         if (!seen) {

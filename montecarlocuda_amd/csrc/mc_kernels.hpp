@@ -999,6 +999,124 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const Tail /* f
     finish_group(acc_s, acc_q);
 }
 
+// ---- 16-asset fp64 basket with the correlation step on the matrix cores ------------------------
+// The Cholesky step x = base + M g of 64 paths is a 16 x 16 by 16 x 64 product (BASELINE.json north_star: "MFMA only if
+// the basket Cholesky step is cast as a dense small-matrix contraction"): four column blocks of 16 paths, each
+// 4 x v_mfma_f64_16x16x4_f64, take the 136 v_fma_f64 per path of the mat-vec out of the vector pipe, which is what the
+// kernel is bound by.  No transposition through LDS: Philox is counter-based, so a lane simply
+// generates the normals the B operand wants from it.  Lane l = 16 q + j holds, for column block c (paths i0 + 16 c + j),
+// the normals of Philox blocks q and q + 4 of that path, i.e. columns k(s, q) = 2 q, 2 q + 1, 2 q + 8, 2 q + 9 of M for
+// the k-steps s = 0..3 -- the host lays M out as the A operand of each step in exactly that column order (BasketDyn
+// consts, after wg: a4[s][lane] = M[j][k(s, q)]).  A lane does the same RNG work as before (8 blocks, 16 normals per
+// trip), for 4 paths x 4 columns instead of 1 path x 16.
+// The accumulators come back as X[asset q + 4 v][path i0 + 16 c + j], v = 0..3: 16 exponentials per lane as before,
+// the weighted sum over assets is 4 in-lane fmas per column block plus a sum over the four lane groups, done as a
+// reduce-scatter with v_permlane32_swap / v_permlane16_swap (6 swaps + 3 adds) that leaves lane l with the basket of
+// path i0 + l: units, per-lane sums and the closing reduction are those of every other basket kernel.
+// Differences from them: the order of the additions inside x and inside the basket sum (results agree to a few ulp,
+// not bit for bit), and a wave prices all 64 paths of a trip or none (paths beyond the range are computed and dropped).
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+// a's lanes 32..63 <-> b's lanes 0..31
+__device__ __forceinline__ void swap_halves(double &a, double &b)
+{
+    uint64_t ua = __builtin_bit_cast(uint64_t, a), ub = __builtin_bit_cast(uint64_t, b);
+    const u32x2 lo = __builtin_amdgcn_permlane32_swap((uint32_t)ua, (uint32_t)ub, false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane32_swap((uint32_t)(ua >> 32), (uint32_t)(ub >> 32), false, false);
+    a = __builtin_bit_cast(double, (uint64_t)lo.x | ((uint64_t)hi.x << 32));
+    b = __builtin_bit_cast(double, (uint64_t)lo.y | ((uint64_t)hi.y << 32));
+}
+// a's odd rows of 16 lanes <-> b's even rows
+__device__ __forceinline__ void swap_rows(double &a, double &b)
+{
+    uint64_t ua = __builtin_bit_cast(uint64_t, a), ub = __builtin_bit_cast(uint64_t, b);
+    const u32x2 lo = __builtin_amdgcn_permlane16_swap((uint32_t)ua, (uint32_t)ub, false, false);
+    const u32x2 hi = __builtin_amdgcn_permlane16_swap((uint32_t)(ua >> 32), (uint32_t)(ub >> 32), false, false);
+    a = __builtin_bit_cast(double, (uint64_t)lo.x | ((uint64_t)hi.x << 32));
+    b = __builtin_bit_cast(double, (uint64_t)lo.y | ((uint64_t)hi.y << 32));
+}
+// p[c] = lane group q's share of the sum for path block c; returns the whole sum for path block q (this lane's own path)
+__device__ __forceinline__ double sum_over_lane_groups(double p0, double p1, double p2, double p3)
+{
+    swap_halves(p0, p2);   // lower half keeps c = 0, upper half c = 2
+    swap_halves(p1, p3);   //                  c = 1             c = 3
+    double r0 = p0 + p2, r1 = p1 + p3;
+    swap_rows(r0, r1);     // even rows keep r0's block, odd rows r1's
+    return r0 + r1;
+}
+
+template <bool ANTI>
+__global__ __launch_bounds__(GROUP) void basket_mfma_f64_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<double> o, const Work w, double *__restrict__ out)
+{
+    stage_tables<double>();
+    constexpr int NB = 4, NP = 16, NH = NB * (NB + 1);
+    const double *base = o.consts + 8 * NH, *coef = base + NP, *wg = coef + NP, *a4 = wg + NP;
+    const int lane = threadIdx.x & 63, q = lane >> 4, j = lane & 15;
+    double A[4], cb[4], cf[4], wr[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        A[s] = a4[64 * s + lane];
+        cb[s] = base[q + 4 * s];
+        cf[s] = coef[q + 4 * s];
+        wr[s] = wg[q + 4 * s];
+    }
+    const uint32_t stride = gridDim.x * GROUP;
+    double acc_s = 0.0, acc_q = 0.0;
+    // wave-uniform trip count: the matrix instructions want all 64 lanes
+    for (uint32_t i0 = blockIdx.x * GROUP + (threadIdx.x & ~63u); i0 < w.n_units; i0 += stride) {
+        double pb[4], pm[4], pl[4], plm[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const uint32_t unit = w.unit_lo + i0 + 16u * c + j;
+            double za[2], zb[2];
+            block_normals(unit, w.unit_hi, (uint32_t)q, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, za);
+            block_normals(unit, w.unit_hi, (uint32_t)q + 4u, 2u, w.seed_lo, w.seed_hi, zb);
+            d4 x = {cb[0], cb[1], cb[2], cb[3]};
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], za[0], x, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[1], za[1], x, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2], zb[0], x, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[3], zb[1], x, 0, 0, 0);
+            double b = 0, m = 0, l = 0, lm = 0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                b = __builtin_fma(cf[v], exp_model(x[v]), b);
+                if (ANTI) {
+                    const double xm = __builtin_fma(-1.0, x[v], 2 * cb[v]);
+                    m = __builtin_fma(cf[v], exp_model(xm), m);
+                    lm = __builtin_fma(wr[v], xm, lm);
+                }
+                l = __builtin_fma(wr[v], x[v], l);
+            }
+            pb[c] = b, pm[c] = m, pl[c] = l, plm[c] = lm;
+        }
+        const double v = sum_over_lane_groups(pb[0], pb[1], pb[2], pb[3]) - o.strike;
+        double p = v > 0 ? v : 0;
+        if (o.cv) {   // wave-uniform
+            const double gv = exp_model(o.cg + sum_over_lane_groups(pl[0], pl[1], pl[2], pl[3])) - o.strike;
+            p -= gv > 0 ? gv : 0;
+        }
+        if (ANTI) {
+            const double vm = sum_over_lane_groups(pm[0], pm[1], pm[2], pm[3]) - o.strike;
+            double pmir = vm > 0 ? vm : 0;
+            if (o.cv) {
+                const double gm = exp_model(o.cg + sum_over_lane_groups(plm[0], plm[1], plm[2], plm[3])) - o.strike;
+                pmir -= gm > 0 ? gm : 0;
+            }
+            p = 0.5 * (p + pmir);
+        }
+        const uint32_t i = i0 + lane;
+        if (i >= w.n_units)
+            p = 0;
+        acc_s += p;
+        acc_q = __builtin_fma(p, p, acc_q);
+        if (out && i < w.n_units)
+            out[i] = p;
+    }
+    group_sum2(acc_s, acc_q);
+    finish_group(acc_s, acc_q);
+}
+
 // =========================================================================================
 // CVA of one call.  Reference device loop, dp/MonteCarloKernel.cu:241-262 (spot advanced
 // first, exposure = Black-Scholes value at the NEW spot and residual maturity :125-129, with

@@ -539,6 +539,46 @@ def test_basket_kernel_families_agree_bitwise_in_f64(mc, eng, n_assets):
             assert got.dtype == np.float64 and np.array_equal(got, default), name
 
 
+@pytest.mark.parametrize("n_assets,anti,cv", [(16, 0, 0), (16, 1, 1), (13, 0, 1), (14, 1, 0)])
+def test_basket_matrix_core_family_matches_default_and_oracle(mc, po, n_assets, anti, cv):
+    """basket_mfma_f64_kernel (MC_BASKET_MFMA=1; off by default because it measured 5-6 % slower): the
+    Cholesky step of 64 paths as 16 v_mfma_f64_16x16x4_f64, every lane generating the normals the B operand wants
+    from it, the basket sum closed across lane groups with v_permlane32_swap / v_permlane16_swap.  Same units, same
+    stream, same per-lane sums as the other families; only the order of the additions inside x and inside the basket
+    differs, so per-path payoffs agree to a few ulp (not bit for bit), and with the oracle within the fp64 tolerance."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    n = 5003   # not a multiple of 64: the last wave prices paths beyond the range and drops them
+    b = basket_inputs(mc, n_assets, "f64", rho=0.4)
+    with mc.Engine(0) as e:
+        e.set_antithetic(bool(anti)), e.set_control_variate(bool(cv))
+        default = e.basket_paths(b, n, SEED, 77, "f64")
+        ref = e.basket(b, 200001, SEED, 5, "f64")
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r)\n"
+            "import montecarlocuda_amd as mc\n"
+            "b = json.load(open(sys.argv[1]))\n"
+            "with mc.Engine(0) as e:\n"
+            "    e.set_antithetic(%d); e.set_control_variate(%d)\n"
+            "    np.save(sys.argv[2], e.basket_paths(b, %d, %d, 77, 'f64'))\n"
+            "    r = e.basket(b, 200001, %d, 5, 'f64')\n"
+            "    print(json.dumps({'sum': r.sum, 'sum2': r.sum2, 'n': r.n}))\n" % (ROOT, anti, cv, n, SEED, SEED))
+    with tempfile.TemporaryDirectory() as d:
+        json.dump(b, open(os.path.join(d, "b.json"), "w"))
+        out = subprocess.run([sys.executable, "-c", code, os.path.join(d, "b.json"), os.path.join(d, "m.npy")], check=True,
+                             env=dict(os.environ, MC_BASKET_MFMA="1"), timeout=300, capture_output=True, text=True)
+        got = np.load(os.path.join(d, "m.npy"))
+        sums = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert got.shape == default.shape and got.dtype == np.float64
+    assert not np.array_equal(got, default), "identical bits: the matrix-core family did not run"
+    assert np.max(np.abs(got - default) / np.maximum(np.abs(default), 1.0)) < 2e-12
+    want, _ = po.dev_basket("f64", b, SEED, 77, n, antithetic=bool(anti), control=bool(cv))
+    assert np.abs(got - f64(want)).max() <= TOL["f64"]["pay"] * 100.0 * 4
+    assert sums["n"] == 200001
+    assert sums["sum"] == pytest.approx(ref.sum, rel=1e-12) and sums["sum2"] == pytest.approx(ref.sum2, rel=1e-12)
+
+
 def test_generic_basket_alternates_with_cva_on_one_context(eng, mc, po):
     """The generic basket's constants and the CVA date table share the context's table buffer: calls of
     both kinds interleaved must each see their own data."""
