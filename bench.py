@@ -147,7 +147,7 @@ def cpu_all_cores(seconds=2.0):
             "sample": f"{n} paths in {dt:.2f} s", "price": float(v.Expected)}
 
 
-def strong_scaling_block(mc, torch, dist, eng, launch_stream, stream, rank, world, grouped, backend, barrier, reps):
+def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, backend, barrier, reps):
     """BASELINE.json's strong-scaling target, measured on this N: ONE pricing call of configs[3] (C4: basket, 16 assets,
     1e9 paths, fp64) and of configs[4] (C5: CVA, 256 dates x 1e7 paths, fp64) -- and of 10x those sizes --
     sharded over the N ranks (mc_shard_range), timed wall-clock from the first launch to the all-reduced triple on the
@@ -160,26 +160,35 @@ def strong_scaling_block(mc, torch, dist, eng, launch_stream, stream, rank, worl
              ("C5", "cva", CVA, 10 ** 7, "CVA on vanilla call, 256 dates x 1e7 paths, fp64 (BASELINE configs[4])"),
              ("C5x10", "cva", CVA, 10 ** 8, "the same, 1e8 paths")]
     out = torch.zeros(3, dtype=torch.float64, device="cuda")
-    for name, prod, inputs, total, desc in specs:
+    pinned = torch.zeros(3, dtype=torch.float64).pin_memory()
+    # N = 1 also times what ONE rank does at N = 2, 4, 8: shard 0 of S of every row through the same code path
+    # ("shard_of" rows) -- the device side of the scaling curve, which a one-GPU box can measure; the all-reduce
+    # between ranks is the only part missing from them
+    shard_rows = []
+    runs = [(spec, 1) for spec in specs]
+    if world == 1:
+        runs += [(spec, S) for S in (2, 4, 8) for spec in specs]
+    t_full = {}
+    for (name, prod, inputs, total, desc), shard_of in runs:
         struct, keep = eng.prepared(prod, "f64", inputs)
-        first, count = mc.shard_range(total, rank, world)
+        first, count = mc.shard_range(total, rank, world) if shard_of == 1 else mc.shard_range(total, 0, shard_of)
         times = []
         host = None
         for r_ in range(-2, reps):
             barrier()
             t0 = time.perf_counter()
+            # launch, RCCL and the read-back all on torch's current stream (a handle torch owns): no hop between streams
             if count:
-                eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), launch_stream)
-                eng.order(stream.cuda_stream)     # torch's current stream (RCCL, the read-back) behind the launch
+                eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), stream.cuda_stream)
             else:
                 out.zero_()
             if grouped and backend == "nccl":
                 dist.all_reduce(out, op=dist.ReduceOp.SUM)      # RCCL, ordered behind the launch (current stream)
-                host = out.cpu()
-            else:
-                host = out.cpu()
-                if grouped:
-                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            pinned.copy_(out, non_blocking=True)                # 24 bytes into pinned host memory
+            stream.synchronize()
+            host = pinned.clone()
+            if grouped and backend != "nccl":
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
             dt = time.perf_counter() - t0
             if r_ >= 0:
                 times.append(dt)
@@ -191,10 +200,17 @@ def strong_scaling_block(mc, torch, dist, eng, launch_stream, stream, rank, worl
         disc = 1.0 if prod == "cva" else math.exp(-float(inputs["r"]) * float(inputs["t"]))
         price, ci = mc.closing(s_, s2_, int(n_), disc)
         med = float(np.median(times))
-        rows.append({"config": name, "workload": desc, "paths_total": total, "paths_per_gpu": count, "reps": reps,
-                     "wall_ms_median": med * 1e3, "wall_ms_min": times[0] * 1e3, "paths_per_s": total / med,
-                     "value": price, "confidence_95": ci, "paths_priced": int(n_)})
-    return {"scaling": "strong", "n_gpus": world, "rows": rows,
+        if shard_of == 1:
+            t_full[name] = med
+            rows.append({"config": name, "workload": desc, "paths_total": total, "paths_per_gpu": count, "reps": reps,
+                         "wall_ms_median": med * 1e3, "wall_ms_min": times[0] * 1e3, "paths_per_s": total / med,
+                         "value": price, "confidence_95": ci, "paths_priced": int(n_)})
+        else:
+            shard_rows.append({"config": name, "shard_of": shard_of, "paths": count, "reps": reps, "wall_ms_median": med * 1e3,
+                         "wall_ms_min": times[0] * 1e3, "device_side_efficiency": t_full[name] / (shard_of * med),
+                         "what": f"shard 0 of {shard_of} on this one GPU: T(1) / ({shard_of} T(shard)); the all-reduce between "
+                                 "ranks is not in it"})
+    return {"scaling": "strong", "n_gpus": world, "rows": rows, "shard_rows": shard_rows,
             "timing": "wall-clock, first launch -> all-reduced {sum, sum2, n} on the host, max over ranks; 2 warm-ups",
             "note": "strong-scaling efficiency of a row = wall_ms_median(N=1) / (N * wall_ms_median(N)), from the driver's "
                     "own N = 1, 2, 4, 8 lines"}
@@ -451,7 +467,7 @@ def main():
 
     strong = None
     if args.strong_reps > 0 and args.workload == "vanilla_f32":
-        strong = strong_scaling_block(mc, torch, dist, eng, launch_streams[0], stream, rank, world, grouped, args.backend, barrier,
+        strong = strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, args.backend, barrier,
                                       args.strong_reps)
 
     if rank == 0:

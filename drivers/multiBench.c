@@ -8,6 +8,9 @@
  * `reps` calls, median and minimum reported; handle (contexts + RCCL communicators) creation reported once,
  * separately.  One JSON object per line on stdout: bench.py embeds them ("c_multi"), people read them.
  *
+ * Then, on the first device alone, shard 0 of G = 2, 4, 8 of every workload: the device side of the scaling curve,
+ * measurable without the other devices ("shard_of" lines).
+ *
  *   multiBench [--reps R] [--max-devices G] [--small]     (--small: 1/100 of the sizes, for tests)
  */
 #include "driver_util.h"
@@ -94,6 +97,41 @@ int main(int argc, char **argv)
                    t1[k] > 0 ? t1[k] / (G * med) : 0.0, r.kernel_ms, r.expected, r.confidence, mc_multi_last_reduce_error(m));
             fflush(stdout);
         }
+        mc_multi_destroy(m);
+    }
+    /* What ONE device does at G = 2, 4, 8, measured on the first device alone: shard 0 of G of every workload through
+     * the same call (launch, all-reduce over a communicator of one, read-back, closing).  T(1) / (G T(shard)) is the
+     * strong-scaling efficiency the device side allows -- everything except the G-rank all-reduce's extra latency --
+     * and it can be measured on a one-GPU box. */
+    {
+        mc_multi *m;
+        mc_result r;
+        CHECK(mc_multi_create(NULL, 1, 0, &m));
+        CHECK(mc_multi_set_timing(m, timing));
+        CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, 0, 1000, &r));
+        for (int G = 2; G <= 8; G *= 2)
+            for (int k = 0; k < 4; ++k) {
+                uint64_t lo = 0, cnt = 0;
+                mc_shard_range(work[k].paths, 0, G, &lo, &cnt);
+                double t[100];
+                for (int i = -2; i < reps; ++i) {
+                    const double t0 = now_s();
+                    if (work[k].is_cva)
+                        CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, lo, cnt, &r));
+                    else
+                        CHECK(mc_multi_basket_run_f64(m, &c4, MC_DEFAULT_SEED, lo, cnt, &r));
+                    if (i >= 0)
+                        t[i] = now_s() - t0;
+                }
+                qsort(t, (size_t)reps, sizeof t[0], cmp_double);
+                const double med = t[reps / 2];
+                printf("{\"shard_of\": %d, \"devices\": 1, \"workload\": \"%s\", \"paths\": %llu, \"reps\": %d, \"wall_ms_median\": %.4f, "
+                       "\"wall_ms_min\": %.4f, \"kernel_ms\": %.4f, \"device_side_efficiency\": %.4f, "
+                       "\"what\": \"shard 0 of %d on one device: T(1) / (%d T(shard)), the all-reduce between devices not included\"}\n",
+                       G, work[k].name, (unsigned long long)cnt, reps, med * 1e3, t[0] * 1e3, r.kernel_ms,
+                       t1[k] > 0 ? t1[k] / (G * med) : 0.0, G, G);
+                fflush(stdout);
+            }
         mc_multi_destroy(m);
     }
     return 0;

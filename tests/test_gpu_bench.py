@@ -56,7 +56,12 @@ def test_bench_contract_single_gpu():
     assert set(rows) == {"C4", "C4x10", "C5", "C5x10"} and rows["C4"]["paths_priced"] == 10 ** 9 and rows["C5x10"]["paths_priced"] == 10 ** 8
     assert 9.70 < rows["C4"]["value"] < 9.74 and 0.1895 < rows["C5"]["value"] < 0.1905
     assert rows["C4x10"]["wall_ms_median"] == pytest.approx(10 * rows["C4"]["wall_ms_median"], rel=0.1)
+    # ... and, at N = 1, what one rank does at N = 2, 4, 8 (shard 0 of S): the device side of the scaling curve
+    sh = {(x["config"], x["shard_of"]): x for x in d["strong"]["shard_rows"]}
+    assert set(sh) == {(c, S) for c in rows for S in (2, 4, 8)} and sh[("C4", 8)]["paths"] == 125000000
+    assert all(0.5 < x["device_side_efficiency"] < 1.1 for x in sh.values()) and sh[("C4x10", 8)]["device_side_efficiency"] > 0.9
     cm = d["c_multi"]
+    assert any("shard_of" in x for x in cm["rows"])
     assert cm["rc"] == 0 and any(x.get("workload", "").startswith("C4 basket") and x["devices"] == 1 for x in cm["rows"])
 
 

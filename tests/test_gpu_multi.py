@@ -63,7 +63,10 @@ def test_strong_scaling_driver_emits_json():
     out = subprocess.run([exe, "--small", "--reps", "3"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     rows = [json.loads(line) for line in out.stdout.splitlines() if line.startswith("{")]   # RCCL prints a version banner
-    runs = [r for r in rows if "workload" in r]
+    shards = [r for r in rows if "shard_of" in r]     # what one device does at G = 2, 4, 8, measured on the first device alone
+    assert {(r["shard_of"], r["workload"][:2]) for r in shards} == {(g, w) for g in (2, 4, 8) for w in ("C4", "C5")}
+    assert all(r["wall_ms_median"] > 0 and 0.05 < r["device_side_efficiency"] < 1.2 for r in shards)
+    runs = [r for r in rows if "workload" in r and "shard_of" not in r]
     assert len(runs) >= 4 and all(r["wall_ms_median"] > 0 and r["rccl_vs_host_rel"] <= 1e-12 for r in runs)
     assert any(r["workload"].startswith("C4 basket n=16") and 9.5 < r["value"] < 9.9 for r in runs)
     assert any(r["workload"].startswith("C5 CVA") and 0.18 < r["value"] < 0.20 for r in runs)
