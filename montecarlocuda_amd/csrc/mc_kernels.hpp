@@ -1202,6 +1202,26 @@ __device__ __forceinline__ f2 bs_exposure_dates(f2 ln2_spot, f2 W, const float *
     return va - vb;
 }
 
+// a * b + c with c read from its SGPR pair by the three-operand instruction (c must be wave-uniform)
+__device__ __forceinline__ double fma_scalar_addend(double a, double b, double c)
+{
+#ifndef MC_AB_CVA_NO_VGPR_CONST
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+#else
+    return __builtin_fma(a, b, c);
+#endif
+}
+// a wave-uniform value in a vector register pair (one copy, where hipcc would make one per use)
+__device__ __forceinline__ double to_vgpr(double x)
+{
+#ifndef MC_AB_CVA_NO_VGPR_CONST
+    asm("" : "+v"(x));
+#endif
+    return x;
+}
+
 __device__ __forceinline__ double hastings_poly(double k)
 {
     double poly = __builtin_fma(k, 1.330274429, -1.821255978);
@@ -1235,8 +1255,19 @@ __device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaS
     ee_b = bs_exposure(ln_b, W_b, sb);
 #else
     const double spot_a = exp_f64(ln_a), spot_b = exp_f64(ln_b);
+    // The table row sits in SGPRs and a VALU instruction reads at most one scalar operand.  hipcc turns fma(W, g, e)
+    // with g and e both scalar into v_fmac_f64 and copies the ADDEND into the destination pair first (two v_mov_b32 per
+    // fma: 6 of the ~124 instructions per date).  Spelled out instead: g into a vector pair once (it serves d1 and d2),
+    // the addends read straight from their SGPRs by the three-operand form -- same fma, same bits, 3 instructions per
+    // date instead of 6.
+#ifndef MC_AB_CVA_NO_VGPR_CONST
+    const double g_a = to_vgpr(sa.g), g_b = to_vgpr(sb.g);
+    const double d1a = fma_scalar_addend(W_a, g_a, sa.e1), d2a = fma_scalar_addend(W_a, g_a, sa.e2);
+    const double d1b = fma_scalar_addend(W_b, g_b, sb.e1), d2b = fma_scalar_addend(W_b, g_b, sb.e2);
+#else
     const double d1a = __builtin_fma(W_a, sa.g, sa.e1), d2a = __builtin_fma(W_a, sa.g, sa.e2);
     const double d1b = __builtin_fma(W_b, sb.g, sb.e1), d2b = __builtin_fma(W_b, sb.g, sb.e2);
+#endif
     const double A_a = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));  // d1 runs away as tau -> 0
     const double A_b = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1b, d1b, ln_b), -800.0));
     double k1a, k2a, k1b, k2b;
@@ -1257,6 +1288,9 @@ __device__ __forceinline__ Real cva_path(Rng &rng, const CvaArgs<Real> &o, const
     f2 acc2 = {0.0f, 0.0f};  // fp32: even / odd dates of the packed date pairs
     Real z[NPB];
     const int n_dates = o.n_bs + o.last_intrinsic;
+    Real bx_v = o.bx;   // in a vector register for the whole path: ln s = fma(W, bx, xk_j) then reads ONE scalar (xk_j)
+    if constexpr (sizeof(Real) == 8)
+        bx_v = to_vgpr(bx_v);
     for (int j0 = 0; j0 < n_dates; j0 += NPB) {
         block_normals(rng, w, c0, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, z);
         if constexpr (sizeof(Real) == 4) {
@@ -1283,10 +1317,10 @@ __device__ __forceinline__ Real cva_path(Rng &rng, const CvaArgs<Real> &o, const
                 const double W_a = W + z[0], W_b = W_a + z[1];
                 W = W_b;
                 double ee_a, ee_b;
-                bs_exposure2(fma_r(W_a, o.bx, sa.xk), W_a, sa, fma_r(W_b, o.bx, sb.xk), W_b, sb, ee_a, ee_b);
+                bs_exposure2(fma_scalar_addend(W_a, bx_v, sa.xk), W_a, sa, fma_scalar_addend(W_b, bx_v, sb.xk), W_b, sb, ee_a, ee_b);
                 if (ANTI) {
                     double em_a, em_b;
-                    bs_exposure2(fma_r(-W_a, o.bx, sa.xk), -W_a, sa, fma_r(-W_b, o.bx, sb.xk), -W_b, sb, em_a, em_b);
+                    bs_exposure2(fma_scalar_addend(-W_a, bx_v, sa.xk), -W_a, sa, fma_scalar_addend(-W_b, bx_v, sb.xk), -W_b, sb, em_a, em_b);
                     ee_a += em_a;
                     ee_b += em_b;
                 }
