@@ -795,6 +795,19 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const Tail /* fir
 // What keeps hipcc from hoisting these loop-invariant loads out of the path loop (and spilling them again)
 // is an offset it cannot see through: an empty volatile asm that redefines `off` (always 0) and is tied
 // to the value computed just before, which also fixes where in the trip each load is issued.
+// A wave-uniform value (in an SGPR pair) into a vector register pair with ONE v_mov_b64 (hipcc emits two v_mov_b32).
+__device__ __forceinline__ double scalar_to_vgpr(double x)
+{
+#ifndef MC_AB_NO_MOV64
+    double r;
+    asm("v_mov_b64 %0, %1" : "=v"(r) : "s"(x));
+    return r;
+#else
+    return x;
+#endif
+}
+__device__ __forceinline__ float scalar_to_vgpr(float x) { return x; }
+
 template <class Real, int NA, bool ANTI>
 __global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<Real> o, const Work w, Real *__restrict__ out)
 {
@@ -832,7 +845,7 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const Tail /* first
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (r < rows) {
-                    x[r] = base[off + 4 * A + r];
+                    x[r] = scalar_to_vgpr(base[off + 4 * A + r]);
                     cf[r] = coef[off + 4 * A + r];
                     wr[r] = wg[off + 4 * A + r];
                 }
