@@ -366,11 +366,15 @@ def main():
 
     def drain(host_sync=True):
         flush_bucket()
+        if not host_sync:
+            # The caller's barrier() follows at once: its collective runs on RCCL's stream BEHIND the bucket's all-reduce
+            # and the host waits for it, so the all-reduced triples are complete when it returns.  Making torch's stream
+            # wait for the all-reduce first (Work.wait) would put two more stream-to-stream hand-overs (RCCL -> torch ->
+            # RCCL, ~12 us each on this platform) into the dependency chain; the works are collected after the barrier.
+            return
         for w in works:
             w.wait()          # stream-level: torch's stream waits for RCCL's
         works.clear()
-        if not host_sync:     # the caller's barrier() follows at once and synchronises (one host wake-up instead of two)
-            return
         if args.poll:
             # poll the launch streams (and torch's) from user space until the work is done, THEN synchronise
             while not (all(e_.idle() for e_ in engines) and stream.query()):
@@ -404,9 +408,18 @@ def main():
     t0 = time.perf_counter()
     for i in range(W, W + K):
         step(i)
+    t_enqueued = time.perf_counter()
     drain(host_sync=not grouped)   # N > 1: RCCL's barrier queues right behind the last bucket's all-reduce
+    t_drained = time.perf_counter()
     barrier()
     elapsed = time.perf_counter() - t0
+    for w in works:          # complete since the barrier (same RCCL stream, earlier in order): orders torch's stream, costs nothing
+        w.wait()
+    works.clear()
+    host_side = {"enqueue_K_steps_ms": (t_enqueued - t0) * 1e3, "drain_ms": (t_drained - t_enqueued) * 1e3,
+                 "closing_barrier_ms": (t0 + elapsed - t_drained) * 1e3,
+                 "what": "host wall-clock inside the timed region of this rank: launching the K steps (asynchronous), the last bucket's "
+                         "all-reduce + waits, the closing barrier + synchronize"}
     samples, kernel_ms_total = eng.profile_read()
     eng.profile(0)
     if grouped:
@@ -504,7 +517,7 @@ def main():
         out = {
             "metric": "Monte Carlo paths/sec", "value": value, "unit": "paths/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": X, "data": "synthetic", "timed_region_s": elapsed,
+            "vs_baseline": None, "dtype": X, "data": "synthetic", "timed_region_s": elapsed, "timed_region_host": host_side,
             "config": {"workload": desc, "paths_per_gpu_per_step": shard_count, "global_paths_per_step": units_per_step,
                        "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
