@@ -286,6 +286,9 @@ def main():
                     help="1: the host polls the launch streams (mc_context_idle) before the closing synchronize of the timed "
                          "region instead of sleeping in it; 0 (default): blocking synchronize only -- measured equal within noise "
                          "(profiles/r02_short_run_variance.log)")
+    ap.add_argument("--collective", default="sync", choices=["sync", "async"],
+                    help="N > 1, RCCL: the bucket all-reduce as a synchronous-mode collective on torch's current stream (default) or "
+                         "async_op=True on the process group's internal stream")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
@@ -342,7 +345,13 @@ def main():
         if grouped and pending[1] > pending[0]:
             rows = triples[pending[0]:pending[1]]
             if args.backend == "nccl":
-                works.append(dist.all_reduce(rows, op=dist.ReduceOp.SUM, async_op=True))
+                if args.collective == "sync":
+                    # a synchronous-mode collective runs on torch's CURRENT stream (PyTorch >= 2.8), which executes no
+                    # pricing kernel here (those are on the contexts' streams): still asynchronous to compute and to the
+                    # host, and without the hand-overs to and from the process group's internal stream
+                    dist.all_reduce(rows, op=dist.ReduceOp.SUM)
+                else:
+                    works.append(dist.all_reduce(rows, op=dist.ReduceOp.SUM, async_op=True))
             else:   # rehearsal path: reduce on the host
                 host = rows.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
