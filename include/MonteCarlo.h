@@ -106,6 +106,9 @@ void printVect(mc_real *vect, int c);
 void printMat(mc_real *mat, int r, int c);
 void prodMat(mc_real *first, mc_real *second, mc_real *result, int f_rows, int f_cols, int s_cols);
 mc_real randMinMax(mc_real min, mc_real max);
+/* Not in the reference: the number of threads the next host_* call will use -- MC_HOST_THREADS, else the hardware
+ * threads OpenMP sees capped by the container's cgroup CPU quota (host_path.c). */
+int mc_host_threads(void);
 
 #ifdef __cplusplus
 }

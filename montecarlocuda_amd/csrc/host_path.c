@@ -196,6 +196,51 @@ static int g_antithetic;
  * (mc_context_set_control_variate); the closed-form mean is added back in host_basketOpt. */
 static int g_control;
 
+/* ---- how many threads ---------------------------------------------------------------------------
+ * MC_HOST_THREADS if set; otherwise OpenMP's default capped by the CPU time the container is actually granted
+ * (cgroup v2 cpu.max, or v1 cfs quota / period): a pod that sees 256 hardware threads but may use 16 CPUs' worth of
+ * time runs HALF as fast on 256 threads as on 16 (throttling: profiles/r02_host_twin_threads.log). */
+static int cgroup_cpu_limit(void)
+{
+    long long quota = -1, period = 100000;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[32] = "";
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0)
+            quota = atoll(q);
+        fclose(f);
+    } else if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) {
+        if (fscanf(f, "%lld", &quota) != 1)
+            quota = -1;
+        fclose(f);
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))) {
+            if (fscanf(f, "%lld", &period) != 1)
+                period = 100000;
+            fclose(f);
+        }
+    }
+    if (quota <= 0 || period <= 0)
+        return 0;   /* no limit */
+    return (int)((quota + period - 1) / period);
+}
+
+/* threads the next host_* call will use (exported for the benchmark's record; not in the reference) */
+int mc_host_threads(void)
+{
+    const char *cap = getenv("MC_HOST_THREADS");
+    if (cap && atoi(cap) > 0)
+        return atoi(cap);
+#ifdef _OPENMP
+    int n = omp_get_num_procs();
+    const int limit = cgroup_cpu_limit();
+    if (limit > 0 && limit < n)
+        n = limit;
+    return n > 0 ? n : 1;
+#else
+    return 1;
+#endif
+}
+
 /* ---- chunked, thread-count-independent accumulation ------------------------------------------ */
 #define CHUNK 65536ll
 typedef void (*chunk_fn)(const void *ctx, uint64_t seed, long long first, long long count, double out[2]);
@@ -210,11 +255,8 @@ static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, doubl
     const uint64_t seed = seed_from_env();
     g_antithetic = getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC"));
     g_control = getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE"));
-    const char *cap = getenv("MC_HOST_THREADS");
-    (void)cap;
 #ifdef _OPENMP
-    if (cap && atoi(cap) > 0)
-        omp_set_num_threads(atoi(cap));
+    omp_set_num_threads(mc_host_threads());
 #endif
 #pragma omp parallel for schedule(dynamic, 4)
     for (long long c = 0; c < n_chunks; ++c) {

@@ -112,6 +112,28 @@ def test_result_does_not_depend_on_thread_count(po):
     assert outs[0] == outs[1] == outs[2], outs
 
 
+def test_thread_count_follows_the_override_and_the_cpu_quota(po):
+    """mc_host_threads(): MC_HOST_THREADS if set, else OpenMP's processors capped by the cgroup CPU quota (a pod that
+    sees 256 hardware threads but is granted 16 CPUs runs half as fast on 256 threads as on 16)."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "montecarlocuda_amd", "csrc", "libmchost_f64.so")
+    code = "import ctypes as C; print(C.CDLL(%r).mc_host_threads())" % lib
+    run = lambda env: int(subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True,
+                                         env=dict({k: v for k, v in os.environ.items() if k != "MC_HOST_THREADS"}, **env)).stdout)
+    assert run({"MC_HOST_THREADS": "3"}) == 3
+    n = run({})
+    limit = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        limit = None if q == "max" else -(-int(q) // int(p))
+    except OSError:
+        pass
+    assert 1 <= n <= len(os.sched_getaffinity(0)) or limit is not None
+    if limit is not None:
+        assert n <= max(1, limit)
+
+
 def test_drivers_build():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")], stdout=subprocess.DEVNULL)
     for b in ("vanillaOpt", "basketOpt", "cvaOpt"):
