@@ -112,7 +112,7 @@ def cpu_baseline(prod, X, inputs, seconds):
     out = {"value": n * per_unit / dt, "unit": unit, "cores": 1, "kind": "reference" if use_ref else "port",
            "sample": f"{n} paths of the same workload in {dt:.1f} s, single thread (the reference is single-threaded: "
                      f"MonteCarloHost.c:185-229), gcc -O2 -ffp-contract=off",
-           "host_cores_available": len(os.sched_getaffinity(0))}
+           "host_cores_available": len(os.sched_getaffinity(0)), "host_cpus_granted": cpus_granted()}
     if prod == "vanilla" and po.ref_available(X, 3, "_O0"):
         # footnote: the reference's own Makefile compiles the host file without -O (Makefile:157,252-253)
         n0 = max(1000, int(n * min(1.0, 3.0 / max(dt, 1e-3))))
@@ -120,6 +120,16 @@ def cpu_baseline(prod, X, inputs, seconds):
         out["value_at_O0"] = n0 / dt0
         out["O0_note"] = f"the same object built with gcc -O0, {n0} paths in {dt0:.1f} s (the reference Makefile's optimisation level)"
     return out
+
+
+def cpus_granted():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max), or None when unlimited / unknown: the GPU boxes show
+    256 hardware threads and grant 16."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else -(-int(q) // int(p))
+    except (OSError, ValueError):
+        return None
 
 
 def cpu_all_cores(seconds=2.0):
