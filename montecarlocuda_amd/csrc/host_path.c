@@ -274,6 +274,28 @@ static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, doubl
     return v;
 }
 
+/* host_simd.c: the same loop over whole units, structure-of-arrays, compiled once per vector ISA */
+typedef void (*vanilla_units_fn)(uint64_t seed, uint64_t unit0, long long n_units, mc_real spot, mc_real strike, mc_real drift,
+                                 mc_real vol, int antithetic, double out[2]);
+void mc_host_vanilla_units_base(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, int, double[2]);
+void mc_host_vanilla_units_avx2(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, int, double[2]);
+void mc_host_vanilla_units_avx512(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, int, double[2]);
+
+static vanilla_units_fn vanilla_units(void)
+{
+#if defined(__x86_64__) && defined(__GNUC__)
+    const char *isa = getenv("MC_HOST_ISA");   /* "base", "avx2", "avx512": tests and A/B runs */
+    if (isa && !strcmp(isa, "base"))
+        return mc_host_vanilla_units_base;
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !(isa && !strcmp(isa, "avx2")))
+        return mc_host_vanilla_units_avx512;
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"))
+        return mc_host_vanilla_units_avx2;
+#endif
+    return mc_host_vanilla_units_base;
+}
+
 /* vanilla: MonteCarloKernel.cu:67-71 */
 static void vanilla_chunk(const void *ctx, uint64_t seed, long long first, long long count, double out[2])
 {
@@ -283,7 +305,17 @@ static void vanilla_chunk(const void *ctx, uint64_t seed, long long first, long 
     double s = 0, s2 = 0;
     mc_real z[NPB];
     uint64_t have = (uint64_t)-1;
-    for (long long i = 0; i < count; ++i) {
+    long long i0 = 0;
+    if (first % NPB == 0 && !getenv("MC_HOST_SCALAR")) {   /* whole batches of units: the vectorised form (host_simd.c) */
+        const long long units = (count / NPB) / 256 * 256;
+        if (units > 0) {
+            double part[2];
+            vanilla_units()(seed, (uint64_t)first / NPB, units, o->s, o->k, drift, vol, g_antithetic, part);
+            s = part[0], s2 = part[1];
+            i0 = units * NPB;
+        }
+    }
+    for (long long i = i0; i < count; ++i) {
         const uint64_t p = (uint64_t)(first + i), unit = p / NPB;
         if (unit != have)
             block_normals(seed, MC_DOMAIN_VANILLA, unit, 0, z), have = unit;

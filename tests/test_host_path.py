@@ -112,6 +112,35 @@ def test_result_does_not_depend_on_thread_count(po):
     assert outs[0] == outs[1] == outs[2], outs
 
 
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_vectorised_vanilla_loop_matches_the_scalar_form(po, X):
+    """host_simd.c (whole units in batches of 256, compiled for x86-64 / AVX2 / AVX-512, glibc's vector math) against the
+    scalar loop of host_path.c (MC_HOST_SCALAR=1) and against the oracle: same stream, same formulas, values within a few
+    ulp -- for the plain and the antithetic estimator, and for a path count that leaves a scalar remainder."""
+    import subprocess
+    import sys
+    lib = os.path.join(ROOT, "montecarlocuda_amd", "csrc", "libmchost_%s.so" % X)
+    ct = "c_double" if X == "f64" else "c_float"
+    code = ("import ctypes as C\n"
+            "class OD(C.Structure): _fields_ = [(k, C.%s) for k in 'skrvt']\n"
+            "class OV(C.Structure): _fields_ = [('Expected', C.%s), ('Confidence', C.%s)]\n"
+            "L = C.CDLL(%r); L.host_vanillaOpt.argtypes=[OD, C.c_int]; L.host_vanillaOpt.restype = OV\n"
+            "v = L.host_vanillaOpt(OD(100, 100, 0.04879, 0.2, 1), 1000003); print(repr(float(v.Expected)), repr(float(v.Confidence)))\n"
+            % (ct, ct, ct, lib))
+    base = {k: v for k, v in os.environ.items() if not k.startswith("MC_")}
+    run = lambda env: [float(x) for x in subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True,
+                                                         env=dict(base, **env)).stdout.split()]
+    tol = 1e-12 if X == "f64" else 2e-6
+    for anti in ("0", "1"):
+        scalar = run({"MC_HOST_SCALAR": "1", "MC_ANTITHETIC": anti})
+        _, o = po.dev_vanilla(X, dict(s=100.0, k=100.0, r=0.04879, v=0.2, t=1.0), SEED,
+                              0, 1000003, want_paths=False, antithetic=anti == "1")
+        for isa in ("base", "avx2", "avx512", ""):      # "" = whatever the CPU supports; an unsupported request falls back
+            got = run({"MC_HOST_ISA": isa, "MC_ANTITHETIC": anti} if isa else {"MC_ANTITHETIC": anti})
+            assert got[0] == pytest.approx(scalar[0], rel=tol) and got[1] == pytest.approx(scalar[1], rel=tol), (isa, anti)
+            assert got[0] == pytest.approx(o["expected"], rel=tol) and got[1] == pytest.approx(o["confidence"], rel=tol), (isa, anti)
+
+
 def test_thread_count_follows_the_override_and_the_cpu_quota(po):
     """mc_host_threads(): MC_HOST_THREADS if set, else OpenMP's processors capped by the cgroup CPU quota (a pod that
     sees 256 hardware threads but is granted 16 CPUs runs half as fast on 256 threads as on 16)."""
