@@ -274,26 +274,48 @@ static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, doubl
     return v;
 }
 
-/* host_simd.c: the same loop over whole units, structure-of-arrays, compiled once per vector ISA */
+/* host_simd.c: the same loops over whole batches, structure-of-arrays, compiled once per vector ISA */
 typedef void (*vanilla_units_fn)(uint64_t seed, uint64_t unit0, long long n_units, mc_real spot, mc_real strike, mc_real drift,
                                  mc_real vol, int antithetic, double out[2]);
-void mc_host_vanilla_units_base(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, int, double[2]);
-void mc_host_vanilla_units_avx2(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, int, double[2]);
-void mc_host_vanilla_units_avx512(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, int, double[2]);
+typedef void (*basket_paths_fn)(uint64_t seed, uint64_t first, long long n_paths, const mc_real *p, const mc_real *d, const mc_real *v,
+                                const mc_real *s0, const mc_real *w, mc_real strike, mc_real t, mc_real r, int antithetic, int control,
+                                double out[2]);
+typedef void (*cva_paths_fn)(uint64_t seed, uint64_t first, long long n_paths, mc_real s0, mc_real strike, mc_real r, mc_real v, mc_real t,
+                             int n_dates, mc_real defint, mc_real lgd, int antithetic, double out[2]);
+#define MC_SIMD_DECL(sfx)                                                                                                        \
+    void mc_host_vanilla_units_##sfx(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, int, double[2]);            \
+    void mc_host_basket_paths_##sfx(uint64_t, uint64_t, long long, const mc_real *, const mc_real *, const mc_real *, const mc_real *, \
+                                    const mc_real *, mc_real, mc_real, mc_real, int, int, double[2]);                               \
+    void mc_host_cva_paths_##sfx(uint64_t, uint64_t, long long, mc_real, mc_real, mc_real, mc_real, mc_real, int, mc_real, mc_real,  \
+                                 int, double[2]);
+MC_SIMD_DECL(base)
+MC_SIMD_DECL(avx2)
+MC_SIMD_DECL(avx512)
+#define SIMD_BATCH 256   /* host_simd.c BATCH */
 
-static vanilla_units_fn vanilla_units(void)
+typedef struct {
+    vanilla_units_fn vanilla;
+    basket_paths_fn basket;
+    cva_paths_fn cva;
+} simd_set;
+
+/* NULL members never; MC_HOST_SCALAR=1 makes the callers skip the set altogether */
+static const simd_set *simd(void)
 {
+    static const simd_set base = {mc_host_vanilla_units_base, mc_host_basket_paths_base, mc_host_cva_paths_base};
 #if defined(__x86_64__) && defined(__GNUC__)
+    static const simd_set avx2 = {mc_host_vanilla_units_avx2, mc_host_basket_paths_avx2, mc_host_cva_paths_avx2};
+    static const simd_set avx512 = {mc_host_vanilla_units_avx512, mc_host_basket_paths_avx512, mc_host_cva_paths_avx512};
     const char *isa = getenv("MC_HOST_ISA");   /* "base", "avx2", "avx512": tests and A/B runs */
     if (isa && !strcmp(isa, "base"))
-        return mc_host_vanilla_units_base;
+        return &base;
     __builtin_cpu_init();
     if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && !(isa && !strcmp(isa, "avx2")))
-        return mc_host_vanilla_units_avx512;
+        return &avx512;
     if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"))
-        return mc_host_vanilla_units_avx2;
+        return &avx2;
 #endif
-    return mc_host_vanilla_units_base;
+    return &base;
 }
 
 /* vanilla: MonteCarloKernel.cu:67-71 */
@@ -307,10 +329,10 @@ static void vanilla_chunk(const void *ctx, uint64_t seed, long long first, long 
     uint64_t have = (uint64_t)-1;
     long long i0 = 0;
     if (first % NPB == 0 && !getenv("MC_HOST_SCALAR")) {   /* whole batches of units: the vectorised form (host_simd.c) */
-        const long long units = (count / NPB) / 256 * 256;
+        const long long units = (count / NPB) / SIMD_BATCH * SIMD_BATCH;
         if (units > 0) {
             double part[2];
-            vanilla_units()(seed, (uint64_t)first / NPB, units, o->s, o->k, drift, vol, g_antithetic, part);
+            simd()->vanilla(seed, (uint64_t)first / NPB, units, o->s, o->k, drift, vol, g_antithetic, part);
             s = part[0], s2 = part[1];
             i0 = units * NPB;
         }
@@ -341,7 +363,14 @@ static void basket_chunk(const void *ctx, uint64_t seed, long long first, long l
     double s = 0, s2 = 0, wsum = 0;
     for (int a = 0; a < N; ++a)
         wsum += (double)o->w[a];
-    for (long long i = 0; i < count; ++i) {
+    long long i0 = 0;
+    if (!getenv("MC_HOST_SCALAR") && count >= SIMD_BATCH) {   /* whole batches of paths: the vectorised form (host_simd.c) */
+        double part[2];
+        i0 = count / SIMD_BATCH * SIMD_BATCH;
+        simd()->basket(seed, (uint64_t)first, i0, &o->p[0][0], o->d, o->v, o->s, o->w, o->k, o->t, o->r, g_antithetic, g_control, part);
+        s = part[0], s2 = part[1];
+    }
+    for (long long i = i0; i < count; ++i) {
         for (int b = 0; b < NBLK; ++b)
             block_normals(seed, MC_DOMAIN_BASKET, (uint64_t)(first + i), (uint32_t)b, g + b * NPB);
         mc_real payoff = 0;
@@ -382,7 +411,14 @@ static void cva_chunk(const void *ctx, uint64_t seed, long long first, long long
     const mc_real step_vol = (mc_real)((double)o->v * sqrt((double)dt));
     double s = 0, s2 = 0;
     mc_real z[NPB];
-    for (long long i = 0; i < count; ++i) {
+    long long i0 = 0;
+    if (!getenv("MC_HOST_SCALAR") && count >= SIMD_BATCH) {   /* whole batches of paths: the vectorised form (host_simd.c) */
+        double part[2];
+        i0 = count / SIMD_BATCH * SIMD_BATCH;
+        simd()->cva(seed, (uint64_t)first, i0, o->s, o->k, o->r, o->v, o->t, c->n, c->defInt, c->lgd, g_antithetic, part);
+        s = part[0], s2 = part[1];
+    }
+    for (long long i = i0; i < count; ++i) {
         mc_real spot = o->s, mirror = o->s, ttm = o->t, acc = 0;
         for (int j = 1; j <= c->n; ++j) {
             const double t_prev = (double)dt * (j - 1), t_now = (double)dt * j;

@@ -3,6 +3,7 @@ many-core CPU twin of the GPU estimator.  Checked here without a GPU against the
 golden outputs (host_bsCall, Chol: bit for bit) and against the oracle's device-formula family on
 the same Philox stream (host_vanillaOpt / host_basketOpt / host_cvaEquityOption)."""
 import ctypes as C
+import math
 import os
 import subprocess
 import sys
@@ -113,32 +114,61 @@ def test_result_does_not_depend_on_thread_count(po):
 
 
 @pytest.mark.parametrize("X", ["f64", "f32"])
-def test_vectorised_vanilla_loop_matches_the_scalar_form(po, X):
-    """host_simd.c (whole units in batches of 256, compiled for x86-64 / AVX2 / AVX-512, glibc's vector math) against the
-    scalar loop of host_path.c (MC_HOST_SCALAR=1) and against the oracle: same stream, same formulas, values within a few
-    ulp -- for the plain and the antithetic estimator, and for a path count that leaves a scalar remainder."""
+def test_vectorised_loops_match_the_scalar_forms(po, X):
+    """host_simd.c (whole batches of 256, compiled for x86-64 / AVX2 / AVX-512, glibc's vector math) against the scalar
+    loops of host_path.c (MC_HOST_SCALAR=1) and against the oracle, for the three products: same stream, same formulas,
+    values within a few ulp -- plain and antithetic (basket: control variate too), path counts that leave a scalar
+    remainder."""
+    import json
     import subprocess
     import sys
     lib = os.path.join(ROOT, "montecarlocuda_amd", "csrc", "libmchost_%s.so" % X)
     ct = "c_double" if X == "f64" else "c_float"
-    code = ("import ctypes as C\n"
-            "class OD(C.Structure): _fields_ = [(k, C.%s) for k in 'skrvt']\n"
-            "class OV(C.Structure): _fields_ = [('Expected', C.%s), ('Confidence', C.%s)]\n"
-            "L = C.CDLL(%r); L.host_vanillaOpt.argtypes=[OD, C.c_int]; L.host_vanillaOpt.restype = OV\n"
-            "v = L.host_vanillaOpt(OD(100, 100, 0.04879, 0.2, 1), 1000003); print(repr(float(v.Expected)), repr(float(v.Confidence)))\n"
-            % (ct, ct, ct, lib))
+    code = ("import ctypes as C, json\n"
+            "R = C.%s\n"
+            "class OD(C.Structure): _fields_ = [(k, R) for k in 'skrvt']\n"
+            "class OV(C.Structure): _fields_ = [('Expected', R), ('Confidence', R)]\n"
+            "class MO(C.Structure): _fields_ = [('s', R * 3), ('v', R * 3), ('p', (R * 3) * 3), ('d', R * 3), ('w', R * 3), ('k', R), ('t', R), ('r', R)]\n"
+            "class CVA(C.Structure): _fields_ = [('defInt', R), ('lgd', R), ('ns', C.c_int), ('option', OD), ('n', C.c_int)]\n"
+            "L = C.CDLL(%r)\n"
+            "for f in ('host_vanillaOpt', 'host_basketOpt', 'host_cvaEquityOption'): getattr(L, f).restype = OV\n"
+            "L.host_vanillaOpt.argtypes = [OD, C.c_int]\n"
+            "out = []\n"
+            "v = L.host_vanillaOpt(OD(100, 100, 0.04879, 0.2, 1), 1000003); out += [float(v.Expected), float(v.Confidence)]\n"
+            "m = MO(); P = %r\n"
+            "for i in range(3):\n"
+            "    m.s[i], m.v[i], m.d[i], m.w[i] = 100.0, (0.2, 0.3, 0.2)[i], (0.0, 0.01, -0.01)[i], (0.3, 0.3, 0.4)[i]\n"
+            "    for j in range(3): m.p[i][j] = P[i][j]\n"
+            "m.k, m.t, m.r = 100.0, 1.0, 0.048790164\n"
+            "v = L.host_basketOpt(C.byref(m), 70001); out += [float(v.Expected), float(v.Confidence)]\n"
+            "c = CVA(0.03, 0.6, 0, OD(100, 100, 0.05, 0.2, 1), 250)\n"
+            "v = L.host_cvaEquityOption(C.byref(c), 3001); out += [float(v.Expected), float(v.Confidence)]\n"
+            "print(json.dumps(out))\n")
+    Lf = po.chol(X, [[1, .5, .5], [.5, 1, .5], [.5, .5, 1]]).tolist()
+    code = code % (ct, lib, Lf)
     base = {k: v for k, v in os.environ.items() if not k.startswith("MC_")}
-    run = lambda env: [float(x) for x in subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True,
-                                                         env=dict(base, **env)).stdout.split()]
+    run = lambda env: json.loads(subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True,
+                                                env=dict(base, **env)).stdout)
     tol = 1e-12 if X == "f64" else 2e-6
-    for anti in ("0", "1"):
-        scalar = run({"MC_HOST_SCALAR": "1", "MC_ANTITHETIC": anti})
-        _, o = po.dev_vanilla(X, dict(s=100.0, k=100.0, r=0.04879, v=0.2, t=1.0), SEED,
-                              0, 1000003, want_paths=False, antithetic=anti == "1")
+    b = dict(s=[100.0] * 3, v=[0.2, 0.3, 0.2], p=Lf, d=[0.0, 0.01, -0.01], w=[0.3, 0.3, 0.4], k=100.0, t=1.0, r=0.048790164)
+    c = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6, n_grid=250)
+    for est in ({}, {"MC_ANTITHETIC": "1"}, {"MC_CONTROL_VARIATE": "1"}, {"MC_ANTITHETIC": "1", "MC_CONTROL_VARIATE": "1"}):
+        anti, cv = "MC_ANTITHETIC" in est, "MC_CONTROL_VARIATE" in est
+        scalar = run(dict(est, MC_HOST_SCALAR="1"))
+        want = []
+        _, o = po.dev_vanilla(X, dict(s=100.0, k=100.0, r=0.04879, v=0.2, t=1.0), SEED, 0, 1000003, want_paths=False, antithetic=anti)
+        want += [o["expected"], o["confidence"]]
+        _, o = po.dev_basket(X, b, SEED, 0, 70001, want_paths=False, antithetic=anti, control=cv)
+        want += [o["expected"], o["confidence"]]       # with the control variate: its closed-form mean already added back
+        _, o = po.dev_cva(X, c, SEED, 0, 3001, want_paths=False, antithetic=anti)
+        want += [o["expected"], o["confidence"]]
         for isa in ("base", "avx2", "avx512", ""):      # "" = whatever the CPU supports; an unsupported request falls back
-            got = run({"MC_HOST_ISA": isa, "MC_ANTITHETIC": anti} if isa else {"MC_ANTITHETIC": anti})
-            assert got[0] == pytest.approx(scalar[0], rel=tol) and got[1] == pytest.approx(scalar[1], rel=tol), (isa, anti)
-            assert got[0] == pytest.approx(o["expected"], rel=tol) and got[1] == pytest.approx(o["confidence"], rel=tol), (isa, anti)
+            got = run(dict(est, MC_HOST_ISA=isa) if isa else est)
+            for k in range(6):
+                # confidences of the control-variate estimator are differences of nearly equal numbers: looser
+                t_k = tol * (50 if (cv and k in (2, 3)) or k == 5 else 1)
+                assert got[k] == pytest.approx(scalar[k], rel=t_k), (isa, est, k)
+                assert got[k] == pytest.approx(want[k], rel=t_k), (isa, est, k)
 
 
 def test_thread_count_follows_the_override_and_the_cpu_quota(po):

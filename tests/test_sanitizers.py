@@ -23,7 +23,7 @@ def test_cpu_code_is_clean_under_asan_ubsan(tmp_path, flag, n):
                         ("avx512", ["-march=skylake-avx512", "-mprefer-vector-width=512"])):
         obj = tmp_path / f"host_simd_{name}.o"
         subprocess.check_call(["gcc", "-std=gnu11", "-O3", "-ffast-math", "-fopenmp-simd", *san, *march, *([flag] if flag else []),
-                               f"-DMC_SIMD_NAME=mc_host_vanilla_units_{name}", f"-I{ROOT}/include", "-c", "-o", str(obj),
+                               f"-DMC_SIMD_SUFFIX={name}", f"-DN={n}", f"-I{ROOT}/include", "-c", "-o", str(obj),
                                os.path.join(CSRC, "host_simd.c")])
         simd.append(str(obj))
     cmd = ["gcc", "-std=gnu11", "-O1", *san, "-fopenmp",
