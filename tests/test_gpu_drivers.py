@@ -65,8 +65,15 @@ def test_basket_driver_with_sixteen_assets(X, tmp_path):
     common = ["-DN=16", f"-I{inc}", *prec, f"-L{csrc}", "-lmc_mi355x", f"-Wl,-rpath,{csrc}"]
     subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-o", str(tmp_path / f"libmcgpu_{X}.so"),
                            os.path.join(csrc, "legacy_abi.c"), *common])
+    simd = []   # host_simd.c: one copy per vector ISA, as the Makefile builds them
+    for name, march in (("base", ["-march=x86-64"]), ("avx2", ["-march=haswell"]),
+                        ("avx512", ["-march=skylake-avx512", "-mprefer-vector-width=512"])):
+        obj = tmp_path / f"host_simd_{name}.o"
+        subprocess.check_call(["gcc", "-O3", "-ffast-math", "-fopenmp-simd", "-std=gnu11", "-fPIC", *march, *prec, "-DN=16",
+                               f"-DMC_SIMD_SUFFIX={name}", f"-I{inc}", "-c", "-o", str(obj), os.path.join(csrc, "host_simd.c")])
+        simd.append(str(obj))
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-fopenmp", "-ffp-contract=off", "-fPIC", "-shared", "-o",
-                           str(tmp_path / f"libmchost_{X}.so"), os.path.join(csrc, "host_path.c"), *common, "-lm"])
+                           str(tmp_path / f"libmchost_{X}.so"), os.path.join(csrc, "host_path.c"), *simd, *common, "-lmvec", "-lm"])
     exe = tmp_path / f"basketOpt16_{X}"
     # the scratch directory comes first on the link line and in the run path: csrc holds N = 3 builds of the same names
     subprocess.check_call(["gcc", "-O2", "-std=gnu11", "-DN=16", f"-I{inc}", *prec, f"-I{os.path.join(ROOT, 'drivers')}", "-o", str(exe),
