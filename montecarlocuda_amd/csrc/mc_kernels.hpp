@@ -1244,6 +1244,17 @@ __device__ __forceinline__ double hastings_poly(double k)
     return poly * k;
 }
 
+// the same polynomial times 1/sqrt(2 pi): coefficients pre-multiplied (each rounded once, at compile time)
+__device__ __forceinline__ double hastings_poly_phi(double k)
+{
+    constexpr double C = 0.39894228040143267793994605993438;
+    double poly = __builtin_fma(k, C * 1.330274429, C * -1.821255978);
+    poly = __builtin_fma(k, poly, C * 1.781477937);
+    poly = __builtin_fma(k, poly, C * -0.356563782);
+    poly = __builtin_fma(k, poly, C * 0.31938153);
+    return poly * k;
+}
+
 __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const CvaStep<double> &st)
 {
     const double spot = exp_f64(ln_spot);
@@ -1274,20 +1285,29 @@ __device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaS
     // the addends read straight from their SGPRs by the three-operand form -- same fma, same bits, 3 instructions per
     // date instead of 6.
 #ifndef MC_AB_CVA_NO_VGPR_CONST
-    const double g_a = to_vgpr(sa.g), g_b = to_vgpr(sb.g);
+    const double g_a = scalar_to_vgpr(sa.g), g_b = scalar_to_vgpr(sb.g);
     const double d1a = fma_scalar_addend(W_a, g_a, sa.e1), d2a = fma_scalar_addend(W_a, g_a, sa.e2);
     const double d1b = fma_scalar_addend(W_b, g_b, sb.e1), d2b = fma_scalar_addend(W_b, g_b, sb.e2);
 #else
     const double d1a = __builtin_fma(W_a, sa.g, sa.e1), d2a = __builtin_fma(W_a, sa.g, sa.e2);
     const double d1b = __builtin_fma(W_b, sb.g, sb.e1), d2b = __builtin_fma(W_b, sb.g, sb.e2);
 #endif
-    const double A_a = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));  // d1 runs away as tau -> 0
+#ifndef MC_AB_CVA_NO_PHI_FOLD
+    // A = C exp(.) with C = 1/sqrt(2 pi) folded into the Hastings coefficients (hastings_poly_phi): one multiply less per date
+    const double A_a = exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));  // d1 runs away as tau -> 0
+    const double A_b = exp_f64(fmax(__builtin_fma(-0.5 * d1b, d1b, ln_b), -800.0));
+#define MC_HASTINGS hastings_poly_phi
+#else
+    const double A_a = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));
     const double A_b = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1b, d1b, ln_b), -800.0));
+#define MC_HASTINGS hastings_poly
+#endif
     double k1a, k2a, k1b, k2b;
     recip4_pos(__builtin_fma(0.2316419, fabs(d1a), 1.0), __builtin_fma(0.2316419, fabs(d2a), 1.0),
                __builtin_fma(0.2316419, fabs(d1b), 1.0), __builtin_fma(0.2316419, fabs(d2b), 1.0), k1a, k2a, k1b, k2b);
-    const double t1a = A_a * hastings_poly(k1a), t2a = A_a * hastings_poly(k2a);
-    const double t1b = A_b * hastings_poly(k1b), t2b = A_b * hastings_poly(k2b);
+    const double t1a = A_a * MC_HASTINGS(k1a), t2a = A_a * MC_HASTINGS(k2a);
+    const double t1b = A_b * MC_HASTINGS(k1b), t2b = A_b * MC_HASTINGS(k2b);
+#undef MC_HASTINGS
     ee_a = (d1a > 0 ? spot_a - t1a : t1a) - (d2a > 0 ? sa.disc - t2a : t2a);
     ee_b = (d1b > 0 ? spot_b - t1b : t1b) - (d2b > 0 ? sb.disc - t2b : t2b);
 #endif
