@@ -14,7 +14,7 @@
 //   sincos_turns(u)    ~36                quadrant from rint(4u), Taylor to y^15 / y^16 on |y| <= 1/2
 //   recip_pos(d)       ~5                 v_rcp_f64 + two Newton steps
 //   exp_f64(x)         ~19                n = rint(x log2 e), two-step reduction, Taylor to r^13, v_ldexp_f64
-//                      ~15 + ds_read      (default) 64-entry table of 2^(j/64), Taylor to r^5
+//                      ~13 + ds_read      (default) 256-entry table of 2^(j/256), Taylor to r^4
 //
 // The two functions inside Box-Muller additionally have table-driven forms (the default), which trade
 // polynomial length for one 16-byte LDS read each -- LDS reads do not occupy the VALU:
@@ -54,17 +54,17 @@ MC_COEF_STORAGE double COS_Q[8] = {-1.2337005501361697,     0.25366950790104803,
 // ---- lookup tables (LDS) --------------------------------------------------------------------------
 struct alignas(16) F64Pair { double x, y; };
 // rows 0..127: {c2_i, t_i} of the log table; rows 128..383: {sin, cos} at the centre of angle slot i;
-// rows 384..415: 2^(j/64), j = 0..63, two per row
+// rows 384..511: 2^(j/256), j = 0..255, two per row
 // (tools/gen_f64_tables.py; 60-digit arithmetic, rounded once)
-__device__ const F64Pair F64_TABLES_ROM[416] = {
+__device__ const F64Pair F64_TABLES_ROM[512] = {
 #include "mc_tables_f64.inc"
 };
-__shared__ F64Pair f64_tables[416];  // 6.5 KB of LDS per workgroup, filled by stage_f64_tables()
+__shared__ F64Pair f64_tables[512];  // 8 KB of LDS per workgroup, filled by stage_f64_tables()
 
 // Every fp64 kernel calls this first (all threads; ends in a barrier).
 __device__ __forceinline__ void stage_f64_tables()
 {
-    for (int i = threadIdx.x; i < 416; i += blockDim.x)
+    for (int i = threadIdx.x; i < 512; i += blockDim.x)
         f64_tables[i] = F64_TABLES_ROM[i];
     __syncthreads();
 }
@@ -72,25 +72,26 @@ __device__ __forceinline__ void stage_f64_tables()
 // e^x for finite x (underflows to 0 through v_ldexp_f64; these kernels never overflow it):
 // x = n ln2 + r, |r| <= ln2/2, Taylor to r^13: 19 instructions, max error 0.86 ulp.
 #if !defined(MC_AB_OCML_EXP) && !defined(MC_AB_EXP_POLY) && !defined(MC_AB_NO_TABLES)
-// Table-driven: x = (64 e + j) ln2/64 + r, |r| <= ln2/128;  e^x = 2^e * T_j * (1 + r + r^2/2 + ... + r^5/120).
-// 14 instructions + one 8-byte LDS read; max error 1.03 ulp (tools/check_f64_tables.c).
+// Table-driven: x = (256 e + j) ln2/256 + r, |r| <= ln2/512;  e^x = 2^e * T_j * (1 + r + r^2/2 + r^3/6 + r^4/24).
+// 13 instructions + one 8-byte LDS read; the dropped term r^5/120 is below 4e-17 relative.  (Round 1 and most of round 2:
+// 64 entries and one more Horner step; the 2 KB table buys one fp64 instruction per exponential -- 16 per 16-asset basket
+// path, 2 per CVA date: profiles/r02_ab_exp256.log.)  Max error: tools/check_f64_tables.c.
 __device__ __forceinline__ double exp_f64(double x)
 {
-    // n = rint(64 x / ln 2) by the 1.5 * 2^52 trick: after the fma the integer sits in the low mantissa bits,
-    // so the int conversion is a register read and the rounding is the fma's own.  PRECONDITION |x| < 2e7
+    // n = rint(256 x / ln 2) by the 1.5 * 2^52 trick: after the fma the integer sits in the low mantissa bits,
+    // so the int conversion is a register read and the rounding is the fma's own.  PRECONDITION |x| < 5e6
     // (|n| < 2^31): beyond it the low word is garbage and so is the result -- callers whose argument can run
     // away (CVA's exp(-d1^2/2) next to maturity) clamp it first.
-    const double shifted = __builtin_fma(x, 92.332482616893656877, 0x1.8p52);
+    const double shifted = __builtin_fma(x, 369.32993046757462751, 0x1.8p52);
     const double n = shifted - 0x1.8p52;
-    double r = __builtin_fma(n, -6.93147180369123816490e-01 / 64, x);
-    r = __builtin_fma(n, -1.90821492927058770002e-10 / 64, r);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01 / 256, x);
+    r = __builtin_fma(n, -1.90821492927058770002e-10 / 256, r);
     const int ni = __double2loint(shifted);
-    const double T = reinterpret_cast<const double *>(f64_tables + 384)[ni & 63];
-    double p = __builtin_fma(r, 1.0 / 120, 1.0 / 24);
-    p = __builtin_fma(r, p, 1.0 / 6);
+    const double T = reinterpret_cast<const double *>(f64_tables + 384)[ni & 255];
+    double p = __builtin_fma(r, 1.0 / 24, 1.0 / 6);
     p = __builtin_fma(r, p, 0.5);
     p = __builtin_fma(r, p, 1.0);
-    return __builtin_amdgcn_ldexp(__builtin_fma(T, r * p, T), ni >> 6);
+    return __builtin_amdgcn_ldexp(__builtin_fma(T, r * p, T), ni >> 8);
 }
 #elif !defined(MC_AB_OCML_EXP)
 __device__ __forceinline__ double exp_f64(double x)

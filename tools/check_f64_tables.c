@@ -8,7 +8,7 @@
 #include <string.h>
 
 typedef struct { double x, y; } d2;
-static const d2 TAB[416] = {
+static const d2 TAB[512] = {
 #include "../montecarlocuda_amd/csrc/mc_tables_f64.inc"
 };
 
@@ -57,19 +57,18 @@ static void sincos_turns_tab(uint32_t lo, uint32_t hi, double *s, double *c)
 
 static double exp_tab(double x)
 {
-    const double shifted = fma(x, 92.332482616893656877, 0x1.8p52);   /* 64 / ln 2; integer lands in the low mantissa bits */
+    const double shifted = fma(x, 369.32993046757462751, 0x1.8p52);   /* 256 / ln 2; integer lands in the low mantissa bits */
     const double n = shifted - 0x1.8p52;
-    double r = fma(n, -6.93147180369123816490e-01 / 64, x);
-    r = fma(n, -1.90821492927058770002e-10 / 64, r);
+    double r = fma(n, -6.93147180369123816490e-01 / 256, x);
+    r = fma(n, -1.90821492927058770002e-10 / 256, r);
     uint32_t shi, slo;
     split(shifted, &shi, &slo);
     const int ni = (int)slo;
-    const double T = ((const double *)(TAB + 384))[ni & 63];
-    double p = fma(r, 1.0 / 120, 1.0 / 24);
-    p = fma(r, p, 1.0 / 6);
+    const double T = ((const double *)(TAB + 384))[ni & 255];
+    double p = fma(r, 1.0 / 24, 1.0 / 6);
     p = fma(r, p, 0.5);
     p = fma(r, p, 1.0);
-    return ldexp(fma(T, r * p, T), ni >> 6);
+    return ldexp(fma(T, r * p, T), ni >> 8);
 }
 
 static uint64_t st = 88172645463325252ull;
