@@ -5,13 +5,14 @@
  * 1e7 paths, fp64) -- and 10x those sizes, as SURVEY 8e asks -- sharded over G = 1, 2, 4, 8 ... devices with
  * mc_multi_* (include/mc_multi.h: shards + one RCCL all-reduce of the 24-byte triple).  Timed as SURVEY 8d/8e
  * prescribe: wall-clock from the first launch to the all-reduced, closed estimate on the host; 2 warm-ups, then
- * `reps` calls, median and minimum reported; handle (contexts + RCCL communicators) creation reported once,
+ * `reps` calls (without the per-device HIP events unless --events; one more call with them gives kernel_ms), median and
+ * minimum reported; handle (contexts + RCCL communicators) creation reported once,
  * separately.  One JSON object per line on stdout: bench.py embeds them ("c_multi"), people read them.
  *
  * Then, on the first device alone, shard 0 of G = 2, 4, 8 of every workload: the device side of the scaling curve,
  * measurable without the other devices ("shard_of" lines).
  *
- *   multiBench [--reps R] [--max-devices G] [--small]     (--small: 1/100 of the sizes, for tests)
+ *   multiBench [--reps R] [--max-devices G] [--small] [--events]    (--small: 1/100 of the sizes, for tests)
  */
 #include "driver_util.h"
 #include "mc_multi.h"
@@ -32,14 +33,15 @@ static int cmp_double(const void *a, const void *b)
 
 int main(int argc, char **argv)
 {
-    int reps = 5, max_devices = 64, small = 0, timing = 1;
+    int reps = 5, max_devices = 64, small = 0, events = 0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--max-devices") && i + 1 < argc) max_devices = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--small")) small = 1;
-        else if (!strcmp(argv[i], "--no-events")) timing = 0;   /* mc_multi_set_timing(m, 0): kernel_ms reads 0 */
+        else if (!strcmp(argv[i], "--events")) events = 1;      /* keep the per-device HIP events during the timed calls too */
+        else if (!strcmp(argv[i], "--no-events")) events = 0;   /* the default, accepted for old command lines */
         else {
-            fprintf(stderr, "usage: %s [--reps R] [--max-devices G] [--small] [--no-events]\n", argv[0]);
+            fprintf(stderr, "usage: %s [--reps R] [--max-devices G] [--small] [--events]\n", argv[0]);
             return 1;
         }
     }
@@ -70,20 +72,22 @@ int main(int argc, char **argv)
         mc_multi *m;
         const double t_create0 = now_s();
         CHECK(mc_multi_create(NULL, G, 0, &m));
-        CHECK(mc_multi_set_timing(m, timing));
         mc_result r;
         CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, 0, 1000, &r));   /* creates the RCCL communicators */
         const double create_s = now_s() - t_create0;
         printf("{\"devices\": %d, \"create_s\": %.3f, \"what\": \"contexts + ncclCommInitAll + first call, once per handle\"}\n", G, create_s);
         for (int k = 0; k < 4; ++k) {
             double t[100];
-            for (int i = -2; i < reps; ++i) {
+            /* the timed calls run without the per-device HIP events (two runtime calls less per device on the launching
+             * thread); call `reps` (not timed) runs with them, for kernel_ms */
+            for (int i = -2; i <= reps; ++i) {
+                CHECK(mc_multi_set_timing(m, events || i == reps));
                 const double t0 = now_s();
                 if (work[k].is_cva)
                     CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, 0, work[k].paths, &r));
                 else
                     CHECK(mc_multi_basket_run_f64(m, &c4, MC_DEFAULT_SEED, 0, work[k].paths, &r));
-                if (i >= 0)
+                if (i >= 0 && i < reps)
                     t[i] = now_s() - t0;
             }
             qsort(t, (size_t)reps, sizeof t[0], cmp_double);
@@ -107,20 +111,20 @@ int main(int argc, char **argv)
         mc_multi *m;
         mc_result r;
         CHECK(mc_multi_create(NULL, 1, 0, &m));
-        CHECK(mc_multi_set_timing(m, timing));
         CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, 0, 1000, &r));
         for (int G = 2; G <= 8; G *= 2)
             for (int k = 0; k < 4; ++k) {
                 uint64_t lo = 0, cnt = 0;
                 mc_shard_range(work[k].paths, 0, G, &lo, &cnt);
                 double t[100];
-                for (int i = -2; i < reps; ++i) {
+                for (int i = -2; i <= reps; ++i) {
+                    CHECK(mc_multi_set_timing(m, events || i == reps));
                     const double t0 = now_s();
                     if (work[k].is_cva)
                         CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, lo, cnt, &r));
                     else
                         CHECK(mc_multi_basket_run_f64(m, &c4, MC_DEFAULT_SEED, lo, cnt, &r));
-                    if (i >= 0)
+                    if (i >= 0 && i < reps)
                         t[i] = now_s() - t0;
                 }
                 qsort(t, (size_t)reps, sizeof t[0], cmp_double);
