@@ -410,6 +410,33 @@ static int grid_for(const mc_context *c, uint32_t n_units)
     return (int)(need < (uint64_t)c->blocks ? (need ? need : 1) : c->blocks);
 }
 
+// Vanilla launches whose units are cheap (4 or 2 paths each): a SMALL call is dominated by what grows with the grid --
+// dispatch, one pair and one ticket per workgroup, the last arriver's sum over the pairs -- not by the simulation.  So a
+// lane gets at least 4 units before the grid grows beyond one workgroup per CU: the 8 x 131 072-path call (the reference
+// drivers' smallest size) runs 256 workgroups instead of 1024 (kernel 7.9 instead of 8.8 us in fp32, 10.1 instead of 12.0 in fp64:
+// profiles/r02_call_latency.log); from 2.1e6 units (8.4e6 fp32 paths) on the grid is the context's `blocks` as before (16 units per lane
+// measured no better at 1e7 paths).  MC_VANILLA_UNITS_PER_LANE=1 restores
+// one unit per lane.
+static int vanilla_units_per_lane()
+{
+    static const int v = [] {
+        const char *e = getenv("MC_VANILLA_UNITS_PER_LANE");
+        const int x = e ? atoi(e) : 4;
+        return x < 1 ? 1 : (x > 1024 ? 1024 : x);
+    }();
+    return v;
+}
+static int grid_for_vanilla(const mc_context *c, uint32_t n_units)
+{
+    const int full = grid_for(c, n_units);
+    const uint64_t per = (uint64_t)GROUP * (uint64_t)vanilla_units_per_lane();
+    uint64_t want = ((uint64_t)n_units + per - 1) / per;
+    const uint64_t floor_wgs = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256);
+    if (want < floor_wgs)
+        want = floor_wgs;
+    return (int)(want < (uint64_t)full ? want : (uint64_t)full);
+}
+
 // One pricing call = one or more simulation launches that share the context's pair buffer.  The Tail tells every
 // launch where its pairs go and how many pairs the whole call has, so that the last workgroup to arrive can close the
 // call inside the kernel (mc_reduce.hpp); in the two-launch form (MC_FINISH=kernel) total stays 0 and
@@ -812,14 +839,15 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         has_head = (first % NPB) != 0;
         has_tail = (end % NPB) != 0 && !(has_head && tail_unit == head);
     }
+    const auto grid = [&](uint32_t units) { return out ? grid_for(c, units) : grid_for_vanilla(c, units); };
     int total = (has_head ? 1 : 0) + (has_tail ? 1 : 0);
     for (const Segment &s : segs)
-        total += grid_for(c, s.count);
+        total += grid(s.count);
     Tail t = make_tail(c, total, scale1, scale2, n, d_triple);
     int slot = 0;
     for (const Segment &s : segs) {
         const Work w = make_work(seed, s, first, end);
-        const int g = grid_for(c, s.count);
+        const int g = grid(s.count);
         t.slot_base = t.ticket_base = (uint32_t)slot;
         if (out)
             masked<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
