@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/mc_mi355x.h"
+#include "mc_hostmath.h"
 #include "mc_kernels.hpp"
 
 using namespace mc;
@@ -25,20 +26,8 @@ using namespace mc;
 // ---------------------------------------------------------------------------------------
 // errors
 // ---------------------------------------------------------------------------------------
-static thread_local std::string g_last_error;
-
-extern "C" const char *mc_last_error(void) { return g_last_error.c_str(); }
-
-static int fail(int code, const char *fmt, ...)
-{
-    char buf[512];
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
-    va_end(ap);
-    g_last_error = buf;
-    return code;
-}
+// The per-thread error text lives in mc_hostmath.c (the host-only object shared with the CPU twin).
+#define fail(...) mc_internal_fail(__VA_ARGS__)
 
 #define HIPCHK(call)                                                                            \
     do {                                                                                        \
@@ -149,6 +138,18 @@ extern "C" int mc_device_count(void)
     return n;
 }
 
+// Wait for everything the context has enqueued, on its own stream AND on the caller stream of its most recent call
+// (mc_*_launch_* may run anywhere; calls on earlier streams are ordered before that one by begin_call).  Used before
+// anything the kernels touch is freed or reallocated.
+static int quiesce(mc_context *c)
+{
+    if (c->stream)
+        HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->used && c->last_stream != c->stream)
+        HIPCHK(hipStreamSynchronize(c->last_stream));
+    return MC_OK;
+}
+
 static int context_allocate(mc_context *c)
 {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -208,8 +209,7 @@ extern "C" void mc_context_destroy(mc_context *c)
     if (!c)
         return;
     (void)hipSetDevice(c->device);
-    if (c->stream)
-        (void)hipStreamSynchronize(c->stream);
+    (void)quiesce(c);   // the launch API runs on caller streams too: nothing of this context may still be in flight
     (void)hipFree(c->partials);
     (void)hipFree(c->tickets);
     (void)hipFree(c->d_xorwow);
@@ -278,51 +278,9 @@ extern "C" int mc_context_set_control_variate(mc_context *c, int on)
     return MC_OK;
 }
 
-// E[max(G - K, 0)] of the geometric-basket control, closed form in fp64 (see mc_mi355x.h)
-template <class B>
-static int control_mean(const B &o, double *mean)
-{
-    if (!mean || o.n < 1 || o.n > MC_MAX_ASSETS_GENERIC || !o.s || !o.v || !o.p || !o.d || !o.w)
-        return fail(MC_ERR_INVALID, "control variate: bad basket");
-    const int n = o.n;
-    double W = 0;
-    for (int a = 0; a < n; ++a) {
-        if (!((double)o.w[a] > 0) || !((double)o.s[a] > 0))
-            return fail(MC_ERR_INVALID, "control variate: needs w[a] > 0 and s[a] > 0 for every asset");
-        W += (double)o.w[a];
-    }
-    if (!((double)o.k > 0))
-        return fail(MC_ERR_INVALID, "control variate: needs k > 0");
-    const double sqrt_t = std::sqrt((double)o.t);
-    double m = std::log(W), var = 0;
-    for (int a = 0; a < n; ++a) {
-        const double va = (double)o.v[a];
-        m += (double)o.w[a] / W * (std::log((double)o.s[a]) + ((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]);
-    }
-    for (int b = 0; b < n; ++b) {
-        double cb = 0;
-        for (int a = b; a < n; ++a)
-            cb += (double)o.w[a] / W * (double)o.v[a] * sqrt_t * (double)o.p[a * n + b];
-        var += cb * cb;
-    }
-    const double sd = std::sqrt(var);
-    if (sd == 0) {
-        const double g = std::exp(m) - (double)o.k;
-        *mean = g > 0 ? g : 0;
-        return MC_OK;
-    }
-    const double d1 = (m - std::log((double)o.k) + var) / sd, d2 = d1 - sd;
-    *mean = std::exp(m + 0.5 * var) * 0.5 * std::erfc(-d1 / std::sqrt(2.0)) - (double)o.k * 0.5 * std::erfc(-d2 / std::sqrt(2.0));
-    return MC_OK;
-}
-extern "C" int mc_basket_control_mean_f32(const mc_basket_f32 *o, double *mean)
-{
-    return o ? control_mean(*o, mean) : fail(MC_ERR_INVALID, "NULL basket");
-}
-extern "C" int mc_basket_control_mean_f64(const mc_basket_f64 *o, double *mean)
-{
-    return o ? control_mean(*o, mean) : fail(MC_ERR_INVALID, "NULL basket");
-}
+// E[max(G - K, 0)] of the geometric-basket control: mc_hostmath.c (closed form in fp64, see mc_mi355x.h)
+static int control_mean(const mc_basket_f32 &o, double *mean) { return mc_basket_control_mean_f32(&o, mean); }
+static int control_mean(const mc_basket_f64 &o, double *mean) { return mc_basket_control_mean_f64(&o, mean); }
 
 extern "C" int mc_context_profile(mc_context *c, int every)
 {
@@ -510,7 +468,16 @@ static int finish_call(mc_context *c, const Tail &t, int total, hipStream_t st)
         for (uint32_t q = 0; q < t.planes; ++q)
             finish_kernel<<<1, GROUP, 0, st>>>(t.partials + (size_t)q * t.plane_stride, total, t.scale1, t.scale2, t.n_paths,
                                                t.triple + 3 * q);
-    HIPCHK(hipGetLastError());
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        // Some launches of the call may have been enqueued and will draw tickets, but the call will never reach its
+        // `total`: left alone the ticket block stays non-zero and every later call on the context would close early or
+        // never.  Drain what was enqueued and put the tickets back to zero before reporting the error.
+        (void)hipStreamSynchronize(st);
+        (void)hipMemsetAsync(c->tickets, 0, sizeof(uint32_t) * TICKET_WORDS, st);
+        (void)hipStreamSynchronize(st);
+        return fail(MC_ERR_HIP, "kernel launch failed: %s (the call's tickets were reset)", hipGetErrorString(e));
+    }
     return MC_OK;
 }
 
@@ -659,7 +626,7 @@ static int ensure_out(mc_context *c, size_t bytes)
     if (c->d_out_bytes >= bytes)
         return MC_OK;
     if (c->d_out) {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        if (int rc = quiesce(c)) return rc;
         HIPCHK(hipFree(c->d_out));
         c->d_out = nullptr;
         c->d_out_bytes = 0;
@@ -679,6 +646,7 @@ static int upload_table(mc_context *c, hipStream_t st, const std::vector<char> &
         if (bytes > c->table_bytes) {
             HIPCHK(hipStreamSynchronize(st));
             if (c->table_stream && c->table_stream != st) HIPCHK(hipStreamSynchronize(c->table_stream));
+            if (int rc = quiesce(c)) return rc;   // a launch on another caller stream may still read the old table
             if (c->d_table) HIPCHK(hipFree(c->d_table));
             if (c->h_table) HIPCHK(hipHostFree(c->h_table));
             c->table_bytes = bytes < 4096 ? 4096 : bytes;
@@ -706,7 +674,7 @@ static int upload_table(mc_context *c, hipStream_t st, const std::vector<char> &
 // ---------------------------------------------------------------------------------------
 static inline bool finite_pos(double x) { return std::isfinite(x) && x > 0; }
 
-// The fp64 kernels' exp is table-driven with a rounding trick that needs |x| < 2e7 (mc_math_f64.hpp); any model
+// The fp64 kernels' exp is table-driven with a rounding trick that needs |x| < EXP_F64_ARG_LIMIT = 5e6 (mc_math_f64.hpp); any model
 // whose exponent can leave the range of a double (|x| > ~700 at the generator's largest normal) is rejected up
 // front instead of pricing garbage.  The 52-bit uniform bottoms out at 2^-53: |z| <= sqrt(2 * 53 ln 2) = 8.572.
 constexpr double Z_MAX_F64 = 8.58;
@@ -731,16 +699,18 @@ template <> struct VanillaTraits<float> {
     }
     static int prepare(const In &o, Opt &k_, double &scale1, double &scale2)
     {
-        if (!finite_pos(o.s) || !finite_pos(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
-            return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
+        // the reference's max(S_T - K, 0) (dp/MonteCarloKernel.cu:70) is defined for any strike: K <= 0 is accepted
+        if (!finite_pos(o.s) || !std::isfinite(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
+            return fail(MC_ERR_INVALID, "vanilla: need s>0, finite k, v>=0, t>=0, finite r");
         const double log2e = 1.4426950408889634074;
         const double drift = ((double)o.r - 0.5 * (double)o.v * (double)o.v) * (double)o.t;
         const double vol = (double)o.v * std::sqrt((double)o.t);
         const double a2 = drift * log2e, b2 = vol * log2e;
         // Box-Muller on 32-bit uniforms cannot exceed |z| = sqrt(2 * 33 ln 2) = 6.764 (u >= 2^-33);
-        // k makes 2^(a2 - k + b2 z) <= 1 for all of them, so the device's [0,1] clamp is exact.
+        // k makes 2^(a2 - k + b2 z) - K/(S 2^k) <= 1 for all of them, so the device's [0,1] clamp is exact.
+        // A negative strike RAISES the payoff (S_T + |K|): it enters the bound like the basket's does (basket_launch_n).
         const double zmax = 6.77;
-        const double k = std::ceil(a2 + b2 * zmax);
+        const double k = std::ceil(std::log2(std::exp2(a2 + b2 * zmax) + ((double)o.k < 0 ? -(double)o.k / (double)o.s : 0.0)));
         if (!(std::fabs(k) < 100))
             return fail(MC_ERR_INVALID, "vanilla f32: drift/volatility out of the float range (k=%g)", k);
         const double two_k = std::ldexp(1.0, (int)k);
@@ -770,8 +740,8 @@ template <> struct VanillaTraits<double> {
     }
     static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
     {
-        if (!finite_pos(o.s) || !finite_pos(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
-            return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
+        if (!finite_pos(o.s) || !std::isfinite(o.k) || !(o.v >= 0) || !(o.t >= 0) || !std::isfinite(o.r))
+            return fail(MC_ERR_INVALID, "vanilla: need s>0, finite k, v>=0, t>=0, finite r");
         k.drift = (o.r - 0.5 * o.v * o.v) * o.t;
         k.vol = o.v * std::sqrt(o.t);
         k.strike = o.k;
@@ -897,7 +867,7 @@ static int ensure_planes(mc_context *c, int planes)
 {
     if (planes <= c->g_planes)
         return MC_OK;
-    HIPCHK(hipStreamSynchronize(c->stream));
+    if (int rc = quiesce(c)) return rc;
     if (c->g_pairs) HIPCHK(hipFree(c->g_pairs));
     if (c->g_triples) HIPCHK(hipFree(c->g_triples));
     c->g_pairs = nullptr, c->g_triples = nullptr, c->g_planes = 0;
@@ -922,6 +892,7 @@ static int planes_run(mc_context *c, int planes, int grid_y, uint64_t unit0, uin
     if (int rc = plan_segments(unit0, n_units, segs)) return rc;
     if (segs.size() > 2)   // a plane holds the pairs of two full launches
         return fail(MC_ERR_INVALID, "greeks: path range too large for one call; split it");
+    HIPCHK(hipMemsetAsync(c->g_triples, 0xFF, sizeof(double) * 3 * (size_t)planes, st));   // poison: see run_sync
     HIPCHK(hipEventRecord(c->ev0, st));
     int pairs = 0;
     for (const Segment &s : segs)
@@ -948,6 +919,9 @@ static int planes_run(mc_context *c, int planes, int grid_y, uint64_t unit0, uin
     const float wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
     for (int q = 0; q < planes; ++q) {
         mc_result *r = out[q];
+        if (!(h[3 * q + 2] == (double)n))
+            return fail(MC_ERR_HIP, "device returned n=%g, expected %llu: the call's final reduction did not complete", h[3 * q + 2],
+                        (unsigned long long)n);
         r->sum = h[3 * q], r->sum2 = h[3 * q + 1], r->n = (uint64_t)h[3 * q + 2], r->kernel_ms = ms, r->wall_ms = wall;
         if (r->n != n)
             return fail(MC_ERR_HIP, "device returned n=%llu, expected %llu", (unsigned long long)r->n, (unsigned long long)n);
@@ -960,8 +934,8 @@ template <class Real, class In, class Opt, bool LR>
 static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first, uint64_t n, mc_vanilla_greeks *out)
 {
     if (int rc = check_common(c, o, first, n, out)) return rc;
-    if (!finite_pos(o->s) || !finite_pos(o->k) || !(o->v >= 0) || !(o->t >= 0) || !std::isfinite((double)o->r))
-        return fail(MC_ERR_INVALID, "vanilla: need s>0, k>0, v>=0, t>=0, finite r");
+    if (!finite_pos(o->s) || !std::isfinite((double)o->k) || !(o->v >= 0) || !(o->t >= 0) || !std::isfinite((double)o->r))
+        return fail(MC_ERR_INVALID, "vanilla: need s>0, finite k, v>=0, t>=0, finite r");
     if (LR && !((double)o->v > 0 && (double)o->t > 0))
         return fail(MC_ERR_INVALID, "likelihood-ratio greeks: need v>0 and t>0 (the scores divide by sigma sqrt t)");
     if (c->antithetic)
@@ -1382,8 +1356,9 @@ static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaS
     args.lgd = v.lgd;
     args.strike = o.k;
     // W is a sum of up to n_grid normals: its worst case is astronomically unlikely, so only the hard limit of the
-    // device's exp (|x| < 2e7) is enforced here; an honest overflow of the spot gives inf, as it would on any machine
-    if (!(std::fabs(ln_s0) + (double)v.n_grid * (std::fabs((double)step_drift) + std::fabs((double)step_vol) * Z_MAX_F64) < 1e7))
+    // device's exp (EXP_F64_ARG_LIMIT, mc_math_f64.hpp) is enforced here; below it an honest overflow of the spot gives
+    // inf, as it would on any machine (beyond it the table index would wrap and return a finite wrong spot)
+    if (!(std::fabs(ln_s0) + (double)v.n_grid * (std::fabs((double)step_drift) + std::fabs((double)step_vol) * Z_MAX_F64) < EXP_F64_ARG_LIMIT))
         return fail(MC_ERR_INVALID, "cva: drift and volatility put the simulated spot outside the range of a double");
     return MC_OK;
 }
@@ -1575,85 +1550,7 @@ extern "C" int mc_cva_greeks_run_f64(mc_context *c, const mc_cva_f64 *v, uint64_
 // ---------------------------------------------------------------------------------------
 // closing + sync wrappers
 // ---------------------------------------------------------------------------------------
-extern "C" void mc_closing(double sum, double sum2, uint64_t n, double discount, double *expected, double *confidence)
-{
-    const double dn = (double)n;
-    if (expected) *expected = discount * (sum / dn);
-    if (confidence) {
-        const double dev = std::sqrt((dn * sum2 - sum * sum) / (dn * (double)(n - 1)));
-        *confidence = 1.96 * dev / std::sqrt(dn);
-    }
-}
-
-extern "C" void mc_shard_range(uint64_t total, int rank, int world, uint64_t *first, uint64_t *count)
-{
-    if (world < 1) world = 1;
-    if (rank < 0) rank = 0;
-    if (rank >= world) rank = world - 1;
-    // floor(rank * total / world) without overflowing 64 bits
-    const unsigned __int128 t = total;
-    const uint64_t lo = (uint64_t)(t * (unsigned)rank / (unsigned)world);
-    const uint64_t hi = (uint64_t)(t * (unsigned)(rank + 1) / (unsigned)world);
-    if (first) *first = lo;
-    if (count) *count = hi - lo;
-}
-
-template <class Real>
-static int chol_impl(int n, const Real *c, Real *a)
-{
-    if (n < 1 || !c || !a)
-        return -1;
-    std::vector<Real> work((size_t)n);
-    int bad = 0;
-    for (int col = 0; col < n; ++col) {
-        for (int row = 0; row < n; ++row) {
-            a[row * n + col] = 0;
-            if (row < col)
-                continue;
-            work[row] = c[row * n + col];
-            for (int q = 0; q < col; ++q)
-                work[row] -= a[col * n + q] * a[row * n + q];
-            if (work[col] > 0)
-                a[row * n + col] = work[row] / std::sqrt(work[col]);
-            else if (row == col)
-                ++bad;
-        }
-    }
-    return bad;
-}
-extern "C" int mc_chol_f32(int n, const float *c, float *a) { return chol_impl<float>(n, c, a); }
-extern "C" int mc_chol_f64(int n, const double *c, double *a) { return chol_impl<double>(n, c, a); }
-
-// Covariance input.  The reference's drivers hold volatilities and a CORRELATION matrix and factor
-// the latter with Chol before either path runs (dp/basketOpt.cu:34-61,96-99); a caller who holds the covariance of
-// the annualised log-returns gets both inputs of the basket structs from it here: v_a = sqrt(cov_aa), correlation
-// cov_ab / (v_a v_b) with an exact unit diagonal, then Chol's factorisation (same arithmetic, same zero-pivot rule,
-// dp/MonteCarloHost.c:90-105).  Like Chol, only the lower triangle of the input is read.  All in Real.
-template <class Real>
-static int factor_from_cov(int n, const Real *cov, Real *v, Real *p)
-{
-    if (n < 1 || !cov || !v || !p)
-        return -1;
-    for (int a = 0; a < n; ++a) {
-        const Real var = cov[a * n + a];
-        if (!(var > 0) || !std::isfinite((double)var))
-            return -1;   // no volatility to extract
-        v[a] = std::sqrt(var);
-    }
-    std::vector<Real> corr((size_t)n * n, (Real)0);
-    for (int a = 0; a < n; ++a) {
-        corr[(size_t)a * n + a] = 1;
-        for (int b = 0; b < a; ++b) {
-            const Real c = cov[a * n + b];
-            if (!std::isfinite((double)c))
-                return -1;
-            corr[(size_t)a * n + b] = corr[(size_t)b * n + a] = c / (v[a] * v[b]);
-        }
-    }
-    return chol_impl<Real>(n, corr.data(), p);
-}
-extern "C" int mc_factor_from_cov_f32(int n, const float *cov, float *v, float *p) { return factor_from_cov<float>(n, cov, v, p); }
-extern "C" int mc_factor_from_cov_f64(int n, const double *cov, double *v, double *p) { return factor_from_cov<double>(n, cov, v, p); }
+// mc_closing, mc_shard_range, mc_chol_*, mc_factor_from_cov_*: mc_hostmath.c (host-only C, shared with the CPU twin)
 
 // run = enqueue on the context stream, wait, read 24 bytes, close.
 //   timing on (default): two HIP events around the kernels (mc_result.kernel_ms), a 24-byte D2H copy, a stream
@@ -1697,6 +1594,9 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         }
         h = c->h_direct;
     } else {
+        // poison the slot (all bits set: NaN): a reduction that never finishes must not hand back the previous call's
+        // triple, whose n word would pass the check below whenever n is unchanged
+        HIPCHK(hipMemsetAsync(c->d_triple, 0xFF, 3 * sizeof(double), c->stream));
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, c->stream));
         if (int rc = enqueue(c->stream, c->d_triple)) return rc;
         if (c->timing) HIPCHK(hipEventRecord(c->ev1, c->stream));
@@ -1704,6 +1604,9 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->timing) HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     }
+    if (!(h[2] == (double)n))   // also catches the poison (NaN) of a reduction that never closed
+        return fail(MC_ERR_HIP, "device returned n=%g, expected %llu: the call's final reduction did not complete", h[2],
+                    (unsigned long long)n);
     out->sum = h[0];
     out->sum2 = h[1];
     out->n = (uint64_t)h[2];

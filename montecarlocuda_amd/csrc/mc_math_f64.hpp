@@ -76,12 +76,15 @@ __device__ __forceinline__ void stage_f64_tables()
 // 13 instructions + one 8-byte LDS read; the dropped term r^5/120 is below 4e-17 relative.  (Round 1 and most of round 2:
 // 64 entries and one more Horner step; the 2 KB table buys one fp64 instruction per exponential -- 16 per 16-asset basket
 // path, 2 per CVA date: profiles/r02_ab_exp256.log.)  Max error: tools/check_f64_tables.c.
+// PRECONDITION of exp_f64: |x| < EXP_F64_ARG_LIMIT.  n = rint(256 x / ln 2) must fit 31 bits (|x| < 5.8e6); the host-side
+// range guards (mc_api.hip) and this comment share the one constant.
+constexpr double EXP_F64_ARG_LIMIT = 5.0e6;
 __device__ __forceinline__ double exp_f64(double x)
 {
     // n = rint(256 x / ln 2) by the 1.5 * 2^52 trick: after the fma the integer sits in the low mantissa bits,
-    // so the int conversion is a register read and the rounding is the fma's own.  PRECONDITION |x| < 5e6
-    // (|n| < 2^31): beyond it the low word is garbage and so is the result -- callers whose argument can run
-    // away (CVA's exp(-d1^2/2) next to maturity) clamp it first.
+    // so the int conversion is a register read and the rounding is the fma's own.  Beyond EXP_F64_ARG_LIMIT the low
+    // word is garbage and so is the result -- callers whose argument can run away (CVA's exp(-d1^2/2) next to
+    // maturity) clamp it first.
     const double shifted = __builtin_fma(x, 369.32993046757462751, 0x1.8p52);
     const double n = shifted - 0x1.8p52;
     double r = __builtin_fma(n, -6.93147180369123816490e-01 / 256, x);

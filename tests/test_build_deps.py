@@ -25,3 +25,17 @@ def test_makefile_lists_every_included_file():
     rule = re.search(r"^libmc_mi355x\.so:(.*)$", text, flags=re.M).group(1).replace("$(INC)", inc).split()
     missing = sorted(n for n in needed if n not in rule)
     assert not missing, f"Makefile rule for libmc_mi355x.so does not depend on {missing}"
+
+
+def test_cpu_twin_needs_no_rocm_runtime():
+    """libmchost_* is the no-GPU path, so it must load where ROCm is absent -- its dynamic section names
+    neither the GPU engine nor the HIP runtime (the shared host math is linked in as an object: mc_hostmath.c)."""
+    import subprocess
+    for X in ("f32", "f64"):
+        lib = os.path.join(CSRC, f"libmchost_{X}.so")
+        assert os.path.exists(lib), f"{lib} not built"
+        dyn = subprocess.run(["readelf", "-d", lib], capture_output=True, text=True, check=True).stdout
+        needed = re.findall(r"\(NEEDED\)\s+Shared library: \[([^\]]+)\]", dyn)
+        assert needed, dyn
+        bad = [n for n in needed if "mc_mi355x" in n or "amdhip" in n or "hsa" in n or "rccl" in n]
+        assert not bad, f"libmchost_{X}.so depends on {bad}"

@@ -686,6 +686,39 @@ def test_basket_zero_and_negative_strike(mc, eng, po, X, n_assets, strike):
 
 
 @pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("strike", [-250.0, -3.5, 0.0])
+def test_vanilla_zero_and_negative_strike(mc, eng, po, X, strike):
+    """The reference's max(S_T - K, 0) (dp/MonteCarloKernel.cu:70) holds for any K; round 2 refused K <= 0 in the vanilla
+    entry points while the basket ones accepted it.  The fp32 hot kernel folds the max into a [0,1] clamp after a
+    power-of-two rescale: |K| must be inside that scale for K < 0 (every path is then worth S_T + |K|).  Per path through
+    the masked kernel, sums through the hot kernel (aligned range) and through the edge launches (unaligned)."""
+    opt = dict(VAN, k=strike)
+    for anti in (False, True):
+        eng.set_antithetic(anti)
+        try:
+            got = f64(eng.vanilla_paths(opt, 4001, SEED, 3, X))
+            e = eng.vanilla(opt, 4001, SEED, 3, X)
+            hot = eng.vanilla(opt, 1 << 16, SEED, 0, X)
+            g3 = eng.vanilla_greeks(opt, 4001, SEED, 3, X)[0] if not anti else None
+        finally:
+            eng.set_antithetic(False)
+        want, o = po.dev_vanilla(X, opt, SEED, 3, 4001, antithetic=anti)
+        _, oh = po.dev_vanilla(X, opt, SEED, 0, 1 << 16, want_paths=False, antithetic=anti)
+        level = VAN["s"] * 3 + abs(strike)
+        assert np.abs(got - f64(want)).max() <= TOL[X]["pay"] * level
+        assert got.min() >= -strike          # S_T > 0: every path is in the money by more than |K|
+        assert e.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"]) and e.sum2 == pytest.approx(o["sum2"], rel=2 * TOL[X]["rel"])
+        assert hot.sum == pytest.approx(oh["sum"], rel=TOL[X]["rel"]) and hot.sum2 == pytest.approx(oh["sum2"], rel=2 * TOL[X]["rel"])
+        assert hot.expected == pytest.approx(oh["expected"], rel=TOL[X]["rel"])
+        if g3 is not None:
+            assert g3.sum == pytest.approx(o["sum"], rel=TOL[X]["rel"])
+    # with K <= 0 the price is the forward minus the discounted strike: E = S - K exp(-rT), within the CI
+    big = eng.vanilla(opt, 10 ** 7, SEED, 0, X)
+    exact = VAN["s"] - strike * math.exp(-VAN["r"] * VAN["t"])
+    assert abs(big.expected - exact) < 3.5 / 1.96 * big.confidence + 1e-5 * exact
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
 def test_greeks_refuse_out_of_range_models(mc, eng, X):
     """The Greeks entry point applies the pricing paths' exponent guards (a huge v sqrt(t) used to return
     inf / NaN sums with MC_OK)."""
