@@ -74,7 +74,7 @@ struct mc_context {
     hipEvent_t table_copied = nullptr;
     hipStream_t table_stream = nullptr;  // stream the cached table was uploaded on
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    // generator: Philox (counter-based, stateless) or XORWOW (one sequence per lane: mc_rng.hpp RngXorwow)
+    // generator: Philox (counter-based, stateless) or XORWOW (one sequence per lane: mc_rng.hpp GenXorwow)
     int rng = MC_RNG_PHILOX;
     uint64_t xorwow_base = 0;            // lane l of a launch runs subsequence xorwow_base + l
     uint32_t *d_xorwow = nullptr;        // start states of lanes [0, blocks * GROUP): 6 words each
@@ -359,6 +359,8 @@ static Work make_work(uint64_t seed, const Segment &s, uint64_t first_path, uint
     w.first_path = first_path;
     w.end_path = end_path;
     w.xorwow = nullptr;
+    w.ext = nullptr;
+    w.ext_per_unit = 0;
     return w;
 }
 
@@ -689,9 +691,9 @@ template <> struct VanillaTraits<float> {
     {
         if (w.xorwow) {
             if (anti)
-                launch_sim(prof, vanilla_f32_kernel<true, RngXorwow>, grid, st, tail, k, w);
+                launch_sim(prof, vanilla_f32_kernel<true, GenXorwow>, grid, st, tail, k, w);
             else
-                launch_sim(prof, vanilla_f32_kernel<false, RngXorwow>, grid, st, tail, k, w);
+                launch_sim(prof, vanilla_f32_kernel<false, GenXorwow>, grid, st, tail, k, w);
         } else if (anti)
             launch_sim(prof, vanilla_f32_kernel<true>, grid, st, tail, k, w);
         else
@@ -716,6 +718,7 @@ template <> struct VanillaTraits<float> {
         const double two_k = std::ldexp(1.0, (int)k);
         k_.a2k = (float)(a2 - k);
         k_.radius2 = (float)(-2.0 * 0.69314718055994530942 * b2 * b2);
+        k_.b2 = (float)b2;
         k_.kappa_k = (float)((double)o.k / (double)o.s / two_k);
         scale1 = (double)o.s * two_k;
         scale2 = scale1 * scale1;
@@ -730,9 +733,9 @@ template <> struct VanillaTraits<double> {
     {
         if (w.xorwow) {
             if (anti)
-                launch_sim(prof, vanilla_kernel<Opt, double, true, RngXorwow>, grid, st, tail, k, w);
+                launch_sim(prof, vanilla_kernel<Opt, double, true, GenXorwow>, grid, st, tail, k, w);
             else
-                launch_sim(prof, vanilla_kernel<Opt, double, false, RngXorwow>, grid, st, tail, k, w);
+                launch_sim(prof, vanilla_kernel<Opt, double, false, GenXorwow>, grid, st, tail, k, w);
         } else if (anti)
             launch_sim(prof, vanilla_kernel<Opt, double, true>, grid, st, tail, k, w);
         else
@@ -760,7 +763,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
                            uint64_t first, uint64_t n, double *d_triple, hipStream_t st, Real *out)
 {
     using T = VanillaTraits<Real>;
-    constexpr uint64_t NPB = npb<Real>::value;
+    constexpr uint64_t NPB = GenPhilox::npb<Real>();
     typename T::Opt k;
     double scale1, scale2;
     if (int rc = T::prepare(*opt, k, scale1, scale2))
@@ -776,7 +779,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     if (c->rng == MC_RNG_XORWOW) {
         // one masked launch over every unit the range touches (no separate edge launches: a lane's sequence would
         // restart in them); the masked kernel is the generic form, the only one compiled for both generators
-        const auto xw = anti ? vanilla_masked_kernel<typename T::Opt, Real, true, RngXorwow> : vanilla_masked_kernel<typename T::Opt, Real, false, RngXorwow>;
+        const auto xw = anti ? vanilla_masked_kernel<typename T::Opt, Real, true, GenXorwow> : vanilla_masked_kernel<typename T::Opt, Real, false, GenXorwow>;
         std::vector<Segment> one;
         const uint64_t u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
         if (int rc = plan_segments(u0, u1 - u0, one)) return rc;
@@ -950,7 +953,7 @@ static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first,
         if (!ok)
             return fail(MC_ERR_INVALID, "greeks: (r - v^2/2) t and v sqrt(t) put the terminal spot outside the range of the simulation type");
     }
-    constexpr uint64_t NPB = npb<Real>::value;
+    constexpr uint64_t NPB = GenPhilox::npb<Real>();
     Opt k;
     greeks_prepare(*o, k);
     const uint64_t end = first + n, u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
@@ -1124,10 +1127,7 @@ static int basket_static_max()
 }
 static bool basket_mfma()
 {
-#ifndef MC_AB_MFMA_DEFAULT
-#define MC_AB_MFMA_DEFAULT 0
-#endif
-    static const int on = env_int("MC_BASKET_MFMA", MC_AB_MFMA_DEFAULT, 0, 1);
+    static const int on = env_int("MC_BASKET_MFMA", 0, 0, 1);
     return on != 0;
 }
 static int basket_tiled_min()
@@ -1209,7 +1209,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     bool pairs = false;  // two paths per lane
     const bool xorwow = c->rng == MC_RNG_XORWOW;
     if (xorwow) {   // one path per lane, normals in the lane's LDS column, any n
-        kernel = c->antithetic ? basket_dyn_kernel<Real, true, RngXorwow> : basket_dyn_kernel<Real, false, RngXorwow>;
+        kernel = c->antithetic ? basket_dyn_kernel<Real, true, GenXorwow> : basket_dyn_kernel<Real, false, GenXorwow>;
     } else if constexpr (sizeof(Real) == 4) {
         pairs = true;
         if (n >= 13 && n >= basket_tiled_min() && n <= 32) {  // normals in registers, no dynamic LDS
@@ -1433,9 +1433,9 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         if (xorwow) {
             w.xorwow = c->d_xorwow;
             if (c->antithetic)
-                launch_sim(prof, cva_kernel<Real, true, RngXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
+                launch_sim(prof, cva_kernel<Real, true, GenXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
             else
-                launch_sim(prof, cva_kernel<Real, false, RngXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
+                launch_sim(prof, cva_kernel<Real, false, GenXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
         } else if (c->antithetic)
             launch_sim(prof, cva_kernel<Real, true>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
         else
@@ -1498,7 +1498,7 @@ static int basket_greeks_run(mc_context *c, const typename BasketIn<Real>::type 
     k.n = na;
     k.strike = o->k;
     k.sqrt_t = (Real)sqrt_t;
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = GenPhilox::npb<Real>();
     const size_t lds = (size_t)((na + NPB - 1) / NPB * NPB) * GROUP * sizeof(Real);
     HIPCHK(hipFuncSetAttribute((const void *)basket_greeks_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<mc_result *> out(1 + 2 * (size_t)na);
@@ -1711,7 +1711,7 @@ static int dump_sync(mc_context *c, uint64_t n, Real *h_out, Enq enqueue)
                                   uint64_t n_units, uint32_t block, Real *h_out)                             \
     {                                                                                                        \
         if (int rc = check_common(c, h_out, first_unit, n_units, h_out)) return rc;                          \
-        constexpr uint64_t NPB = npb<Real>::value;                                                           \
+        constexpr uint64_t NPB = GenPhilox::npb<Real>();                                                           \
         return dump_sync<Real>(c, n_units * NPB, h_out, [&](hipStream_t st, double *, Real *d) -> int {      \
             std::vector<Segment> segs;                                                                       \
             if (int rc = plan_segments(first_unit, n_units, segs)) return rc;                                \

@@ -13,10 +13,7 @@
 // HBM traffic per launch: kernel arguments (and a table of <= 20 KB) in, 16 B per workgroup out --
 // the kernels are bound by VALU/transcendental issue, not by memory (DESIGN.md "Roofline").
 //
-// `Work` describes one segment: units [unit_lo, unit_lo + n_units) with a common high word
-// (the host splits a range so that unit_lo + n_units <= 2^32 and n_units <= 2^31; only the low
-// word differs between lanes, which moves part of Philox's first rounds to the scalar unit:
-// mc_rng.hpp, philox_unit).
+// Work (one segment of units) and the generator policies (`Gen`: where the normals come from): mc_rng.hpp.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -32,16 +29,9 @@ constexpr int GROUP = 256;  // lanes per workgroup = 4 waves = one wave per SIMD
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
-
-struct Work {
-    uint32_t seed_lo, seed_hi;  // Philox key
-    uint32_t unit_lo, unit_hi;  // first unit of the segment (64-bit counter, split)
-    uint32_t n_units;           // units in the segment
-    // path window for masked launches (vanilla edges, per-path dumps): a path is live iff
-    // first_path <= p < end_path.  Ignored by the unmasked kernels.
-    uint64_t first_path, end_path;
-    const uint32_t *xorwow;     // XORWOW mode only: start states of the launch's lanes, 6 words each (mc_rng.hpp: RngXorwow)
-};
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 bcast(float x) { return (f2){x, x}; }
+__device__ __forceinline__ f2 pk_exp2(f2 x) { return (f2){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}; }
 
 // =========================================================================================
 // Vanilla call.  Reference device formula, dp/MonteCarloKernel.cu:67-71:
@@ -58,85 +48,101 @@ struct Work {
 //       costs no precision.  Sums are scaled back by S 2^k and (S 2^k)^2 in the finishing kernel.
 struct VanillaF32 {
     float a2k, radius2, kappa_k;
+    float b2;   // read by the external-normals form only (the hot form has it folded into radius2)
 };
 struct VanillaF64 {
     double drift, vol, strike, spot;
 };
-
-typedef float f2 __attribute__((ext_vector_type(2)));  // one VGPR pair: v_pk_{fma,mul,add}_f32 operands
 
 __device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 
 // clamp(a + b, 0, 1) for BOTH halves of a packed pair in ONE instruction: v_pk_add_f32 with the output clamp.  hipcc
 // never selects it (a packed min/max pair becomes two v_pk ops plus two scalar v_max ... clamp), hence the asm.  The
 // fp32 vanilla payoffs max(2^x - kappa, 0) of two paths cost one issue slot this way instead of two v_sub_f32 ... clamp
-// (63 -> 61 VALU instructions per Philox block).  Not used in the basket kernels: there the "v" operands push wave-uniform
-// constants out of the scalar registers and cost more v_readlane than the packing saves (145 -> 152 at n = 4).
+// (63 -> 61 VALU instructions per Philox block; -2.7 % time, profiles/r02_ab_packed_clamp.log).  Not used in the basket
+// kernels: there the "v" operands push wave-uniform constants out of the scalar registers and cost more v_readlane than
+// the packing saves (145 -> 152 at n = 4).
 __device__ __forceinline__ f2 pk_add_clamp01(f2 a, f2 b)
 {
-#ifdef MC_AB_SCALAR_CLAMP
-    return (f2){clamp01(a.x + b.x), clamp01(a.y + b.y)};
-#else
     // s_nop 0: gfx950 needs one wait state between a transcendental (the v_exp_f32 that produced `a`) and a VALU
     // instruction reading its result; hipcc inserts it for its own instructions but does not look inside an asm
     // (without it the antithetic kernel read a stale exponential: caught by test_vanilla_many_trips_vs_oracle)
     f2 r;
     asm("s_nop 0\n\tv_pk_add_f32 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
     return r;
-#endif
 }
 
-// The 4 scaled payoffs of one Philox block.  Box-Muller pair A = words (x, y), pair B = words
-// (z, w); values are kept as {A, B} register pairs so the uniform scaling, the radius scaling and
-// the exponent fma issue as packed-f32 instructions (2 results per 4-cycle issue slot):
+// Box-Muller for the packed-fp32 kernels: the two word pairs (xa, ya) and (xb, yb) -- one Philox block's two pairs in
+// the vanilla kernel, the same pair of TWO paths' blocks in the basket kernels -- as the halves of packed registers, so
+// the uniform scaling, the radius scaling and z = r trig issue as v_pk_*_f32 (2 results per 4-cycle issue slot).
+// Returns the radius {a, b} scaled by sqrt(scale2 / (-2 ln 2)) and the trig values; callers form z = r c, r s (or fold
+// them into an fma).  v_log_f32 is log2 and v_sin/v_cos_f32 take revolutions: 2 pi never appears.
+__device__ __forceinline__ void box_muller_pk(uint32_t xa, uint32_t ya, uint32_t xb, uint32_t yb, float scale2, f2 &rad, f2 &c, f2 &s)
+{
+    const f2 ua = pk_fma((f2){(float)xa, (float)xb}, bcast(0x1p-32f), bcast(0x1p-33f));  // radius uniforms
+    const f2 ub = {angle_f32(ya), angle_f32(yb)};                                        // angle uniforms (revolutions, in [1, 2))
+    const f2 t = (f2){__builtin_amdgcn_logf(ua.x), __builtin_amdgcn_logf(ua.y)} * bcast(scale2);
+    rad = (f2){__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+    c = (f2){__builtin_amdgcn_cosf(ub.x), __builtin_amdgcn_cosf(ub.y)};
+    s = (f2){__builtin_amdgcn_sinf(ub.x), __builtin_amdgcn_sinf(ub.y)};
+}
+
+// The 4 scaled payoffs of one unit (one Philox block).  Box-Muller pair A = words (x, y), pair B = words
+// (z, w); values are kept as {A, B} register pairs:
 //   pc = cos-branch payoffs {A, B} = paths 4q+0, 4q+2;  ps = sin-branch {A, B} = paths 4q+1, 4q+3
+// b2 is folded into the radius (o.radius2), so a path's exponent is ONE fma after its trig value.
 //
 // ANTI = antithetic variates (not in the reference): every normal z also prices the
 // mirrored path -z; the sample is the mean of the two payoffs (here their sum: the 1/2 rides on the
-// finishing kernel's scale).  Costs one more fma + exponential + clamp-subtract per path.
-template <bool ANTI, class Rng = RngPhilox>
-__device__ __forceinline__ void vanilla_unit_pk(Rng &rng, const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)
+// finishing step's scale).  Costs one more fma + exponential + clamp-subtract per path.
+//
+// GenExternal (tests): the four normals come from memory and the exponent is fma(z, b2, a2k); everything after the
+// exponent -- exponential, clamp-subtract, sums, flushes, final reduction -- is the code of the hot path.
+template <bool ANTI, class Gen>
+__device__ __forceinline__ void vanilla_unit_pk(Gen &gen, const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)
 {
-    const u32x4 r = rng.draw(w, c0, 0u, 1u /*MC_DOMAIN_VANILLA*/);
-    const f2 scale = {0x1p-32f, 0x1p-32f}, half = {0x1p-33f, 0x1p-33f};
-    const f2 ua = __builtin_elementwise_fma((f2){(float)r.x, (float)r.z}, scale, half);  // radius uniforms
-    const f2 ub = {angle_f32(r.y), angle_f32(r.w)};  // angle uniforms (revolutions, in [1, 2))
-    const f2 t = (f2){__builtin_amdgcn_logf(ua.x), __builtin_amdgcn_logf(ua.y)} * (f2){o.radius2, o.radius2};
-    const f2 rad = {__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
-    const f2 c = {__builtin_amdgcn_cosf(ub.x), __builtin_amdgcn_cosf(ub.y)};
-    const f2 s = {__builtin_amdgcn_sinf(ub.x), __builtin_amdgcn_sinf(ub.y)};
-    const f2 a = {o.a2k, o.a2k};
-    const f2 yc = __builtin_elementwise_fma(c, rad, a);
-    const f2 ys = __builtin_elementwise_fma(s, rad, a);
-    const f2 neg_kappa = {-o.kappa_k, -o.kappa_k};
-    pc = pk_add_clamp01((f2){__builtin_amdgcn_exp2f(yc.x), __builtin_amdgcn_exp2f(yc.y)}, neg_kappa);
-    ps = pk_add_clamp01((f2){__builtin_amdgcn_exp2f(ys.x), __builtin_amdgcn_exp2f(ys.y)}, neg_kappa);
+    const f2 a = bcast(o.a2k);
+    f2 yc, ys, mc_, ms_;   // exponents (log2 units) of the cos / sin branch paths and of their mirrors
+    if constexpr (Gen::external) {
+        float z[4];
+        gen.normals(w, c0, 0u, 1u /*MC_DOMAIN_VANILLA*/, z);
+        const f2 zc = {z[0], z[2]}, zs = {z[1], z[3]}, b = bcast(o.b2);
+        yc = pk_fma(zc, b, a), ys = pk_fma(zs, b, a);
+        mc_ = pk_fma(-zc, b, a), ms_ = pk_fma(-zs, b, a);
+    } else {
+        const u32x4 r = gen.words(w, c0, 0u, 1u /*MC_DOMAIN_VANILLA*/);
+        f2 rad, c, s;
+        box_muller_pk(r.x, r.y, r.z, r.w, o.radius2, rad, c, s);
+        yc = pk_fma(c, rad, a), ys = pk_fma(s, rad, a);
+        mc_ = pk_fma(-c, rad, a), ms_ = pk_fma(-s, rad, a);
+    }
+    const f2 neg_kappa = bcast(-o.kappa_k);
+    pc = pk_add_clamp01(pk_exp2(yc), neg_kappa);
+    ps = pk_add_clamp01(pk_exp2(ys), neg_kappa);
     if (ANTI) {
-        const f2 mc_ = __builtin_elementwise_fma(-c, rad, a);
-        const f2 ms_ = __builtin_elementwise_fma(-s, rad, a);
-        pc += pk_add_clamp01((f2){__builtin_amdgcn_exp2f(mc_.x), __builtin_amdgcn_exp2f(mc_.y)}, neg_kappa);
-        ps += pk_add_clamp01((f2){__builtin_amdgcn_exp2f(ms_.x), __builtin_amdgcn_exp2f(ms_.y)}, neg_kappa);
+        pc += pk_add_clamp01(pk_exp2(mc_), neg_kappa);
+        ps += pk_add_clamp01(pk_exp2(ms_), neg_kappa);
     }
 }
 
 // path order inside the unit: 4q+0 = cos A, 4q+1 = sin A, 4q+2 = cos B, 4q+3 = sin B
-template <bool ANTI, class Rng>
-__device__ __forceinline__ void vanilla_unit(Rng &rng, const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
+template <bool ANTI, class Gen>
+__device__ __forceinline__ void vanilla_unit(Gen &gen, const VanillaF32 &o, const Work &w, uint32_t c0, float (&p)[4])
 {
     f2 pc, ps;
-    vanilla_unit_pk<ANTI>(rng, o, w, c0, pc, ps);
+    vanilla_unit_pk<ANTI>(gen, o, w, c0, pc, ps);
     p[0] = pc.x;
     p[1] = ps.x;
     p[2] = pc.y;
     p[3] = ps.y;
 }
-template <bool ANTI, class Rng>
-__device__ __forceinline__ void vanilla_unit(Rng &rng, const VanillaF64 &o, const Work &w, uint32_t c0, double (&p)[2])
+template <bool ANTI, class Gen, int NPB>
+__device__ __forceinline__ void vanilla_unit(Gen &gen, const VanillaF64 &o, const Work &w, uint32_t c0, double (&p)[NPB])
 {
-    double z[2];
-    block_normals(rng, w, c0, 0u, 1u /*MC_DOMAIN_VANILLA*/, z);
+    double z[NPB];
+    gen.normals(w, c0, 0u, 1u /*MC_DOMAIN_VANILLA*/, z);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NPB; ++j) {
         p[j] = fmax(o.spot * exp_f64(o.drift + o.vol * z[j]) - o.strike, 0.0);
         if (ANTI)
             p[j] = 0.5 * (p[j] + fmax(o.spot * exp_f64(o.drift - o.vol * z[j]) - o.strike, 0.0));
@@ -151,7 +157,7 @@ __device__ __forceinline__ void vanilla_unit(Rng &rng, const VanillaF64 &o, cons
 // trip at the end is peeled.
 constexpr uint32_t VANILLA_F32_FLUSH = 8;
 
-template <bool ANTI, class Rng = RngPhilox>
+template <bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const VanillaF32 o, const Work w)
 {
     const uint32_t stride = gridDim.x * GROUP;
@@ -160,14 +166,14 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first 
     double acc_s = 0.0, acc_q = 0.0;
     f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};
     uint32_t c0 = w.unit_lo + gtid;
-    Rng rng(w);   // Philox: stateless; XORWOW: the lane's sequence (units ascending, as the masked kernel draws them)
+    Gen gen(w);   // Philox: stateless; XORWOW: the lane's sequence (units ascending, as the masked kernel draws them)
     for (uint32_t trip = 0; trip < full_trips; ++trip, c0 += stride) {
         f2 pc, ps;
-        vanilla_unit_pk<ANTI>(rng, o, w, c0, pc, ps);
+        vanilla_unit_pk<ANTI>(gen, o, w, c0, pc, ps);
         s2 += pc;
         s2 += ps;
-        q2 = __builtin_elementwise_fma(pc, pc, q2);
-        q2 = __builtin_elementwise_fma(ps, ps, q2);
+        q2 = pk_fma(pc, pc, q2);
+        q2 = pk_fma(ps, ps, q2);
         if ((trip & (VANILLA_F32_FLUSH - 1)) == VANILLA_F32_FLUSH - 1) {
             acc_s += (double)(s2.x + s2.y);
             acc_q += (double)(q2.x + q2.y);
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first 
     }
     if (full_trips * stride + gtid < w.n_units) {  // the partial last trip
         f2 pc, ps;
-        vanilla_unit_pk<ANTI>(rng, o, w, c0, pc, ps);
+        vanilla_unit_pk<ANTI>(gen, o, w, c0, pc, ps);
         s2 += pc + ps;
         q2 += pc * pc + ps * ps;
     }
@@ -188,18 +194,18 @@ __global__ __launch_bounds__(GROUP) void vanilla_f32_kernel(const Tail /* first 
 }
 
 // f64 (and the generic form): each unit's payoffs go straight into the fp64 accumulators.
-template <class Opt, class Real, bool ANTI, class Rng = RngPhilox>
+template <class Opt, class Real, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w)
 {
     stage_tables<Real>();
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = Gen::template npb<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
-    Rng rng(w);
+    Gen gen(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p[NPB];
-        vanilla_unit<ANTI>(rng, o, w, w.unit_lo + i, p);
+        vanilla_unit<ANTI>(gen, o, w, w.unit_lo + i, p);
         Real s = p[0], q = p[0] * p[0];
 #pragma unroll
         for (int j = 1; j < NPB; ++j) {
@@ -216,19 +222,19 @@ __global__ __launch_bounds__(GROUP) void vanilla_kernel(const Tail /* first argu
 // Masked kernel: honours the path window (partial first/last units) and optionally stores
 // every per-path payoff (currency units) to `out[p - first_path]`.  Used for range edges and
 // by the parity tests; never on the hot path.
-template <class Opt, class Real, bool ANTI, class Rng = RngPhilox>
+template <class Opt, class Real, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void vanilla_masked_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w,
                                                                Real *__restrict__ out, Real out_scale)
 {
     stage_tables<Real>();
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = Gen::template npb<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
-    Rng rng(w);
+    Gen gen(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p[NPB];
-        vanilla_unit<ANTI>(rng, o, w, w.unit_lo + i, p);
+        vanilla_unit<ANTI>(gen, o, w, w.unit_lo + i, p);
         const uint64_t unit = ((uint64_t)w.unit_hi << 32) | (uint32_t)(w.unit_lo + i);
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
@@ -265,12 +271,13 @@ template <class Opt, class Real, bool LR>
 __global__ __launch_bounds__(GROUP) void vanilla_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const Opt o, const Work w)
 {
     stage_tables<Real>();
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = GenPhilox::npb<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     double acc[6] = {0, 0, 0, 0, 0, 0};
+    GenPhilox gen(w);
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
         Real z[NPB];
-        block_normals(w.unit_lo + i, w.unit_hi, 0u, 1u /*MC_DOMAIN_VANILLA*/, w.seed_lo, w.seed_hi, z);
+        gen.normals(w, w.unit_lo + i, 0u, 1u /*MC_DOMAIN_VANILLA*/, z);
         const uint64_t unit = ((uint64_t)w.unit_hi << 32) | (uint32_t)(w.unit_lo + i);
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
@@ -331,30 +338,19 @@ struct BasketArgs {
 // VGPR lanes and pays a v_readlane_b32 -- a full VALU issue slot -- per use: 272 of 870 instructions per
 // trip at n=16 f32), so they are staged once per workgroup into LDS and read back as broadcast
 // ds_reads, which do not occupy the VALU.
-#ifdef MC_AB_BASKET_SGPR   // A/B switch (tools/ab_f64.py): never stage in LDS
-template <class Real, int NA> constexpr bool basket_consts_in_lds() { return false; }
-#else
-#ifndef MC_AB_F64_LDS_MAX
-#define MC_AB_F64_LDS_MAX 9
-#endif
-template <class Real, int NA> constexpr bool basket_consts_in_lds()
-{
-    return sizeof(Real) == 4 ? NA > 5 : (NA > 3 && NA <= MC_AB_F64_LDS_MAX);
-}
-#endif
-// Whether the LDS reads are additionally pinned every few rows (ConstsLds::fence).  In-process A/B on
-// MI355X (tools/ab_basket.py, profiles/r01_ab_basket_lds.log), kernel time LDS vs SGPR constants:
+// Which sizes stage (in-process A/B on MI355X, tools/ab_basket.py, profiles/r01_ab_basket_lds.log; kernel time LDS vs
+// SGPR constants):
 //   f32  n=6 -1 %, n=8 -11 %, n=10 -15 % (no fence);  n=12 -15 %, n=16 -20 % (fence every 4 rows; -6 % / -5 % without)
 //   f64  n=4 -7 %, n=7 -10 %, n=8 -12 %, n=9 -11 %, n=10 +1 %, n=12 +2 %, n=16 +6 % (no fence; a fence costs f64
 //        3-9 %).  From n=10 hipcc keeps the staged constants in > 256 registers: one wave per SIMD, every LDS
 //        latency exposed; asking for more waves (amdgpu_waves_per_eu) turns that into scratch spills, so those
-//        sizes stay on the SGPR path.
-// Returns the fence period in rows (0 = never).
-#ifdef MC_AB_FENCE_PERIOD
-template <class Real, int NA> constexpr int basket_fence_rows() { return MC_AB_FENCE_PERIOD; }
-#else
+//        sizes stay on the SGPR path (and run the tiled kernels by default: mc_api.hip).
+template <class Real, int NA> constexpr bool basket_consts_in_lds()
+{
+    return sizeof(Real) == 4 ? NA > 5 : (NA > 3 && NA <= 9);
+}
+// Whether the LDS reads are additionally pinned every few rows (ConstsLds::fence): the fence period in rows (0 = never).
 template <class Real, int NA> constexpr int basket_fence_rows() { return sizeof(Real) == 4 && NA >= 11 ? 4 : 0; }
-#endif
 
 template <class Real, int NA>
 struct ConstsArg {  // kernel arguments (SGPRs)
@@ -406,20 +402,129 @@ struct ConstsLds {  // staged copy: m | base | coef | wg
 __device__ __forceinline__ float exp_model(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ double exp_model(double x) { return exp_f64(x); }
 
-template <class Real, int NA, bool ANTI, class Consts>
-__device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, Consts k, const Work &w, uint32_t c0)
+// The end of a basket path, shared by every one-path-per-lane basket kernel: from the weighted sum of the terminal
+// prices (and of the mirrored path's, ANTI) to the sample.  Reference: dp/MonteCarloKernel.cu:96-100.
+//   cv (wave-uniform): geometric-basket control variate -- the sample is payoff(arithmetic) - payoff(geometric),
+//   lg / lgm = ln G of the path and of its mirror in the kernel's exponent units.
+template <bool ANTI, class Real>
+__device__ __forceinline__ Real basket_sample(Real basket, Real mirror, Real lg, Real lgm, Real strike, int cv)
 {
-    constexpr int NPB = npb<Real>::value;
-    constexpr int NBLK = (NA + NPB - 1) / NPB;
-    Real g[NBLK * NPB];
+    const Real v = basket - strike;
+    Real pay = v > 0 ? v : 0;
+    if (cv) {
+        const Real gv = exp_model(lg) - strike;
+        pay -= gv > 0 ? gv : 0;
+    }
+    if (ANTI) {
+        const Real vm = mirror - strike;
+        Real pm = vm > 0 ? vm : 0;
+        if (cv) {
+            const Real gm = exp_model(lgm) - strike;
+            pm -= gm > 0 ? gm : 0;
+        }
+        pay = (Real)0.5 * (pay + pm);
+    }
+    return pay;
+}
+// the same for two paths in packed halves (the fp32 tiled / generic kernels: plain max, no power-of-two rescale)
+template <bool ANTI>
+__device__ __forceinline__ f2 basket_sample_pk(f2 basket, f2 mirror, f2 lg, f2 lgm, float strike_, int cv)
+{
+    const f2 zero = {0.0f, 0.0f}, strike = bcast(strike_);
+    f2 p = __builtin_elementwise_max(basket - strike, zero);
+    if (cv)
+        p -= __builtin_elementwise_max(pk_exp2(lg) - strike, zero);
+    if (ANTI) {
+        f2 pm = __builtin_elementwise_max(mirror - strike, zero);
+        if (cv)
+            pm -= __builtin_elementwise_max(pk_exp2(lgm) - strike, zero);
+        p = bcast(0.5f) * (p + pm);
+    }
+    return p;
+}
+
+// One row of the folded model: the asset's exponent x is done; add its terminal price (and the mirrored path's, whose
+// exponent is base - m g = 2 base - x) to the weighted sums, and its log to the control variate's.
+// wg() yields the row's control-variate weight; it is only evaluated where it is used (for the LDS-staged constants it
+// is a read), cv is wave-uniform.
+template <bool ANTI, class Real, class Wg>
+__device__ __forceinline__ void basket_row(Real x, Real base, Real coef, Wg wg, int cv, Real &basket, Real &mirror, Real &lg, Real &lgm)
+{
+    basket = fma_r(coef, exp_model(x), basket);
+    if (cv)
+        lg = fma_r(wg(), x, lg);
+    if (ANTI) {
+        const Real xm = fma_r((Real)-1, x, 2 * base);
+        mirror = fma_r(coef, exp_model(xm), mirror);
+        if (cv)
+            lgm = fma_r(wg(), xm, lgm);
+    }
+}
+template <bool ANTI, class Wg>
+__device__ __forceinline__ void basket_row_pk(f2 x, float base, float coef, Wg wg, int cv, f2 &basket, f2 &mirror, f2 &lg, f2 &lgm)
+{
+    basket = pk_fma(bcast(coef), pk_exp2(x), basket);
+    if (cv)
+        lg = pk_fma(bcast(wg()), x, lg);
+    if (ANTI) {
+        const f2 xm = pk_fma(bcast(-1.0f), x, bcast(2.0f * base));
+        mirror = pk_fma(bcast(coef), pk_exp2(xm), mirror);
+        if (cv)
+            lgm = pk_fma(bcast(wg()), xm, lgm);
+    }
+}
+
+// All normals of one path: blocks 0 .. NBLK-1 of unit c0 in the basket domain
+template <class Gen, class Real, int NG>
+__device__ __forceinline__ void basket_normals(Gen &gen, const Work &w, uint32_t c0, Real (&g)[NG])
+{
+    constexpr int NPB = Gen::template npb<Real>();
+    static_assert(NG % NPB == 0, "whole blocks");
 #pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
+    for (int b = 0; b < NG / NPB; ++b) {
         Real z[NPB];
-        block_normals(c0, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
+        gen.normals(w, c0, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, z);
 #pragma unroll
         for (int j = 0; j < NPB; ++j)
             g[b * NPB + j] = z[j];
     }
+}
+// ... of TWO paths (units cA, cB) as packed halves {A, B}: the fp32 two-paths-per-lane kernels.  Blocks first_block ..
+// first_block + NBLK - 1; dst(k) = where normal k of them goes (a register array or the lane's LDS column).
+template <int NBLK, class Gen, class Dst>
+__device__ __forceinline__ void basket_normals_pk(Gen &gen, const Work &w, uint32_t cA, uint32_t cB, Dst dst, uint32_t first_block = 0)
+{
+#pragma unroll
+    for (int b = 0; b < NBLK; ++b) {
+        if constexpr (Gen::external) {
+            float za[4], zb[4];
+            gen.normals(w, cA, first_block + (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, za);
+            gen.normals(w, cB, first_block + (uint32_t)b, 2u, zb);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst(4 * b + j) = (f2){za[j], zb[j]};
+        } else {
+            const u32x4 ra = gen.words(w, cA, first_block + (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/);
+            const u32x4 rb = gen.words(w, cB, first_block + (uint32_t)b, 2u);
+            // Box-Muller pair X = words (x, y), pair Z = words (z, w); halves = {path A, path B}
+            f2 rx, cx, sx, rz, cz, sz;
+            box_muller_pk(ra.x, ra.y, rb.x, rb.y, NEG_2LN2_F32, rx, cx, sx);
+            box_muller_pk(ra.z, ra.w, rb.z, rb.w, NEG_2LN2_F32, rz, cz, sz);
+            dst(4 * b + 0) = rx * cx;
+            dst(4 * b + 1) = rx * sx;
+            dst(4 * b + 2) = rz * cz;
+            dst(4 * b + 3) = rz * sz;
+        }
+    }
+}
+
+template <class Real, int NA, bool ANTI, class Gen, class Consts>
+__device__ __forceinline__ Real basket_path(Gen &gen, const BasketArgs<Real, NA> &o, Consts k, const Work &w, uint32_t c0)
+{
+    constexpr int NPB = Gen::template npb<Real>();
+    constexpr int NBLK = (NA + NPB - 1) / NPB;
+    Real g[NBLK * NPB];
+    basket_normals(gen, w, c0, g);
     Real basket = 0, mirror = 0, lg = o.cg, lgm = o.cg;
     k.fence(0, g[0]);
 #pragma unroll
@@ -429,36 +534,13 @@ __device__ __forceinline__ Real basket_path(const BasketArgs<Real, NA> &o, Const
 #pragma unroll
         for (int b = 0; b <= a; ++b)
             x = fma_r(k.m(a * (a + 1) / 2 + b), g[b], x);
-        basket = fma_r(coef, exp_model(x), basket);
-        if (o.cv)
-            lg = fma_r(k.wg(a), x, lg);
+        basket_row<ANTI>(x, base, coef, [&] { return k.wg(a); }, o.cv, basket, mirror, lg, lgm);
         k.fence(a + 1, x);
-        if (ANTI) {  // exponent of the mirrored path: base - m g = 2 base - x
-            const Real xm = fma_r((Real)-1, x, 2 * base);
-            mirror = fma_r(coef, exp_model(xm), mirror);
-            if (o.cv)
-                lgm = fma_r(k.wg(a), xm, lgm);
-        }
     }
-    const Real v = basket - o.strike;
-    Real pay = v > 0 ? v : 0;
-    if (o.cv) {  // wave-uniform
-        const Real gv = exp_model(lg) - o.strike;
-        pay -= gv > 0 ? gv : 0;
-    }
-    if (ANTI) {
-        const Real vm = mirror - o.strike;
-        Real pm = vm > 0 ? vm : 0;
-        if (o.cv) {
-            const Real gm = exp_model(lgm) - o.strike;
-            pm -= gm > 0 ? gm : 0;
-        }
-        pay = (Real)0.5 * (pay + pm);
-    }
-    return pay;
+    return basket_sample<ANTI>(basket, mirror, lg, lgm, o.strike, o.cv);
 }
 
-template <class Real, int NA, bool ANTI>
+template <class Real, int NA, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void basket_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketArgs<Real, NA> o, const Work w,
                                                        Real *__restrict__ out)
 {
@@ -470,12 +552,13 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const Tail /* first argum
     __shared__ Real lds_consts[IN_LDS ? ConstsLds<Real, NA>::COUNT : 1];
     if (IN_LDS)
         ConstsLds<Real, NA>::stage(lds_consts, o);
+    Gen gen(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         Real p;
         if constexpr (IN_LDS)
-            p = basket_path<Real, NA, ANTI>(o, ConstsLds<Real, NA>{lds_consts}, w, w.unit_lo + i);
+            p = basket_path<Real, NA, ANTI>(gen, o, ConstsLds<Real, NA>{lds_consts}, w, w.unit_lo + i);
         else
-            p = basket_path<Real, NA, ANTI>(o, ConstsArg<Real, NA>{o}, w, w.unit_lo + i);
+            p = basket_path<Real, NA, ANTI>(gen, o, ConstsArg<Real, NA>{o}, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests
@@ -491,33 +574,12 @@ __global__ __launch_bounds__(GROUP) void basket_kernel(const Tail /* first argum
 // 4-cycle slot.  The payoff's max(.,0) is the free [0,1] clamp of the subtract after an exact
 // power-of-two rescale (coef and strike carry 2^-k, k from the generator's |z| < 6.77 bound);
 // the finishing kernel scales the sums back.  Lane pairing: units i and i + stride of one trip.
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 bcast(float x) { return (f2){x, x}; }
-
-template <int NA, bool ANTI, class Consts>
-__device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, Consts k, const Work &w, uint32_t cA, uint32_t cB)
+template <int NA, bool ANTI, class Gen, class Consts>
+__device__ __forceinline__ f2 basket_pair_f32(Gen &gen, const BasketArgs<float, NA> &o, Consts k, const Work &w, uint32_t cA, uint32_t cB)
 {
     constexpr int NBLK = (NA + 3) / 4;
     f2 g[NBLK * 4];
-    const f2 scale = bcast(0x1p-32f), half = bcast(0x1p-33f), neg2ln2 = bcast(NEG_2LN2_F32);
-#pragma unroll
-    for (int b = 0; b < NBLK; ++b) {
-        const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
-        const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
-        // Box-Muller pair X = words (x, y), pair Z = words (z, w); halves = {path A, path B}
-        const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
-        const f2 ax = {angle_f32(ra.y), angle_f32(rb.y)};
-        const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
-        const f2 az = {angle_f32(ra.w), angle_f32(rb.w)};
-        const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
-        const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
-        const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
-        const f2 rz = {__builtin_amdgcn_sqrtf(tz.x), __builtin_amdgcn_sqrtf(tz.y)};
-        g[4 * b + 0] = rx * (f2){__builtin_amdgcn_cosf(ax.x), __builtin_amdgcn_cosf(ax.y)};
-        g[4 * b + 1] = rx * (f2){__builtin_amdgcn_sinf(ax.x), __builtin_amdgcn_sinf(ax.y)};
-        g[4 * b + 2] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
-        g[4 * b + 3] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
-    }
+    basket_normals_pk<NBLK>(gen, w, cA, cB, [&](int i) -> f2 & { return g[i]; });
     f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f}, lg = bcast(o.cg), lgm = bcast(o.cg);
     k.fence(0, g[0].x);
 #pragma unroll
@@ -527,22 +589,15 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, Co
 #pragma unroll
         for (int b = 0; b <= a; ++b)
             x = pk_fma(bcast(k.m(a * (a + 1) / 2 + b)), g[b], x);
-        basket = pk_fma(bcast(coef), (f2){__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)}, basket);
-        if (o.cv)
-            lg = pk_fma(bcast(k.wg(a)), x, lg);
+        basket_row_pk<ANTI>(x, base, coef, [&] { return k.wg(a); }, o.cv, basket, mirror, lg, lgm);
         k.fence(a + 1, x.x);
-        if (ANTI) {  // mirrored path: base - m g = 2 base - x
-            const f2 xm = pk_fma(bcast(-1.0f), x, bcast(2.0f * base));
-            mirror = pk_fma(bcast(coef), (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
-            if (o.cv)
-                lgm = pk_fma(bcast(k.wg(a)), xm, lgm);
-        }
     }
-    // the geometric mean never exceeds the arithmetic one, so the same 2^-k scale keeps it in [0,1]
+    // payoff = the free [0,1] clamp of the subtract after the power-of-two rescale; the geometric mean never exceeds
+    // the arithmetic one, so the same 2^-k scale keeps it in [0,1]
     f2 pay = {clamp01(basket.x - o.strike), clamp01(basket.y - o.strike)};
     if (o.cv)  // wave-uniform
         pay -= (f2){clamp01(__builtin_amdgcn_exp2f(lg.x) - o.strike), clamp01(__builtin_amdgcn_exp2f(lg.y) - o.strike)};
-    if (ANTI) {  // sum of the two values; the 1/2 rides on the finishing kernel's scale
+    if (ANTI) {  // sum of the two values; the 1/2 rides on the finishing step's scale
         pay += (f2){clamp01(mirror.x - o.strike), clamp01(mirror.y - o.strike)};
         if (o.cv)
             pay -= (f2){clamp01(__builtin_amdgcn_exp2f(lgm.x) - o.strike), clamp01(__builtin_amdgcn_exp2f(lgm.y) - o.strike)};
@@ -552,7 +607,7 @@ __device__ __forceinline__ f2 basket_pair_f32(const BasketArgs<float, NA> &o, Co
 
 constexpr uint32_t BASKET_F32_FLUSH = 8;
 
-template <int NA, bool ANTI>
+template <int NA, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketArgs<float, NA> o, const Work w, float *__restrict__ out,
                                                            float out_scale)
 {
@@ -565,11 +620,12 @@ __global__ __launch_bounds__(GROUP) void basket_f32_kernel(const Tail /* first a
     __shared__ float lds_consts[IN_LDS ? ConstsLds<float, NA>::COUNT : 1];
     if (IN_LDS)
         ConstsLds<float, NA>::stage(lds_consts, o);
+    Gen gen(w);
     const auto pair = [&](uint32_t cA, uint32_t cB) __attribute__((always_inline)) {
         if constexpr (IN_LDS)
-            return basket_pair_f32<NA, ANTI>(o, ConstsLds<float, NA>{lds_consts}, w, cA, cB);
+            return basket_pair_f32<NA, ANTI>(gen, o, ConstsLds<float, NA>{lds_consts}, w, cA, cB);
         else
-            return basket_pair_f32<NA, ANTI>(o, ConstsArg<float, NA>{o}, w, cA, cB);
+            return basket_pair_f32<NA, ANTI>(gen, o, ConstsArg<float, NA>{o}, w, cA, cB);
     };
     uint32_t i = gtid;
     for (uint32_t trip = 0; trip < full_trips; ++trip, i += 2 * stride) {
@@ -624,13 +680,13 @@ struct BasketDyn {
     int cv;
 };
 
-template <class Real, bool ANTI, class Rng = RngPhilox>
+template <class Real, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = Gen::template npb<Real>();
     const int nb = (o.n + 3) >> 2, np = nb * 4, nblk = np / NPB;
     // constant address space: wave-uniform reads become scalar loads (s_load_dwordx16 per tile) whatever the
     // compiler can or cannot prove about the kernel's global stores
@@ -638,11 +694,11 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const Tail /* first a
     const cptr tiles = (cptr)o.consts, base = tiles + 8 * nb * (nb + 1), coef = base + np, wg = coef + np;
     const uint32_t stride = gridDim.x * GROUP;
     double acc_s = 0.0, acc_q = 0.0;
-    Rng rng(w);
+    Gen gen(w);
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
         for (int b = 0; b < nblk; ++b) {
             Real z[NPB];
-            block_normals(rng, w, w.unit_lo + i, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, z);
+            gen.normals(w, w.unit_lo + i, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, z);
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
                 g[(b * NPB + j) * GROUP] = z[j];
@@ -664,32 +720,10 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const Tail /* first a
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const Real cf = coef[4 * A + r], wr = wg[4 * A + r];
-                basket = fma_r(cf, exp_model(x[r]), basket);
-                lg = fma_r(wr, x[r], lg);
-                if (ANTI) {
-                    const Real xm = fma_r((Real)-1, x[r], 2 * base[4 * A + r]);
-                    mirror = fma_r(cf, exp_model(xm), mirror);
-                    lgm = fma_r(wr, xm, lgm);
-                }
-            }
+            for (int r = 0; r < 4; ++r)   // wg is zero without the control variate: its sums are formed unconditionally
+                basket_row<ANTI>(x[r], (Real)base[4 * A + r], (Real)coef[4 * A + r], [&] { return (Real)wg[4 * A + r]; }, 1, basket, mirror, lg, lgm);
         }
-        const Real v = basket - o.strike;
-        Real p = v > 0 ? v : 0;
-        if (o.cv) {
-            const Real gv = exp_model(lg) - o.strike;
-            p -= gv > 0 ? gv : 0;
-        }
-        if (ANTI) {
-            const Real vm = mirror - o.strike;
-            Real pm = vm > 0 ? vm : 0;
-            if (o.cv) {
-                const Real gm = exp_model(lgm) - o.strike;
-                pm -= gm > 0 ? gm : 0;
-            }
-            p = (Real)0.5 * (p + pm);
-        }
+        const Real p = basket_sample<ANTI>(basket, mirror, lg, lgm, o.strike, o.cv);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)
@@ -712,27 +746,13 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const Tail /* fir
     typedef const __attribute__((address_space(4))) float *cptr;
     const cptr tiles = (cptr)o.consts, base = tiles + 8 * nb * (nb + 1), coef = base + np, wg = coef + np;
     const uint32_t stride = gridDim.x * GROUP;
-    const f2 scale = bcast(0x1p-32f), half = bcast(0x1p-33f), neg2ln2 = bcast(NEG_2LN2_F32);
     double acc_s = 0.0, acc_q = 0.0;
+    GenPhilox gen(w);
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += 2 * stride) {
         const bool has_b = i + stride < w.n_units;  // false only in a range's last trip
         const uint32_t cA = w.unit_lo + i, cB = w.unit_lo + (has_b ? i + stride : i);
-        for (int b = 0; b < nb; ++b) {
-            const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
-            const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
-            const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
-            const f2 ax = {angle_f32(ra.y), angle_f32(rb.y)};
-            const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
-            const f2 az = {angle_f32(ra.w), angle_f32(rb.w)};
-            const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
-            const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
-            const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
-            const f2 rz = {__builtin_amdgcn_sqrtf(tz.x), __builtin_amdgcn_sqrtf(tz.y)};
-            g[(4 * b + 0) * GROUP] = rx * (f2){__builtin_amdgcn_cosf(ax.x), __builtin_amdgcn_cosf(ax.y)};
-            g[(4 * b + 1) * GROUP] = rx * (f2){__builtin_amdgcn_sinf(ax.x), __builtin_amdgcn_sinf(ax.y)};
-            g[(4 * b + 2) * GROUP] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
-            g[(4 * b + 3) * GROUP] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
-        }
+        for (int b = 0; b < nb; ++b)
+            basket_normals_pk<1>(gen, w, cA, cB, [&](int k) -> f2 & { return g[(4 * b + k) * GROUP]; }, (uint32_t)b);
         f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f}, lg = bcast(o.cg), lgm = bcast(o.cg);
         cptr tile = tiles;
         for (int A = 0; A < nb; ++A) {
@@ -750,27 +770,10 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const Tail /* fir
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const f2 cf = bcast(coef[4 * A + r]), wr = bcast(wg[4 * A + r]);
-                basket = pk_fma(cf, (f2){__builtin_amdgcn_exp2f(x[r].x), __builtin_amdgcn_exp2f(x[r].y)}, basket);
-                lg = pk_fma(wr, x[r], lg);
-                if (ANTI) {
-                    const f2 xm = pk_fma(bcast(-1.0f), x[r], bcast(2.0f * base[4 * A + r]));
-                    mirror = pk_fma(cf, (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
-                    lgm = pk_fma(wr, xm, lgm);
-                }
-            }
+            for (int r = 0; r < 4; ++r)
+                basket_row_pk<ANTI>(x[r], base[4 * A + r], coef[4 * A + r], [&] { return wg[4 * A + r]; }, 1, basket, mirror, lg, lgm);
         }
-        const f2 zero = {0.0f, 0.0f}, strike = bcast(o.strike);
-        f2 p = __builtin_elementwise_max(basket - strike, zero);
-        if (o.cv)
-            p -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lg.x), __builtin_amdgcn_exp2f(lg.y)} - strike, zero);
-        if (ANTI) {
-            f2 pm = __builtin_elementwise_max(mirror - strike, zero);
-            if (o.cv)
-                pm -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lgm.x), __builtin_amdgcn_exp2f(lgm.y)} - strike, zero);
-            p = bcast(0.5f) * (p + pm);
-        }
+        f2 p = basket_sample_pk<ANTI>(basket, mirror, lg, lgm, o.strike, o.cv);
         if (!has_b)
             p.y = 0.0f;
         acc_s += (double)p.x + (double)p.y;
@@ -798,36 +801,26 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_f32_kernel(const Tail /* fir
 // A wave-uniform value (in an SGPR pair) into a vector register pair with ONE v_mov_b64 (hipcc emits two v_mov_b32).
 __device__ __forceinline__ double scalar_to_vgpr(double x)
 {
-#ifndef MC_AB_NO_MOV64
     double r;
     asm("v_mov_b64 %0, %1" : "=v"(r) : "s"(x));
     return r;
-#else
-    return x;
-#endif
 }
 __device__ __forceinline__ float scalar_to_vgpr(float x) { return x; }
 
-template <class Real, int NA, bool ANTI>
+template <class Real, int NA, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
-    constexpr int NB = (NA + 3) / 4, NP = 4 * NB, NPB = npb<Real>::value, NBLK = (NA + NPB - 1) / NPB;
+    constexpr int NB = (NA + 3) / 4, NP = 4 * NB, NPB = Gen::template npb<Real>(), NBLK = (NA + NPB - 1) / NPB;
     constexpr int NH = NB * (NB + 1);  // half tiles in the buffer
     typedef const __attribute__((address_space(4))) Real *cptr;
     const cptr tiles = (cptr)o.consts, base = tiles + 8 * NH, coef = base + NP, wg = coef + NP;
     const uint32_t stride = gridDim.x * GROUP;
     double acc_s = 0.0, acc_q = 0.0;
+    Gen gen(w);
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
         Real g[NBLK * NPB];
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) {
-            Real z[NPB];
-            block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
-#pragma unroll
-            for (int j = 0; j < NPB; ++j)
-                g[b * NPB + j] = z[j];
-        }
+        basket_normals(gen, w, w.unit_lo + i, g);
         Real basket = 0, mirror = 0, lg = o.cg, lgm = o.cg;
         Real tl[2][8];
         int off = 0;
@@ -872,31 +865,10 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const Tail /* first
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (r < rows) {
-                    basket = fma_r(cf[r], exp_model(x[r]), basket);
-                    lg = fma_r(wr[r], x[r], lg);
-                    if (ANTI) {
-                        const Real xm = fma_r((Real)-1, x[r], 2 * base[off + 4 * A + r]);
-                        mirror = fma_r(cf[r], exp_model(xm), mirror);
-                        lgm = fma_r(wr[r], xm, lgm);
-                    }
-                }
+                if (r < rows)
+                    basket_row<ANTI>(x[r], (Real)base[off + 4 * A + r], cf[r], [&] { return wr[r]; }, 1, basket, mirror, lg, lgm);
         }
-        const Real v = basket - o.strike;
-        Real p = v > 0 ? v : 0;
-        if (o.cv) {
-            const Real gv = exp_model(lg) - o.strike;
-            p -= gv > 0 ? gv : 0;
-        }
-        if (ANTI) {
-            const Real vm = mirror - o.strike;
-            Real pm = vm > 0 ? vm : 0;
-            if (o.cv) {
-                const Real gm = exp_model(lgm) - o.strike;
-                pm -= gm > 0 ? gm : 0;
-            }
-            p = (Real)0.5 * (p + pm);
-        }
+        const Real p = basket_sample<ANTI>(basket, mirror, lg, lgm, o.strike, o.cv);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)
@@ -909,36 +881,20 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_kernel(const Tail /* first
 // fp32 form of the tiled kernel (12..32 assets): two paths per lane in packed halves (like basket_f32_kernel
 // and basket_dyn_f32_kernel), normals in registers, each whole 4 x 4 tile (16 floats) one scalar load issued a
 // tile ahead.  Plain max for the payoff (no power-of-two rescale: the host folds none for these sizes).
-template <int NA, bool ANTI>
+template <int NA, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<float> o, const Work w, float *__restrict__ out)
 {
     constexpr int NB = (NA + 3) / 4, NP = 4 * NB, NT = NB * (NB + 1) / 2;
     typedef const __attribute__((address_space(4))) float *cptr;
     const cptr tiles = (cptr)o.consts, base = tiles + 16 * NT, coef = base + NP, wg = coef + NP;
     const uint32_t stride = gridDim.x * GROUP;
-    const f2 scale = bcast(0x1p-32f), half = bcast(0x1p-33f), neg2ln2 = bcast(NEG_2LN2_F32);
     double acc_s = 0.0, acc_q = 0.0;
+    Gen gen(w);
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += 2 * stride) {
         const bool has_b = i + stride < w.n_units;  // false only in a range's last trip
         const uint32_t cA = w.unit_lo + i, cB = w.unit_lo + (has_b ? i + stride : i);
         f2 g[NP];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const u32x4 ra = philox_unit(cA, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi);
-            const u32x4 rb = philox_unit(cB, w.unit_hi, (uint32_t)b, 2u, w.seed_lo, w.seed_hi);
-            const f2 ux = pk_fma((f2){(float)ra.x, (float)rb.x}, scale, half);
-            const f2 ax = {angle_f32(ra.y), angle_f32(rb.y)};
-            const f2 uz = pk_fma((f2){(float)ra.z, (float)rb.z}, scale, half);
-            const f2 az = {angle_f32(ra.w), angle_f32(rb.w)};
-            const f2 tx = (f2){__builtin_amdgcn_logf(ux.x), __builtin_amdgcn_logf(ux.y)} * neg2ln2;
-            const f2 tz = (f2){__builtin_amdgcn_logf(uz.x), __builtin_amdgcn_logf(uz.y)} * neg2ln2;
-            const f2 rx = {__builtin_amdgcn_sqrtf(tx.x), __builtin_amdgcn_sqrtf(tx.y)};
-            const f2 rz = {__builtin_amdgcn_sqrtf(tz.x), __builtin_amdgcn_sqrtf(tz.y)};
-            g[4 * b + 0] = rx * (f2){__builtin_amdgcn_cosf(ax.x), __builtin_amdgcn_cosf(ax.y)};
-            g[4 * b + 1] = rx * (f2){__builtin_amdgcn_sinf(ax.x), __builtin_amdgcn_sinf(ax.y)};
-            g[4 * b + 2] = rz * (f2){__builtin_amdgcn_cosf(az.x), __builtin_amdgcn_cosf(az.y)};
-            g[4 * b + 3] = rz * (f2){__builtin_amdgcn_sinf(az.x), __builtin_amdgcn_sinf(az.y)};
-        }
+        basket_normals_pk<NB>(gen, w, cA, cB, [&](int k) -> f2 & { return g[k]; });
         f2 basket = {0.0f, 0.0f}, mirror = {0.0f, 0.0f}, lg = bcast(o.cg), lgm = bcast(o.cg);
         float tl[2][16];
         int off = 0;
@@ -978,26 +934,10 @@ __global__ __launch_bounds__(GROUP) void basket_tiled_f32_kernel(const Tail /* f
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (r < rows) {
-                    basket = pk_fma(bcast(cf[r]), (f2){__builtin_amdgcn_exp2f(x[r].x), __builtin_amdgcn_exp2f(x[r].y)}, basket);
-                    lg = pk_fma(bcast(wr[r]), x[r], lg);
-                    if (ANTI) {
-                        const f2 xm = pk_fma(bcast(-1.0f), x[r], bcast(2.0f * bs[r]));
-                        mirror = pk_fma(bcast(cf[r]), (f2){__builtin_amdgcn_exp2f(xm.x), __builtin_amdgcn_exp2f(xm.y)}, mirror);
-                        lgm = pk_fma(bcast(wr[r]), xm, lgm);
-                    }
-                }
+                if (r < rows)
+                    basket_row_pk<ANTI>(x[r], bs[r], cf[r], [&] { return wr[r]; }, 1, basket, mirror, lg, lgm);
         }
-        const f2 zero = {0.0f, 0.0f}, strike = bcast(o.strike);
-        f2 p = __builtin_elementwise_max(basket - strike, zero);
-        if (o.cv)
-            p -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lg.x), __builtin_amdgcn_exp2f(lg.y)} - strike, zero);
-        if (ANTI) {
-            f2 pm = __builtin_elementwise_max(mirror - strike, zero);
-            if (o.cv)
-                pm -= __builtin_elementwise_max((f2){__builtin_amdgcn_exp2f(lgm.x), __builtin_amdgcn_exp2f(lgm.y)} - strike, zero);
-            p = bcast(0.5f) * (p + pm);
-        }
+        f2 p = basket_sample_pk<ANTI>(basket, mirror, lg, lgm, o.strike, o.cv);
         if (!has_b)
             p.y = 0.0f;
         acc_s += (double)p.x + (double)p.y;
@@ -1076,6 +1016,7 @@ __global__ __launch_bounds__(GROUP) void basket_mfma_f64_kernel(const Tail /* fi
     }
     const uint32_t stride = gridDim.x * GROUP;
     double acc_s = 0.0, acc_q = 0.0;
+    GenPhilox gen(w);
     // wave-uniform trip count: the matrix instructions want all 64 lanes
     for (uint32_t i0 = blockIdx.x * GROUP + (threadIdx.x & ~63u); i0 < w.n_units; i0 += stride) {
         double pb[4], pm[4], pl[4], plm[4];
@@ -1083,8 +1024,8 @@ __global__ __launch_bounds__(GROUP) void basket_mfma_f64_kernel(const Tail /* fi
         for (int c = 0; c < 4; ++c) {
             const uint32_t unit = w.unit_lo + i0 + 16u * c + j;
             double za[2], zb[2];
-            block_normals(unit, w.unit_hi, (uint32_t)q, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, za);
-            block_normals(unit, w.unit_hi, (uint32_t)q + 4u, 2u, w.seed_lo, w.seed_hi, zb);
+            gen.normals(w, unit, (uint32_t)q, 2u /*MC_DOMAIN_BASKET*/, za);
+            gen.normals(w, unit, (uint32_t)q + 4u, 2u, zb);
             d4 x = {cb[0], cb[1], cb[2], cb[3]};
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], za[0], x, 0, 0, 0);
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[1], za[1], x, 0, 0, 0);
@@ -1092,32 +1033,16 @@ __global__ __launch_bounds__(GROUP) void basket_mfma_f64_kernel(const Tail /* fi
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[3], zb[1], x, 0, 0, 0);
             double b = 0, m = 0, l = 0, lm = 0;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                b = __builtin_fma(cf[v], exp_model(x[v]), b);
-                if (ANTI) {
-                    const double xm = __builtin_fma(-1.0, x[v], 2 * cb[v]);
-                    m = __builtin_fma(cf[v], exp_model(xm), m);
-                    lm = __builtin_fma(wr[v], xm, lm);
-                }
-                l = __builtin_fma(wr[v], x[v], l);
-            }
+            for (int v = 0; v < 4; ++v)
+                basket_row<ANTI>(x[v], cb[v], cf[v], [&] { return wr[v]; }, 1, b, m, l, lm);
             pb[c] = b, pm[c] = m, pl[c] = l, plm[c] = lm;
         }
-        const double v = sum_over_lane_groups(pb[0], pb[1], pb[2], pb[3]) - o.strike;
-        double p = v > 0 ? v : 0;
-        if (o.cv) {   // wave-uniform
-            const double gv = exp_model(o.cg + sum_over_lane_groups(pl[0], pl[1], pl[2], pl[3])) - o.strike;
-            p -= gv > 0 ? gv : 0;
-        }
-        if (ANTI) {
-            const double vm = sum_over_lane_groups(pm[0], pm[1], pm[2], pm[3]) - o.strike;
-            double pmir = vm > 0 ? vm : 0;
-            if (o.cv) {
-                const double gm = exp_model(o.cg + sum_over_lane_groups(plm[0], plm[1], plm[2], plm[3])) - o.strike;
-                pmir -= gm > 0 ? gm : 0;
-            }
-            p = 0.5 * (p + pmir);
-        }
+        // the sums over the four lane groups (the control variate's only when it is on: wave-uniform)
+        const double basket = sum_over_lane_groups(pb[0], pb[1], pb[2], pb[3]);
+        const double mirror = ANTI ? sum_over_lane_groups(pm[0], pm[1], pm[2], pm[3]) : 0.0;
+        const double lg = o.cv ? o.cg + sum_over_lane_groups(pl[0], pl[1], pl[2], pl[3]) : 0.0;
+        const double lgm = (ANTI && o.cv) ? o.cg + sum_over_lane_groups(plm[0], plm[1], plm[2], plm[3]) : 0.0;
+        double p = basket_sample<ANTI>(basket, mirror, lg, lgm, o.strike, o.cv);
         const uint32_t i = i0 + lane;
         if (i >= w.n_units)
             p = 0;
@@ -1218,20 +1143,14 @@ __device__ __forceinline__ f2 bs_exposure_dates(f2 ln2_spot, f2 W, const float *
 // a * b + c with c read from its SGPR pair by the three-operand instruction (c must be wave-uniform)
 __device__ __forceinline__ double fma_scalar_addend(double a, double b, double c)
 {
-#ifndef MC_AB_CVA_NO_VGPR_CONST
     double r;
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
     return r;
-#else
-    return __builtin_fma(a, b, c);
-#endif
 }
 // a wave-uniform value in a vector register pair (one copy, where hipcc would make one per use)
 __device__ __forceinline__ double to_vgpr(double x)
 {
-#ifndef MC_AB_CVA_NO_VGPR_CONST
     asm("" : "+v"(x));
-#endif
     return x;
 }
 
@@ -1269,54 +1188,65 @@ __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const Cv
     return a - b;
 }
 
-// fp64: the two dates of one Philox block together, so that their four Hastings reciprocals share one v_rcp_f64.
-// Same operations per date as bs_exposure except for that shared reciprocal.
+// fp64: two consecutive dates of a path together, so that their four Hastings reciprocals share one v_rcp_f64 (a
+// 16-cycle instruction: -3.7 % kernel time for sharing in pairs, a further -1.3 % for four).  Same operations per date
+// as bs_exposure except for that shared reciprocal and 1/sqrt(2 pi) folded into the Hastings coefficients.
 __device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaStep<double> &sa, double ln_b, double W_b,
                                              const CvaStep<double> &sb, double &ee_a, double &ee_b)
 {
-#ifdef MC_AB_CVA_PER_DATE
-    ee_a = bs_exposure(ln_a, W_a, sa);
-    ee_b = bs_exposure(ln_b, W_b, sb);
-#else
     const double spot_a = exp_f64(ln_a), spot_b = exp_f64(ln_b);
     // The table row sits in SGPRs and a VALU instruction reads at most one scalar operand.  hipcc turns fma(W, g, e)
     // with g and e both scalar into v_fmac_f64 and copies the ADDEND into the destination pair first (two v_mov_b32 per
     // fma: 6 of the ~124 instructions per date).  Spelled out instead: g into a vector pair once (it serves d1 and d2),
     // the addends read straight from their SGPRs by the three-operand form -- same fma, same bits, 3 instructions per
-    // date instead of 6.
-#ifndef MC_AB_CVA_NO_VGPR_CONST
+    // date instead of 6 (-3.1 % instructions, -2.4 % time: profiles/r02_ab_cva_scalar_addend.log).
     const double g_a = scalar_to_vgpr(sa.g), g_b = scalar_to_vgpr(sb.g);
     const double d1a = fma_scalar_addend(W_a, g_a, sa.e1), d2a = fma_scalar_addend(W_a, g_a, sa.e2);
     const double d1b = fma_scalar_addend(W_b, g_b, sb.e1), d2b = fma_scalar_addend(W_b, g_b, sb.e2);
-#else
-    const double d1a = __builtin_fma(W_a, sa.g, sa.e1), d2a = __builtin_fma(W_a, sa.g, sa.e2);
-    const double d1b = __builtin_fma(W_b, sb.g, sb.e1), d2b = __builtin_fma(W_b, sb.g, sb.e2);
-#endif
-#ifndef MC_AB_CVA_NO_PHI_FOLD
     // A = C exp(.) with C = 1/sqrt(2 pi) folded into the Hastings coefficients (hastings_poly_phi): one multiply less per date
     const double A_a = exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));  // d1 runs away as tau -> 0
     const double A_b = exp_f64(fmax(__builtin_fma(-0.5 * d1b, d1b, ln_b), -800.0));
-#define MC_HASTINGS hastings_poly_phi
-#else
-    const double A_a = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));
-    const double A_b = 0.39894228040143267793994605993438 * exp_f64(fmax(__builtin_fma(-0.5 * d1b, d1b, ln_b), -800.0));
-#define MC_HASTINGS hastings_poly
-#endif
     double k1a, k2a, k1b, k2b;
     recip4_pos(__builtin_fma(0.2316419, fabs(d1a), 1.0), __builtin_fma(0.2316419, fabs(d2a), 1.0),
                __builtin_fma(0.2316419, fabs(d1b), 1.0), __builtin_fma(0.2316419, fabs(d2b), 1.0), k1a, k2a, k1b, k2b);
-    const double t1a = A_a * MC_HASTINGS(k1a), t2a = A_a * MC_HASTINGS(k2a);
-    const double t1b = A_b * MC_HASTINGS(k1b), t2b = A_b * MC_HASTINGS(k2b);
-#undef MC_HASTINGS
+    const double t1a = A_a * hastings_poly_phi(k1a), t2a = A_a * hastings_poly_phi(k2a);
+    const double t1b = A_b * hastings_poly_phi(k1b), t2b = A_b * hastings_poly_phi(k2b);
     ee_a = (d1a > 0 ? spot_a - t1a : t1a) - (d2a > 0 ? sa.disc - t2a : t2a);
     ee_b = (d1b > 0 ? spot_b - t1b : t1b) - (d2b > 0 ? sb.disc - t2b : t2b);
-#endif
 }
 
-template <class Real, bool ANTI, class Rng>
-__device__ __forceinline__ Real cva_path(Rng &rng, const CvaArgs<Real> &o, const Work &w, uint32_t c0)
+// One date the slow way: any date of a block that the pair forms below do not cover (a block's tail at the end of the
+// grid, the intrinsic-value date).  j is wave-uniform: the table row comes through scalar loads.
+template <class Real, bool ANTI>
+__device__ __forceinline__ void cva_single_date(const CvaArgs<Real> &o, int j, int n_dates, Real z, Real &W, Real &acc)
 {
-    constexpr int NPB = npb<Real>::value;
+    if (j >= n_dates)
+        return;
+    const CvaStep<Real> st = o.steps[j];
+    W += z;
+    const Real ln_spot = fma_r(W, o.bx, st.xk);     // natural log in f64, log2 in f32
+    const Real ln_mirror = fma_r(-W, o.bx, st.xk);  // the path driven by -z (ANTI only)
+    Real ee;
+    if (j < o.n_bs) {
+        ee = bs_exposure(ln_spot, W, st);
+        if (ANTI)
+            ee += bs_exposure(ln_mirror, -W, st);
+    } else {
+        const Real iv = exp_model(ln_spot) - o.strike;
+        ee = iv > 0 ? iv : 0;
+        if (ANTI) {
+            const Real ivm = exp_model(ln_mirror) - o.strike;
+            ee += ivm > 0 ? ivm : 0;
+        }
+    }
+    acc = fma_r(st.dp, ee, acc);
+}
+
+template <class Real, bool ANTI, class Gen>
+__device__ __forceinline__ Real cva_path(Gen &gen, const CvaArgs<Real> &o, const Work &w, uint32_t c0)
+{
+    constexpr int NPB = Gen::template npb<Real>();
+    static_assert(NPB % 2 == 0, "dates are priced in pairs");
     Real W = 0, acc = 0;
     f2 acc2 = {0.0f, 0.0f};  // fp32: even / odd dates of the packed date pairs
     Real z[NPB];
@@ -1325,65 +1255,40 @@ __device__ __forceinline__ Real cva_path(Rng &rng, const CvaArgs<Real> &o, const
     if constexpr (sizeof(Real) == 8)
         bx_v = to_vgpr(bx_v);
     for (int j0 = 0; j0 < n_dates; j0 += NPB) {
-        block_normals(rng, w, c0, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, z);
-        if constexpr (sizeof(Real) == 4) {
-#ifndef MC_AB_CVA_F32_PER_DATE
-            if (j0 + 3 < o.n_bs) {  // wave-uniform: all four dates of this block have a closed-form exposure
+        gen.normals(w, c0, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, z);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float *row = o.pairs + 12 * (j0 / 2 + h);
+        for (int h = 0; h < NPB / 2; ++h) {
+            const int j = j0 + 2 * h;
+            if (j + 1 < o.n_bs) {  // wave-uniform: both dates of this pair have a closed-form exposure
+                if constexpr (sizeof(Real) == 4) {
+                    // fp32: the pair's rows once more, field by field ({g, g'} ... {dp, dp'} adjacent: mc_api.hip), so the
+                    // two dates ride in the halves of every packed instruction (-8 % against packing d1, d2 of one date)
+                    const float *row = o.pairs + 12 * (j / 2);
                     const f2 Wp = {W + z[2 * h], (W + z[2 * h]) + z[2 * h + 1]};
                     W = Wp.y;
                     const f2 bx = {o.bx, o.bx}, xk = {row[6], row[7]}, dp = {row[10], row[11]};
-                    f2 ee = bs_exposure_dates(__builtin_elementwise_fma(Wp, bx, xk), Wp, row);
+                    f2 ee = bs_exposure_dates(pk_fma(Wp, bx, xk), Wp, row);
                     if (ANTI)
-                        ee += bs_exposure_dates(__builtin_elementwise_fma(-Wp, bx, xk), -Wp, row);
-                    acc2 = __builtin_elementwise_fma(dp, ee, acc2);
-                }
-                continue;
-            }
-#endif
-        }
-        if constexpr (sizeof(Real) == 8) {
-            if (j0 + 1 < o.n_bs) {  // wave-uniform: both dates of this block have a closed-form exposure
-                const CvaStep<double> sa = o.steps[j0], sb = o.steps[j0 + 1];
-                const double W_a = W + z[0], W_b = W_a + z[1];
-                W = W_b;
-                double ee_a, ee_b;
-                bs_exposure2(fma_scalar_addend(W_a, bx_v, sa.xk), W_a, sa, fma_scalar_addend(W_b, bx_v, sb.xk), W_b, sb, ee_a, ee_b);
-                if (ANTI) {
-                    double em_a, em_b;
-                    bs_exposure2(fma_scalar_addend(-W_a, bx_v, sa.xk), -W_a, sa, fma_scalar_addend(-W_b, bx_v, sb.xk), -W_b, sb, em_a, em_b);
-                    ee_a += em_a;
-                    ee_b += em_b;
-                }
-                acc = fma_r(sa.dp, ee_a, acc);
-                acc = fma_r(sb.dp, ee_b, acc);
-                continue;
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < NPB; ++jj) {
-            const int j = j0 + jj;  // wave-uniform: the table is read through scalar loads
-            if (j < n_dates) {
-                const CvaStep<Real> st = o.steps[j];
-                W += z[jj];
-                const Real ln_spot = fma_r(W, o.bx, st.xk);  // natural log in f64, log2 in f32
-                const Real ln_mirror = fma_r(-W, o.bx, st.xk);  // the path driven by -z (ANTI only)
-                Real ee;
-                if (j < o.n_bs) {
-                    ee = bs_exposure(ln_spot, W, st);
-                    if (ANTI)
-                        ee += bs_exposure(ln_mirror, -W, st);
+                        ee += bs_exposure_dates(pk_fma(-Wp, bx, xk), -Wp, row);
+                    acc2 = pk_fma(dp, ee, acc2);
                 } else {
-                    const Real iv = exp_model(ln_spot) - o.strike;
-                    ee = iv > 0 ? iv : 0;
+                    const CvaStep<double> sa = o.steps[j], sb = o.steps[j + 1];
+                    const double W_a = W + z[2 * h], W_b = W_a + z[2 * h + 1];
+                    W = W_b;
+                    double ee_a, ee_b;
+                    bs_exposure2(fma_scalar_addend(W_a, bx_v, sa.xk), W_a, sa, fma_scalar_addend(W_b, bx_v, sb.xk), W_b, sb, ee_a, ee_b);
                     if (ANTI) {
-                        const Real ivm = exp_model(ln_mirror) - o.strike;
-                        ee += ivm > 0 ? ivm : 0;
+                        double em_a, em_b;
+                        bs_exposure2(fma_scalar_addend(-W_a, bx_v, sa.xk), -W_a, sa, fma_scalar_addend(-W_b, bx_v, sb.xk), -W_b, sb, em_a, em_b);
+                        ee_a += em_a;
+                        ee_b += em_b;
                     }
+                    acc = fma_r(sa.dp, ee_a, acc);
+                    acc = fma_r(sb.dp, ee_b, acc);
                 }
-                acc = fma_r(st.dp, ee, acc);
+            } else {
+                cva_single_date<Real, ANTI>(o, j, n_dates, z[2 * h], W, acc);
+                cva_single_date<Real, ANTI>(o, j + 1, n_dates, z[2 * h + 1], W, acc);
             }
         }
     }
@@ -1392,16 +1297,16 @@ __device__ __forceinline__ Real cva_path(Rng &rng, const CvaArgs<Real> &o, const
     return acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);
 }
 
-template <class Real, bool ANTI, class Rng = RngPhilox>
+template <class Real, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
     double acc_s = 0.0, acc_q = 0.0;
-    Rng rng(w);
+    Gen gen(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
-        const Real p = cva_path<Real, ANTI>(rng, o, w, w.unit_lo + i);
+        const Real p = cva_path<Real, ANTI>(gen, o, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests
@@ -1438,8 +1343,9 @@ __global__ __launch_bounds__(GROUP) void basket_greeks_kernel(const Tail /* firs
     stage_tables<Real>();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = GenPhilox::npb<Real>();
     const int n = o.n, nblk = (n + NPB - 1) / NPB, mine = blockIdx.y;
+    GenPhilox gen(w);
     typedef const __attribute__((address_space(4))) Real *cptr;
     const cptr L = (cptr)o.consts, d = L + n * n, mu = d + n, v = mu + n, wt = v + n, s0 = wt + n, inv_s = s0 + n, vt = inv_s + n;
     const uint32_t stride = gridDim.x * GROUP;
@@ -1447,7 +1353,7 @@ __global__ __launch_bounds__(GROUP) void basket_greeks_kernel(const Tail /* firs
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
         for (int b = 0; b < nblk; ++b) {
             Real z[NPB];
-            block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, w.seed_lo, w.seed_hi, z);
+            gen.normals(w, w.unit_lo + i, (uint32_t)b, 2u /*MC_DOMAIN_BASKET*/, z);
 #pragma unroll
             for (int j = 0; j < NPB; ++j)
                 g[(b * NPB + j) * GROUP] = z[j];
@@ -1524,9 +1430,10 @@ __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first a
                                                            Real sqrt_dt)
 {
     stage_tables<Real>();
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = GenPhilox::npb<Real>();
     const uint32_t stride = gridDim.x * GROUP;
     const int n_dates = o.n_bs + o.last_intrinsic;
+    GenPhilox gen(w);
     typedef const __attribute__((address_space(4))) Real *cptr;
     const cptr sqrt_tau = (cptr)o.extra, sig_t = sqrt_tau + n_dates;
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -1534,7 +1441,7 @@ __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first a
         Real W = 0, cva = 0, delta = 0, vega = 0, z[NPB];
         for (int j = 0; j < n_dates; ++j) {   // wave-uniform: table rows through scalar loads
             if (j % NPB == 0)
-                block_normals(w.unit_lo + i, w.unit_hi, (uint32_t)(j / NPB), 3u /*MC_DOMAIN_CVA*/, w.seed_lo, w.seed_hi, z);
+                gen.normals(w, w.unit_lo + i, (uint32_t)(j / NPB), 3u /*MC_DOMAIN_CVA*/, z);
             const CvaStep<Real> st = o.steps[j];
             Real zz = z[0];
 #pragma unroll
@@ -1572,18 +1479,19 @@ __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first a
 }
 
 // =========================================================================================
-// Normals dump (parity tests of the generator itself).
+// Normals dump (parity tests of the generator itself): Gen::npb<Real>() normals per unit, unit-major.
 // =========================================================================================
-template <class Real>
+template <class Real, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void normals_kernel(const Work w, uint32_t block, uint32_t domain,
                                                         Real *__restrict__ out)
 {
     stage_tables<Real>();
-    constexpr int NPB = npb<Real>::value;
+    constexpr int NPB = Gen::template npb<Real>();
     const uint32_t stride = gridDim.x * GROUP;
+    Gen gen(w);
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
         Real z[NPB];
-        block_normals(w.unit_lo + i, w.unit_hi, block, domain, w.seed_lo, w.seed_hi, z);
+        gen.normals(w, w.unit_lo + i, block, domain, z);
 #pragma unroll
         for (int j = 0; j < NPB; ++j)
             out[(uint64_t)i * NPB + j] = z[j];

@@ -11,6 +11,10 @@
 // One Philox block gives four 32-bit words = 4 normals in f32 (one word per uniform) or
 // 2 normals in f64 (two words per uniform), by two-branch Box-Muller.  The oracle twin of
 // this file is oracle/mc_oracle_impl.h:orc_dev_normals (tests compare them word for word).
+//
+// WHERE a kernel's normals come from is a policy class (the `Gen` template parameter of every simulation kernel,
+// "generator policies" below): Philox (default), XORWOW (the reference's generator), Philox with fp32 normals widened
+// to double (the reference's own dp arithmetic, opt-in), or a caller-supplied array in HBM (tests only).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -68,101 +72,6 @@ __device__ __forceinline__ u32x4 philox_unit(uint32_t unit_lo, uint32_t unit_hi,
     return philox4x32_10(unit_hi, unit_lo, block, domain, k0, k1);
 }
 
-// ---- where a kernel's random words come from -------------------------------------------------------
-// `Work` (mc_kernels.hpp) is known to the kernels only; the generator policies take what they need from it.
-//
-// RngPhilox: the engine's generator.  Stateless: block (unit, block, domain) is a pure function of the counter.
-//
-// RngXorwow: the reference's generator (cuRAND XORWOW, dp/MonteCarloKernel.cu:285-290 curand_init, :68,78,250
-// curand_normal) as a SECOND, selectable generator (SURVEY 8f-4, mc_context_set_generator).  Marsaglia's xorwow:
-// 160 bits of xorshift state + a Weyl word, ~9 integer instructions per 32-bit word.  One sequence per LANE of the
-// launch, exactly like the reference's one curandState per thread: lane l starts from rocRAND's
-// rocrand_init(seed, subsequence = base + l, offset 0) -- the subsequences are 2^67 words apart -- and draws four
-// words whenever a kernel asks for a "block", in the order it asks (the counter arguments are ignored).  The start
-// states come from a context-owned array in HBM (24 B per lane, read once per launch: the reference reads 48 B per
-// thread, :189), filled by xorwow_init_kernel below when (seed, base) change; nothing is written back, so a call is
-// reproducible -- but, unlike Philox, WHICH normals a path gets depends on the launch geometry (DESIGN.md).
-struct RngPhilox {
-    template <class W> __device__ __forceinline__ explicit RngPhilox(const W &) {}
-    template <class W>
-    __device__ __forceinline__ u32x4 draw(const W &w, uint32_t unit_lo, uint32_t block, uint32_t domain)
-    {
-        return philox_unit(unit_lo, w.unit_hi, block, domain, w.seed_lo, w.seed_hi);
-    }
-};
-
-struct RngXorwow {
-    uint32_t x0, x1, x2, x3, x4, d;
-    template <class W> __device__ __forceinline__ explicit RngXorwow(const W &w)
-    {
-        const uint32_t *p = w.xorwow + 6u * (blockIdx.x * blockDim.x + threadIdx.x);
-        x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], d = p[5];
-    }
-    __device__ __forceinline__ uint32_t next()
-    {
-        const uint32_t t = x0 ^ (x0 >> 2);
-        x0 = x1, x1 = x2, x2 = x3, x3 = x4;
-        x4 = xor3(x4, x4 << 4, t ^ (t << 1));
-        d += 362437u;
-        return d + x4;
-    }
-    template <class W> __device__ __forceinline__ u32x4 draw(const W &, uint32_t, uint32_t, uint32_t)
-    {
-        u32x4 r;
-        r.x = next(), r.y = next(), r.z = next(), r.w = next();
-        return r;
-    }
-};
-
-// Start states of XORWOW lanes [0, lanes): the seeded state (5 xorshift words + Weyl word, prepared on the host)
-// jumped ahead by (base + lane) * 2^67 steps.  jump[i] = A^(2^67 * 2^i) over GF(2), A = one xorshift step, as 160
-// columns of 5 words (column c = image of state bit c); the host computes them by repeated squaring (mc_api.hip).
-// A jump is one conditional xor of a column per set state bit, per set bit of the subsequence number.
-constexpr int XORWOW_JUMP_BITS = 48;   // subsequence numbers below 2^48
-__global__ __launch_bounds__(256) void xorwow_init_kernel(const uint32_t *__restrict__ jump, uint32_t s0, uint32_t s1, uint32_t s2,
-                                                          uint32_t s3, uint32_t s4, uint32_t weyl, uint64_t base, uint32_t lanes,
-                                                          uint32_t *__restrict__ states)
-{
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= lanes)
-        return;
-    uint32_t v[5] = {s0, s1, s2, s3, s4};
-    const uint64_t sub = base + lane;
-    for (int i = 0; i < XORWOW_JUMP_BITS; ++i) {
-        if (!((sub >> i) & 1u))
-            continue;
-        const uint32_t *m = jump + (size_t)i * 160 * 5;
-        uint32_t r[5] = {0, 0, 0, 0, 0};
-        for (int c = 0; c < 160; ++c) {
-            const uint32_t mask = 0u - ((v[c >> 5] >> (c & 31)) & 1u);
-#pragma unroll
-            for (int k = 0; k < 5; ++k)
-                r[k] ^= mask & m[c * 5 + k];
-        }
-#pragma unroll
-        for (int k = 0; k < 5; ++k)
-            v[k] = r[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k)
-        states[6 * (size_t)lane + k] = v[k];
-    states[6 * (size_t)lane + 5] = weyl;
-}
-
-// `count` consecutive words of each of XORWOW lanes [0, lanes): the generator alone, for the word-for-word
-// comparison with rocRAND's engine (tests).  out[lane * count + k].
-__global__ __launch_bounds__(256) void xorwow_words_kernel(const uint32_t *__restrict__ states, uint32_t lanes, uint32_t count,
-                                                           uint32_t *__restrict__ out)
-{
-    struct { const uint32_t *xorwow; } w = {states};
-    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= lanes)
-        return;
-    RngXorwow rng(w);
-    for (uint32_t k = 0; k < count; ++k)
-        out[(size_t)lane * count + k] = rng.next();
-}
-
 // ---- f32 ---------------------------------------------------------------------------------
 // u = x * 2^-32 + 2^-33  in (0, 1]   (one v_cvt_f32_u32 + one v_fma_f32)
 __device__ __forceinline__ float u01_f32(uint32_t x)
@@ -207,19 +116,6 @@ __device__ __forceinline__ double u01_f64(uint32_t lo, uint32_t hi)
 }
 
 // Kernels that draw fp64 normals call stage_tables<double>() first (LDS tables of mc_math_f64.hpp).
-#ifdef MC_AB_NO_TABLES   // A/B switch (tools/ab_f64.py): polynomial-only log and sincos
-__device__ __forceinline__ void box_muller_f64(const u32x4 r, double &z_cos, double &z_sin)
-{
-    const double ua = u01_f64(r.x, r.y);
-    const double ub = u01_f64(r.z, r.w);
-    const double radius = sqrt_pos(-2.0 * log_unit(ua));
-    double s, c;
-    sincos_turns(ub, s, c);  // angle 2*pi*ub, quadrant reduction exact
-    z_cos = radius * c;
-    z_sin = radius * s;
-}
-template <class Real> __device__ __forceinline__ void stage_tables() {}
-#else
 __device__ __forceinline__ void box_muller_f64(const u32x4 r, double &z_cos, double &z_sin)
 {
     const double radius = sqrt_pos(neg2log_unit_tab(u01_f64(r.x, r.y)));
@@ -233,13 +129,8 @@ template <class Real> __device__ __forceinline__ void stage_tables()
     if constexpr (sizeof(Real) == 8)
         stage_f64_tables();
 }
-#endif
 
-template <class Real> struct npb;           // normals per Philox block
-template <> struct npb<float> { static constexpr int value = 4; };
-template <> struct npb<double> { static constexpr int value = 2; };
-
-// All normals of one block of four words, precision-generic: out[0..npb)
+// All normals of one block of four words: 4 in f32 (one word per uniform), 2 in f64 (two words per uniform)
 __device__ __forceinline__ void words_to_normals(const u32x4 r, float (&out)[4])
 {
     box_muller_f32(r.x, r.y, NEG_2LN2_F32, out[0], out[1]);
@@ -247,21 +138,181 @@ __device__ __forceinline__ void words_to_normals(const u32x4 r, float (&out)[4])
 }
 __device__ __forceinline__ void words_to_normals(const u32x4 r, double (&out)[2]) { box_muller_f64(r, out[0], out[1]); }
 
-__device__ __forceinline__ void block_normals(uint32_t unit_lo, uint32_t unit_hi, uint32_t block, uint32_t domain,
-                                              uint32_t k0, uint32_t k1, float (&out)[4])
+// ---- the unit of work a launch strides over (host side: mc_api.hip make_work) ----------------------------
+// `Work` describes one segment: units [unit_lo, unit_lo + n_units) with a common high word
+// (the host splits a range so that unit_lo + n_units <= 2^32 and n_units <= 2^31; only the low
+// word differs between lanes, which moves part of Philox's first rounds to the scalar unit: philox_unit).
+struct Work {
+    uint32_t seed_lo, seed_hi;  // Philox key
+    uint32_t unit_lo, unit_hi;  // first unit of the segment (64-bit counter, split)
+    uint32_t n_units;           // units in the segment
+    // path window for masked launches (vanilla edges, per-path dumps): a path is live iff
+    // first_path <= p < end_path.  Ignored by the unmasked kernels.
+    uint64_t first_path, end_path;
+    const uint32_t *xorwow;     // GenXorwow only: start states of the launch's lanes, 6 words each
+    const void *ext;            // GenExternal only (tests): normals of the segment's units, `ext_per_unit` Reals per unit
+    uint32_t ext_per_unit;
+};
+
+typedef float f2 __attribute__((ext_vector_type(2)));  // one VGPR pair: v_pk_{fma,mul,add}_f32 operands
+
+// ---- generator policies -------------------------------------------------------------------------------
+// A policy object lives in a lane's registers for the whole launch.  Interface:
+//   Gen(const Work &)                                   per-lane set-up (XORWOW: load the lane's state)
+//   npb<Real>()                                         normals one "block" yields in that precision
+//   normals(w, unit_lo, block, domain, Real (&z)[npb])  the normals of block `block` of unit `unit_lo`
+//   words(w, unit_lo, block, domain)                    the block's four raw words (word-level kernels: the packed-fp32
+//                                                       kernels build two paths' normals from words themselves);
+//                                                       absent when `external`
+//   external                                            normals come from memory, there are no words
+//
+// GenPhilox: the engine's generator.  Stateless: block (unit, block, domain) is a pure function of the counter.
+//
+// GenXorwow: the reference's generator (cuRAND XORWOW, dp/MonteCarloKernel.cu:285-290 curand_init, :68,78,250
+// curand_normal) as a SECOND, selectable generator (SURVEY 8f-4, mc_context_set_generator).  Marsaglia's xorwow:
+// 160 bits of xorshift state + a Weyl word, ~9 integer instructions per 32-bit word.  One sequence per LANE of the
+// launch, exactly like the reference's one curandState per thread: lane l starts from rocRAND's
+// rocrand_init(seed, subsequence = base + l, offset 0) -- the subsequences are 2^67 words apart -- and draws four
+// words whenever a kernel asks for a "block", in the order it asks (the counter arguments are ignored).  The start
+// states come from a context-owned array in HBM (24 B per lane, read once per launch: the reference reads 48 B per
+// thread, :189), filled by xorwow_init_kernel below when (seed, base) change; nothing is written back, so a call is
+// reproducible -- but, unlike Philox, WHICH normals a path gets depends on the launch geometry (DESIGN.md).
+//
+// GenPhiloxF32N (fp64 kernels only, opt-in: mc_context_set_normals): the reference's own "double precision" --
+// `double z = curand_normal(...)`, a FLOAT normal widened to double (dp/MonteCarloKernel.cu:68,78,250).
+// One Philox block then yields FOUR normals through the hardware transcendentals of the fp32 path instead of two
+// through mc_math_f64.hpp; everything downstream of the normal stays fp64.  Its own stream layout (4 normals per
+// block in fp64), mirrored by the oracle (orc_set_normals_f32).
+//
+// GenExternal (tests only: mc_*_from_normals_*): the normals are read from a caller-supplied array, `ext_per_unit`
+// Reals per unit, so that the reference's own normal stream (glibc rand() + Box-Muller, MonteCarloHost.c:117-121) can be
+// pushed through the very payoff / accumulation / final-reduction code of the hot kernels and compared with the
+// compiled reference's outputs (tests/test_gpu_from_normals.py).  Indices beyond a unit's count read as 0.
+struct GenPhilox {
+    static constexpr bool external = false;
+    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 2; }
+    __device__ __forceinline__ explicit GenPhilox(const Work &) {}
+    __device__ __forceinline__ u32x4 words(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain)
+    {
+        return philox_unit(unit_lo, w.unit_hi, block, domain, w.seed_lo, w.seed_hi);
+    }
+    template <class Real, int N>
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, Real (&z)[N])
+    {
+        words_to_normals(words(w, unit_lo, block, domain), z);
+    }
+};
+
+struct GenXorwow {
+    static constexpr bool external = false;
+    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 2; }
+    uint32_t x0, x1, x2, x3, x4, d;
+    __device__ __forceinline__ explicit GenXorwow(const uint32_t *states)
+    {
+        const uint32_t *p = states + 6u * (blockIdx.x * blockDim.x + threadIdx.x);
+        x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], d = p[5];
+    }
+    __device__ __forceinline__ explicit GenXorwow(const Work &w) : GenXorwow(w.xorwow) {}
+    __device__ __forceinline__ uint32_t next()
+    {
+        const uint32_t t = x0 ^ (x0 >> 2);
+        x0 = x1, x1 = x2, x2 = x3, x3 = x4;
+        x4 = xor3(x4, x4 << 4, t ^ (t << 1));
+        d += 362437u;
+        return d + x4;
+    }
+    __device__ __forceinline__ u32x4 words(const Work &, uint32_t, uint32_t, uint32_t)
+    {
+        u32x4 r;
+        r.x = next(), r.y = next(), r.z = next(), r.w = next();
+        return r;
+    }
+    template <class Real, int N>
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, Real (&z)[N])
+    {
+        words_to_normals(words(w, unit_lo, block, domain), z);
+    }
+};
+
+struct GenPhiloxF32N : GenPhilox {
+    template <class Real> static constexpr int npb() { return 4; }
+    __device__ __forceinline__ explicit GenPhiloxF32N(const Work &w) : GenPhilox(w) {}
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, double (&z)[4])
+    {
+        float f[4];
+        words_to_normals(words(w, unit_lo, block, domain), f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            z[j] = (double)f[j];   // the widening of `double z = curand_normal(...)`
+    }
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, float (&z)[4])
+    {
+        words_to_normals(words(w, unit_lo, block, domain), z);
+    }
+};
+
+struct GenExternal {
+    static constexpr bool external = true;
+    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 2; }
+    __device__ __forceinline__ explicit GenExternal(const Work &) {}
+    template <class Real, int N>
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t, Real (&z)[N])
+    {
+        const Real *p = static_cast<const Real *>(w.ext) + (size_t)(unit_lo - w.unit_lo) * w.ext_per_unit;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const uint32_t idx = block * (uint32_t)N + (uint32_t)j;
+            z[j] = idx < w.ext_per_unit ? p[idx] : (Real)0;
+        }
+    }
+};
+
+// Start states of XORWOW lanes [0, lanes): the seeded state (5 xorshift words + Weyl word, prepared on the host)
+// jumped ahead by (base + lane) * 2^67 steps.  jump[i] = A^(2^67 * 2^i) over GF(2), A = one xorshift step, as 160
+// columns of 5 words (column c = image of state bit c); the host computes them by repeated squaring (mc_api.hip).
+// A jump is one conditional xor of a column per set state bit, per set bit of the subsequence number.
+constexpr int XORWOW_JUMP_BITS = 48;   // subsequence numbers below 2^48
+__global__ __launch_bounds__(256) void xorwow_init_kernel(const uint32_t *__restrict__ jump, uint32_t s0, uint32_t s1, uint32_t s2,
+                                                          uint32_t s3, uint32_t s4, uint32_t weyl, uint64_t base, uint32_t lanes,
+                                                          uint32_t *__restrict__ states)
 {
-    words_to_normals(philox_unit(unit_lo, unit_hi, block, domain, k0, k1), out);
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= lanes)
+        return;
+    uint32_t v[5] = {s0, s1, s2, s3, s4};
+    const uint64_t sub = base + lane;
+    for (int i = 0; i < XORWOW_JUMP_BITS; ++i) {
+        if (!((sub >> i) & 1u))
+            continue;
+        const uint32_t *m = jump + (size_t)i * 160 * 5;
+        uint32_t r[5] = {0, 0, 0, 0, 0};
+        for (int c = 0; c < 160; ++c) {
+            const uint32_t mask = 0u - ((v[c >> 5] >> (c & 31)) & 1u);
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                r[k] ^= mask & m[c * 5 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            v[k] = r[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        states[6 * (size_t)lane + k] = v[k];
+    states[6 * (size_t)lane + 5] = weyl;
 }
-__device__ __forceinline__ void block_normals(uint32_t unit_lo, uint32_t unit_hi, uint32_t block, uint32_t domain,
-                                              uint32_t k0, uint32_t k1, double (&out)[2])
+
+// `count` consecutive words of each of XORWOW lanes [0, lanes): the generator alone, for the word-for-word
+// comparison with rocRAND's engine (tests).  out[lane * count + k].
+__global__ __launch_bounds__(256) void xorwow_words_kernel(const uint32_t *__restrict__ states, uint32_t lanes, uint32_t count,
+                                                           uint32_t *__restrict__ out)
 {
-    words_to_normals(philox_unit(unit_lo, unit_hi, block, domain, k0, k1), out);
-}
-// the same through a generator policy (RngPhilox: identical to the above; RngXorwow: the lane's next four words)
-template <class Rng, class W, class Real, int NPB>
-__device__ __forceinline__ void block_normals(Rng &rng, const W &w, uint32_t unit_lo, uint32_t block, uint32_t domain, Real (&out)[NPB])
-{
-    words_to_normals(rng.draw(w, unit_lo, block, domain), out);
+    const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane >= lanes)
+        return;
+    GenXorwow rng(states);
+    for (uint32_t k = 0; k < count; ++k)
+        out[(size_t)lane * count + k] = rng.next();
 }
 
 }  // namespace mc

@@ -171,6 +171,11 @@ static void orc_block_words(uint64_t seed, uint32_t domain, uint64_t unit, uint3
 }
 static int orc_xorwow_active(void) { return xw_mode.on; }
 
+/* fp64 family: 0 = native fp64 normals (2 per block), 1 = four fp32 normals per block widened to double (the reference's
+ * dp arithmetic; twin of the product's MC_NORMALS_F32).  See mc_oracle_impl.h: orc_dev_normals. */
+static int orc_normals_f32_mode;
+void orc_set_normals_f32(int on) { orc_normals_f32_mode = on != 0; }
+
 /* price = discount * sum/n;  s^2 = (n sum2 - sum^2) / (n (n-1));  CI = 1.96 s / sqrt(n).
  * dp/MonteCarloHost.c:220-228, dp/MonteCarloKernel.cu:420-423 (and :466-468 for CVA). */
 void orc_closing(double sum, double sum2, long long n, double discount, double *expected,

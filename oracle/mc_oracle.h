@@ -59,6 +59,15 @@ void orc_xorwow_jump_column(int i, int c, uint32_t out[5]);
 void orc_xorwow_begin(uint64_t seed, uint64_t subsequence_base, uint32_t lanes, uint64_t unit0);
 void orc_xorwow_end(void);
 
+/* fp64 orc_dev_* family: 1 = draw FOUR fp32 normals per block and widen them (`double z = curand_normal(...)`,
+ * dp/MonteCarloKernel.cu:68,78,250), 0 (default) = native fp64 normals.  Twin of mc_context_set_normals. */
+void orc_set_normals_f32(int on);
+
+/* flags of orc_dev_cva_on_normals_* (bridge tests): see mc_oracle_impl.h */
+#define ORC_CVA_HOST_ORDER 1
+#define ORC_CVA_REF_DP 2
+#define ORC_CVA_REF_T0 4
+
 /* Closing formulas shared by every estimator: reference MonteCarloHost.c:220-228 /
  * MonteCarloKernel.cu:420-423 (discount = exp(-rT) for prices, 1 for CVA :466). fp64. */
 void orc_closing(double sum, double sum2, long long n, double discount,
@@ -80,6 +89,31 @@ void orc_closing(double sum, double sum2, long long n, double discount,
                              int vol_in_diffusion, orc_result *out);                             \
     void orc_host_cva_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint, REAL lgd,         \
                           int n_grid, int paths, unsigned seed, orc_result *out);                \
+    /* the same with every path's value handed back (test tap; arithmetic untouched) */          \
+    void orc_host_vanilla_paths_##X(REAL s, REAL k, REAL r, REAL v, REAL t, int paths,           \
+                                    unsigned seed, REAL *payoffs, orc_result *out);              \
+    void orc_host_basket_paths_##X(int n, const REAL *s, const REAL *v, const REAL *p,           \
+                                   const REAL *d, const REAL *w, REAL k, REAL t, REAL r,         \
+                                   int paths, unsigned seed, int vol_in_diffusion,               \
+                                   REAL *payoffs, orc_result *out);                              \
+    void orc_host_cva_paths_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint, REAL lgd,   \
+                                int n_grid, int paths, unsigned seed, REAL *values,              \
+                                orc_result *out);                                                \
+    /* the reference's sequential REAL accumulation + closing on given per-path values */        \
+    void orc_ref_close_##X(const REAL *values, int paths, int discounted, REAL r, REAL t,        \
+                           orc_result *out);                                                     \
+    /* the DEVICE formulas on a caller-supplied normal stream (bridge to the compiled reference) */ \
+    int orc_dev_npb_##X(void);                                                                   \
+    void orc_dev_vanilla_on_normals_##X(REAL s, REAL k, REAL r, REAL v, REAL t, const REAL *z,   \
+                                        uint64_t n_paths, int antithetic, REAL *payoffs,         \
+                                        orc_result *out);                                        \
+    void orc_dev_basket_on_normals_##X(int n, const REAL *s, const REAL *v, const REAL *p,       \
+                                       const REAL *d, const REAL *w, REAL k, REAL t, REAL r,     \
+                                       const REAL *g, uint64_t n_paths, int mode,                \
+                                       REAL *payoffs, orc_result *out);                          \
+    void orc_dev_cva_on_normals_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint,         \
+                                    REAL lgd, int n_grid, const REAL *z, uint64_t n_paths,       \
+                                    int antithetic, int flags, REAL *values, orc_result *out);   \
     /* product stream (Philox), device formulas */                                               \
     void orc_dev_normals_##X(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block,      \
                              REAL *z);                                                           \

@@ -145,9 +145,10 @@ static void FN(host_close)(REAL sum, REAL sum2, int paths, int discounted, REAL 
     out->n = paths;
 }
 
-/* Vanilla: dp/MonteCarloHost.c:170-173 (payoff) inside :185-199 (loop). */
-void FN(orc_host_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, int paths, unsigned seed,
-                          orc_result *out)
+/* Vanilla: dp/MonteCarloHost.c:170-173 (payoff) inside :185-199 (loop).  `payoffs` (optional, test tap): every path's
+ * payoff as the reference forms it -- the arithmetic is untouched, the E/CI stay bit-pinned to the compiled reference. */
+void FN(orc_host_vanilla_paths)(REAL s, REAL k, REAL r, REAL v, REAL t, int paths, unsigned seed,
+                                REAL *payoffs, orc_result *out)
 {
     REAL sum = 0, sum2 = 0;
     srand(seed);
@@ -157,10 +158,17 @@ void FN(orc_host_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, int paths, uns
         REAL diffusion = g * SQRT_R(t) * v;
         REAL value = s * EXP_R((REAL)(drift + (double)diffusion)) - k;
         REAL payoff = value > 0 ? value : 0;
+        if (payoffs)
+            payoffs[i] = payoff;
         sum += payoff;
         sum2 += payoff * payoff;
     }
     FN(host_close)(sum, sum2, paths, 1, r, t, out);
+}
+void FN(orc_host_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, int paths, unsigned seed,
+                          orc_result *out)
+{
+    FN(orc_host_vanilla_paths)(s, k, r, v, t, paths, seed, NULL, out);
 }
 
 /* Basket: dp/MonteCarloHost.c:150-161 (correlated normals: n draws, FULL n x n product,
@@ -169,9 +177,9 @@ void FN(orc_host_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, int paths, uns
  *   vol_in_diffusion = 0 : si =      g[i]*sqrt(t)   (dp/MonteCarloHost.c:180 -- the reference
  *                          dp CPU bug; kept ONLY so the unmodified dp object
  *                          pins stream / mat-vec / accumulation order bit for bit) */
-void FN(orc_host_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
-                         const REAL *w, REAL k, REAL t, REAL r, int paths, unsigned seed,
-                         int vol_in_diffusion, orc_result *out)
+void FN(orc_host_basket_paths)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                               const REAL *w, REAL k, REAL t, REAL r, int paths, unsigned seed,
+                               int vol_in_diffusion, REAL *payoffs, orc_result *out)
 {
     REAL sum = 0, sum2 = 0;
     REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)n * 2);
@@ -199,18 +207,26 @@ void FN(orc_host_basket)(int n, const REAL *s, const REAL *v, const REAL *p, con
             basket += bt[a] * w[a];
         REAL value = basket - k;
         REAL payoff = value > 0 ? value : 0;
+        if (payoffs)
+            payoffs[i] = payoff;
         sum += payoff;
         sum2 += payoff * payoff;
     }
     free(g);
     FN(host_close)(sum, sum2, paths, 1, r, t, out);
 }
+void FN(orc_host_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                         const REAL *w, REAL k, REAL t, REAL r, int paths, unsigned seed,
+                         int vol_in_diffusion, orc_result *out)
+{
+    FN(orc_host_basket_paths)(n, s, v, p, d, w, k, t, r, paths, seed, vol_in_diffusion, NULL, out);
+}
 
 /* CVA, HOST ordering: dp/MonteCarloHost.c:231-276.  Exposure at step j is priced at the
  * spot of step j-1 (the new spot is stored after the exposure, :254-261);
  * time to maturity by repeated subtraction, exposure zero once it goes negative (:255-259). */
-void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd,
-                      int n_grid, int paths, unsigned seed, orc_result *out)
+void FN(orc_host_cva_paths)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd,
+                            int n_grid, int paths, unsigned seed, REAL *values, orc_result *out)
 {
     REAL sum = 0, sum2 = 0;
     REAL dt = t0 / n_grid;
@@ -230,10 +246,31 @@ void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REA
             spot = next;
         }
         acc *= lgd;
+        if (values)
+            values[i] = acc;
         sum += acc;
         sum2 += acc * acc;
     }
     FN(host_close)(sum, sum2, paths, 0, r, t0, out);
+}
+void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd,
+                      int n_grid, int paths, unsigned seed, orc_result *out)
+{
+    FN(orc_host_cva_paths)(s0, k, r, v, t0, defint, lgd, n_grid, paths, seed, NULL, out);
+}
+
+/* The reference's accumulation and closing applied to a given list of per-path values: sequential sums in REAL
+ * (dp/MonteCarloHost.c:196-198,214-216,264-266), then :220-228 / :270-275.  With the values of orc_host_*_paths it
+ * reproduces the reference's (Expected, Confidence) bit for bit; with the values of the orc_dev_*_on_normals functions
+ * below it says what the reference would have printed had it evaluated the DEVICE formulas on its own normals. */
+void FN(orc_ref_close)(const REAL *values, int paths, int discounted, REAL r, REAL t, orc_result *out)
+{
+    REAL sum = 0, sum2 = 0;
+    for (int i = 0; i < paths; i++) {
+        sum += values[i];
+        sum2 += values[i] * values[i];
+    }
+    FN(host_close)(sum, sum2, paths, discounted, r, t, out);
 }
 
 /* ===================================================================================== */
@@ -245,7 +282,7 @@ void FN(orc_host_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REA
  * f32: radius uniform u_a = fma(x, 2^-32, 2^-33) in (0,1], angle u_b = 1 + (x >> 9) 2^-23 revolutions;  f64: u = ((x_hi:x_lo >> 12) + 0.5) 2^-52 in (0,1)
  *   radius = sqrt(-2 ln u_a),  z_even = radius cos(2 pi u_b),  z_odd = radius sin(2 pi u_b)
  * The f32 radius is written with log2 (the HIP kernel's v_log_f32 is a base-2 log). */
-void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
+static void FN(dev_normals_native)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
 {
     uint32_t x[4];
     orc_block_words(seed, domain, unit, block, x);   /* Philox(counter, key), or the owning lane's XORWOW sequence */
@@ -273,6 +310,74 @@ void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t
 #endif
 }
 
+/* The normals of one block as the orc_dev_* family sees them, and how many there are:
+ *   default               ORC_NPB native normals (above)
+ *   orc_set_normals_f32   fp64 family only: FOUR fp32 normals of the block, widened -- the reference's own dp arithmetic,
+ *                         `double z = curand_normal(...)` (dp/MonteCarloKernel.cu:68,78,250); twin of the
+ *                         product's GenPhiloxF32N (mc_context_set_normals(ctx, MC_NORMALS_F32)). */
+int FN(orc_dev_npb)(void)
+{
+#if !ORC_IS_F32
+    if (orc_normals_f32_mode)
+        return 4;
+#endif
+    return ORC_NPB;
+}
+void FN(orc_dev_normals)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
+{
+#if !ORC_IS_F32
+    if (orc_normals_f32_mode) {
+        float f[4];
+        dev_normals_native_f32(seed, domain, unit, block, f);
+        for (int j = 0; j < 4; j++)
+            z[j] = (double)f[j];
+        return;
+    }
+#endif
+    FN(dev_normals_native)(seed, domain, unit, block, z);
+}
+
+/* Normal source of the per-path formulas below: the product stream (block by block, each block fetched once and in
+ * order -- what the XORWOW mode needs), or a caller-supplied array of `per_unit` normals per unit (the *_on_normals
+ * entry points: the reference's own glibc stream pushed through the DEVICE formulas). */
+typedef struct {
+    const REAL *ext;
+    uint64_t per_unit, first_unit;
+    uint64_t seed;
+    uint32_t domain;
+    uint64_t have_unit;
+    uint32_t have_block;
+    int have;
+    REAL z[4];
+} FN(nsrc);
+
+static FN(nsrc) FN(nsrc_stream)(uint64_t seed, uint32_t domain)
+{
+    FN(nsrc) q;
+    memset(&q, 0, sizeof q);
+    q.seed = seed, q.domain = domain;
+    return q;
+}
+static FN(nsrc) FN(nsrc_external)(const REAL *z, uint64_t per_unit, uint64_t first_unit)
+{
+    FN(nsrc) q;
+    memset(&q, 0, sizeof q);
+    q.ext = z, q.per_unit = per_unit, q.first_unit = first_unit;
+    return q;
+}
+/* normal number idx of unit `unit` */
+static REAL FN(nsrc_get)(FN(nsrc) *q, uint64_t unit, uint32_t idx)
+{
+    if (q->ext)
+        return idx < q->per_unit ? q->ext[(unit - q->first_unit) * q->per_unit + idx] : (REAL)0;
+    const uint32_t npb = (uint32_t)FN(orc_dev_npb)(), block = idx / npb;
+    if (!q->have || unit != q->have_unit || block != q->have_block) {
+        FN(orc_dev_normals)(q->seed, q->domain, unit, block, q->z);
+        q->have = 1, q->have_unit = unit, q->have_block = block;
+    }
+    return q->z[idx % npb];
+}
+
 static void FN(dev_finish)(double sum, double sum2, uint64_t n, double discount, orc_result *out)
 {
     if (!out)
@@ -287,25 +392,19 @@ static void FN(dev_finish)(double sum, double sum2, uint64_t n, double discount,
  *   payoff = max(S exp((r - v^2/2) T + v sqrt(T) z) - K, 0)
  * Path p draws normal (p mod NPB) of Philox unit (p div NPB), block 0, domain VANILLA.
  * Per-path values in REAL, (sum, sum2) accumulated in fp64. */
-void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
-                         uint64_t first_path, uint64_t n_paths, int antithetic, REAL *payoffs, orc_result *out)
+static void FN(dev_vanilla_core)(REAL s, REAL k, REAL r, REAL v, REAL t, FN(nsrc) *src, uint64_t npb,
+                                 uint64_t first_path, uint64_t n_paths, int antithetic, REAL *payoffs, orc_result *out)
 {
     const REAL drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)t);
     const REAL vol = (REAL)((double)v * sqrt((double)t));
     double sum = 0, sum2 = 0;
-    REAL z[ORC_NPB];
-    uint64_t have = (uint64_t)-1;
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t p = first_path + i;
-        uint64_t unit = p / ORC_NPB;
-        if (unit != have) {
-            FN(orc_dev_normals)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
-            have = unit;
-        }
-        REAL value = s * EXP_R(drift + vol * z[p % ORC_NPB]) - k;
+        REAL z = FN(nsrc_get)(src, p / npb, (uint32_t)(p % npb));
+        REAL value = s * EXP_R(drift + vol * z) - k;
         REAL payoff = value > 0 ? value : 0;
         if (antithetic) { /* sample = mean of the payoffs at z and -z */
-            REAL mirror = s * EXP_R(drift - vol * z[p % ORC_NPB]) - k;
+            REAL mirror = s * EXP_R(drift - vol * z) - k;
             payoff = (REAL)0.5 * (payoff + (mirror > 0 ? mirror : 0));
         }
         if (payoffs)
@@ -314,6 +413,20 @@ void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
         sum2 += (double)payoff * (double)payoff;
     }
     FN(dev_finish)(sum, sum2, n_paths, exp(-(double)r * (double)t), out);
+}
+void FN(orc_dev_vanilla)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t seed,
+                         uint64_t first_path, uint64_t n_paths, int antithetic, REAL *payoffs, orc_result *out)
+{
+    FN(nsrc) src = FN(nsrc_stream)(seed, ORC_DOMAIN_VANILLA);
+    FN(dev_vanilla_core)(s, k, r, v, t, &src, (uint64_t)FN(orc_dev_npb)(), first_path, n_paths, antithetic, payoffs, out);
+}
+/* The same formula on a caller-supplied normal per path (z[i] prices path i): with the reference's own stream
+ * (orc_host_gaussians) this bridges the device formulas to the compiled reference's outputs -- tests/test_oracle_bridge.py. */
+void FN(orc_dev_vanilla_on_normals)(REAL s, REAL k, REAL r, REAL v, REAL t, const REAL *z, uint64_t n_paths,
+                                    int antithetic, REAL *payoffs, orc_result *out)
+{
+    FN(nsrc) src = FN(nsrc_external)(z, 1, 0);
+    FN(dev_vanilla_core)(s, k, r, v, t, &src, 1, 0, n_paths, antithetic, payoffs, out);
 }
 
 /* Basket, device formulas dp/MonteCarloKernel.cu:74-87 (bt = P g + d, P = Cholesky factor
@@ -337,7 +450,7 @@ void FN(orc_dev_vanilla_greeks)(REAL s, REAL k, REAL r, REAL v, REAL t, uint64_t
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t p = first_path + i, unit = p / ORC_NPB;
         if (unit != have) {
-            FN(orc_dev_normals)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
+            FN(dev_normals_native)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
             have = unit;
         }
         REAL zz = z[p % ORC_NPB];
@@ -367,7 +480,7 @@ void FN(orc_dev_vanilla_greeks_lr)(REAL s, REAL k, REAL r, REAL v, REAL t, uint6
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t p = first_path + i, unit = p / ORC_NPB;
         if (unit != have) {
-            FN(orc_dev_normals)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
+            FN(dev_normals_native)(seed, ORC_DOMAIN_VANILLA, unit, 0, z);
             have = unit;
         }
         REAL zz = z[p % ORC_NPB];
@@ -395,7 +508,7 @@ void FN(orc_dev_basket_greeks)(int n, const REAL *s, const REAL *v, const REAL *
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t path = first_path + i;
         for (int b = 0; b < nblk; b++)
-            FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
+            FN(dev_normals_native)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
         REAL basket = 0;
         for (int a = 0; a < n; a++) {
             REAL bt = 0;
@@ -456,14 +569,15 @@ double FN(orc_basket_control_mean)(int n, const REAL *s, const REAL *v, const RE
 
 /* `mode` bit 0: antithetic variates; bit 1: geometric-basket control variate (the per-path value is
  * then payoff(arithmetic) - payoff(geometric), and the closed-form mean above is added back to the
- * expectation). */
-void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
-                        const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,
-                        uint64_t first_path, uint64_t n_paths, int mode, REAL *payoffs, orc_result *out)
+ * expectation); bit 2 (bridge tests only): the diffusion WITHOUT the volatility, si = bt_a sqrt T -- what the
+ * reference's dp CPU path computes (dp/MonteCarloHost.c:180), so that the unmodified dp object can pin
+ * the device formulas' mat-vec and accumulation order bit for bit. */
+static void FN(dev_basket_core)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                                const REAL *w, REAL k, REAL t, REAL r, FN(nsrc) *src, int n_draw,
+                                uint64_t first_path, uint64_t n_paths, int mode, REAL *payoffs, orc_result *out)
 {
-    const int antithetic = mode & 1, control = (mode >> 1) & 1;
-    int nblk = (n + ORC_NPB - 1) / ORC_NPB;
-    REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)(nblk * ORC_NPB));
+    const int antithetic = mode & 1, control = (mode >> 1) & 1, no_vol = (mode >> 2) & 1;
+    REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)(n_draw > n ? n_draw : n));
     const REAL sqrt_t = (REAL)sqrt((double)t);
     double wsum = 0;
     for (int a = 0; a < n; a++)
@@ -471,13 +585,10 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
     double sum = 0, sum2 = 0;
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t path = first_path + i;
-        for (int b = 0; b < nblk; b++)
-            FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
-        if (orc_xorwow_active()) { /* the generic kernel pads n to a multiple of 4 normals: the lane's sequence moves on */
-            REAL skip[ORC_NPB];
-            for (int b = nblk; b < 4 * ((n + 3) / 4) / ORC_NPB; b++)
-                FN(orc_dev_normals)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, skip);
-        }
+        /* n_draw >= n normals are drawn (whole blocks; in XORWOW mode the generic kernel's padding to a multiple of 4
+         * too: the lane's sequence moves on) */
+        for (int b = 0; b < n_draw; b++)
+            g[b] = FN(nsrc_get)(src, path, (uint32_t)b);
         REAL payoff = 0;
         for (int sign = 1; sign >= (antithetic ? -1 : 1); sign -= 2) {
             REAL basket = 0, lg = (REAL)log(wsum);
@@ -487,9 +598,10 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
                     bt += p[a * n + b] * ((REAL)sign * g[b]);
                 bt += d[a];
                 REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
-                REAL sa = s[a] * EXP_R(mu + v[a] * bt * sqrt_t);
+                REAL si = no_vol ? bt * sqrt_t : v[a] * bt * sqrt_t;
+                REAL sa = s[a] * EXP_R(mu + si);
                 basket += sa * w[a];
-                lg += (REAL)((double)w[a] / wsum) * (LOG_R(s[a]) + (mu + v[a] * bt * sqrt_t));
+                lg += (REAL)((double)w[a] / wsum) * (LOG_R(s[a]) + (mu + si));
             }
             REAL value = basket - k;
             payoff += value > 0 ? value : 0;
@@ -511,6 +623,26 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
     if (control && out)
         out->expected += disc * FN(orc_basket_control_mean)(n, s, v, p, d, w, k, t, r);
 }
+void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                        const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,
+                        uint64_t first_path, uint64_t n_paths, int mode, REAL *payoffs, orc_result *out)
+{
+    const int npb = FN(orc_dev_npb)();
+    int n_draw = (n + npb - 1) / npb * npb;
+    if (orc_xorwow_active())
+        n_draw = 4 * ((n + 3) / 4);
+    FN(nsrc) src = FN(nsrc_stream)(seed, ORC_DOMAIN_BASKET);
+    FN(dev_basket_core)(n, s, v, p, d, w, k, t, r, &src, n_draw, first_path, n_paths, mode & 3, payoffs, out);
+}
+/* The same formulas on a caller-supplied stream, n normals per path in drawing order (g[i * n + a]: path i, asset a) --
+ * the order the reference's simGaussVect draws them (dp/MonteCarloHost.c:150-161). */
+void FN(orc_dev_basket_on_normals)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,
+                                   const REAL *w, REAL k, REAL t, REAL r, const REAL *g, uint64_t n_paths,
+                                   int mode, REAL *payoffs, orc_result *out)
+{
+    FN(nsrc) src = FN(nsrc_external)(g, (uint64_t)n, 0);
+    FN(dev_basket_core)(n, s, v, p, d, w, k, t, r, &src, n, 0, n_paths, mode, payoffs, out);
+}
 
 /* CVA, DEVICE ordering dp/MonteCarloKernel.cu:241-262: at step j the spot is advanced FIRST
  * and the exposure is the Black-Scholes value at the NEW spot and the new time to maturity
@@ -522,34 +654,41 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
  *   - residual maturity exactly 0 -> exposure = intrinsic max(s-K,0), the limit of the
  *     closed form, instead of 0/0;
  *   - step j uses normal (j-1): Philox unit = path, block = (j-1) div NPB, domain CVA;
- *   - result is LGD * sum_j dp_j ee_j, NOT discounted (dp/MonteCarloKernel.cu:259,466). */
-void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid,
-                     uint64_t seed, uint64_t first_path, uint64_t n_paths, int antithetic, REAL *values,
-                     orc_result *out)
+ *   - result is LGD * sum_j dp_j ee_j, NOT discounted (dp/MonteCarloKernel.cu:259,466).
+ * `flags` (bridge tests only; 0 = the product's semantics above):
+ *   ORC_CVA_HOST_ORDER  the reference CPU loop's ordering (dp/MonteCarloHost.c:252-262): a normal is drawn at EVERY date,
+ *                       and the exposure of date j is priced at the spot of date j-1
+ *   ORC_CVA_REF_DP      dp_j as the reference forms it, a difference of two exponentials in REAL (:253, device :248)
+ *   ORC_CVA_REF_T0      a date with residual maturity exactly 0 goes through the closed form like any other (0/0 and all) */
+static void FN(dev_cva_core)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid,
+                             FN(nsrc) *src, uint64_t first_path, uint64_t n_paths, int antithetic, int flags,
+                             REAL *values, orc_result *out)
 {
+    const int host_order = flags & ORC_CVA_HOST_ORDER, ref_dp = flags & ORC_CVA_REF_DP, ref_t0 = flags & ORC_CVA_REF_T0;
     const REAL dt = t0 / n_grid;
     const REAL step_drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)dt);
     const REAL step_vol = (REAL)((double)v * sqrt((double)dt));
     double sum = 0, sum2 = 0;
-    REAL z[ORC_NPB];
     for (uint64_t i = 0; i < n_paths; i++) {
         uint64_t path = first_path + i;
         REAL spot = s0, mirror = s0, ttm = t0, acc = 0;
         for (int j = 1; j <= n_grid; j++) {
             double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
             /* e^{-l a} - e^{-l b} = -e^{-l a} expm1(-l (b - a)) */
-            REAL dpd = (REAL)(-exp(-(double)defint * t_prev) * expm1(-(double)defint * (t_now - t_prev)));
+            REAL dpd = ref_dp ? EXP_R(-(dt * (j - 1)) * defint) - EXP_R(-(dt * j) * defint)
+                              : (REAL)(-exp(-(double)defint * t_prev) * expm1(-(double)defint * (t_now - t_prev)));
             REAL ee = 0;
+            REAL spot_was = spot, mirror_was = mirror;
             ttm -= dt;
+            if (ttm >= 0 || host_order) {
+                REAL z = FN(nsrc_get)(src, path, (uint32_t)(j - 1));
+                spot = spot * EXP_R(step_drift + step_vol * z);
+                mirror = mirror * EXP_R(step_drift - step_vol * z);
+            }
             if (ttm >= 0) {
-                int idx = j - 1;
-                if (idx % ORC_NPB == 0)
-                    FN(orc_dev_normals)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
-                spot = spot * EXP_R(step_drift + step_vol * z[idx % ORC_NPB]);
-                mirror = mirror * EXP_R(step_drift - step_vol * z[idx % ORC_NPB]);
                 for (int leg = 0; leg < (antithetic ? 2 : 1); leg++) {
-                    REAL sx = leg ? mirror : spot, e1;
-                    if (ttm == 0) {
+                    REAL sx = host_order ? (leg ? mirror_was : spot_was) : (leg ? mirror : spot), e1;
+                    if (ttm == 0 && !ref_t0) {
                         REAL iv = sx - k;
                         e1 = iv > 0 ? iv : 0;
                     } else {
@@ -569,6 +708,20 @@ void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL
         sum2 += (double)acc * (double)acc;
     }
     FN(dev_finish)(sum, sum2, n_paths, 1.0, out);
+}
+void FN(orc_dev_cva)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid,
+                     uint64_t seed, uint64_t first_path, uint64_t n_paths, int antithetic, REAL *values,
+                     orc_result *out)
+{
+    FN(nsrc) src = FN(nsrc_stream)(seed, ORC_DOMAIN_CVA);
+    FN(dev_cva_core)(s0, k, r, v, t0, defint, lgd, n_grid, &src, first_path, n_paths, antithetic, 0, values, out);
+}
+/* The same loop on a caller-supplied stream, n_grid normals per path (z[i * n_grid + j - 1]: path i, date j). */
+void FN(orc_dev_cva_on_normals)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid,
+                                const REAL *z, uint64_t n_paths, int antithetic, int flags, REAL *values, orc_result *out)
+{
+    FN(nsrc) src = FN(nsrc_external)(z, (uint64_t)n_grid, 0);
+    FN(dev_cva_core)(s0, k, r, v, t0, defint, lgd, n_grid, &src, 0, n_paths, antithetic, flags, values, out);
 }
 
 /* CVA with its pathwise delta and vega: the loop of orc_dev_cva (plain estimator) carrying
@@ -597,7 +750,7 @@ void FN(orc_dev_cva_greeks)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defin
                 continue;
             int idx = j - 1;
             if (idx % ORC_NPB == 0)
-                FN(orc_dev_normals)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
+                FN(dev_normals_native)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
             spot = spot * EXP_R(step_drift + step_vol * z[idx % ORC_NPB]);
             wsum += z[idx % ORC_NPB];
             REAL ee, sd, sphi = 0;

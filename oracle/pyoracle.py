@@ -91,6 +91,21 @@ def lib() -> C.CDLL:
         for nm in ("orc_host_vanilla", "orc_host_basket", "orc_host_cva", "orc_dev_normals",
                    "orc_dev_vanilla", "orc_dev_basket", "orc_dev_cva"):
             f(nm).restype = None
+        # per-path taps of the host family, the reference's accumulation, the device formulas on a given normal stream
+        f("orc_host_vanilla_paths").argtypes = [R] * 5 + [C.c_int, C.c_uint, RP, res]
+        f("orc_host_basket_paths").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R, C.c_int, C.c_uint, C.c_int, RP, res]
+        f("orc_host_cva_paths").argtypes = [R] * 7 + [C.c_int, C.c_int, C.c_uint, RP, res]
+        f("orc_ref_close").argtypes = [RP, C.c_int, C.c_int, R, R, res]
+        f("orc_dev_vanilla_on_normals").argtypes = [R] * 5 + [RP, C.c_uint64, C.c_int, RP, res]
+        f("orc_dev_basket_on_normals").argtypes = [C.c_int, RP, RP, RP, RP, RP, R, R, R, RP, C.c_uint64, C.c_int, RP, res]
+        f("orc_dev_cva_on_normals").argtypes = [R] * 7 + [C.c_int, RP, C.c_uint64, C.c_int, C.c_int, RP, res]
+        for nm in ("orc_host_vanilla_paths", "orc_host_basket_paths", "orc_host_cva_paths", "orc_ref_close",
+                   "orc_dev_vanilla_on_normals", "orc_dev_basket_on_normals", "orc_dev_cva_on_normals"):
+            f(nm).restype = None
+        f("orc_dev_npb").argtypes = []
+        f("orc_dev_npb").restype = C.c_int
+    L.orc_set_normals_f32.argtypes = [C.c_int]
+    L.orc_set_normals_f32.restype = None
     return L
 
 
@@ -223,11 +238,104 @@ def host_cva(X, c, paths, seed):
     return r.as_dict()
 
 
+def dev_npb(X):
+    """Normals per block the orc_dev_* family of precision X currently draws (4; 2 in native fp64)."""
+    return int(getattr(lib(), f"orc_dev_npb_{X}")())
+
+
 def dev_normals(X, seed, domain, unit, block):
-    out = np.zeros(NPB[X], dtype=NP[X])
+    out = np.zeros(4, dtype=NP[X])
     getattr(lib(), f"orc_dev_normals_{X}")(seed, domain, unit, block,
                                            out.ctypes.data_as(C.POINTER(CT[X])))
-    return out
+    return out[:dev_npb(X)].copy()
+
+
+class normals_f32:
+    """Context manager: inside it the fp64 dev_* family draws FOUR fp32 normals per block, widened to double -- the
+    reference's dp arithmetic (``double z = curand_normal(...)``), twin of the product's MC_NORMALS_F32 mode."""
+
+    def __enter__(self):
+        lib().orc_set_normals_f32(1)
+        return self
+
+    def __exit__(self, *a):
+        lib().orc_set_normals_f32(0)
+
+
+CVA_HOST_ORDER, CVA_REF_DP, CVA_REF_T0 = 1, 2, 4     # flags of dev_cva_on_normals (mc_oracle.h)
+BASKET_NO_VOL = 4                                     # mode bit of dev_basket_on_normals: the dp CPU path's diffusion
+
+
+def host_vanilla_paths(X, opt, paths, seed):
+    """(per-path payoffs, result) of the reference CPU algorithm on its own stream (the E/CI are bit-pinned)."""
+    out = np.zeros(paths, dtype=NP[X])
+    r = OrcResult()
+    getattr(lib(), f"orc_host_vanilla_paths_{X}")(opt["s"], opt["k"], opt["r"], opt["v"], opt["t"], paths, seed,
+                                                  out.ctypes.data_as(C.POINTER(CT[X])), C.byref(r))
+    return out, r.as_dict()
+
+
+def host_basket_paths(X, b, paths, seed, vol_in_diffusion=None):
+    if vol_in_diffusion is None:
+        vol_in_diffusion = 1 if X == "f32" else 0
+    n = len(b["s"])
+    keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
+    out = np.zeros(paths, dtype=NP[X])
+    r = OrcResult()
+    getattr(lib(), f"orc_host_basket_paths_{X}")(n, *[p for _, p in keep], b["k"], b["t"], b["r"], paths, seed,
+                                                 vol_in_diffusion, out.ctypes.data_as(C.POINTER(CT[X])), C.byref(r))
+    return out, r.as_dict()
+
+
+def host_cva_paths(X, c, paths, seed):
+    out = np.zeros(paths, dtype=NP[X])
+    r = OrcResult()
+    getattr(lib(), f"orc_host_cva_paths_{X}")(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"], c["lgd"], c["n_grid"],
+                                              paths, seed, out.ctypes.data_as(C.POINTER(CT[X])), C.byref(r))
+    return out, r.as_dict()
+
+
+def ref_close(X, values, discounted, r, t):
+    """The reference's sequential accumulation in REAL + its closing formulas on given per-path values."""
+    v, vp = _arr(values, X)
+    res = OrcResult()
+    getattr(lib(), f"orc_ref_close_{X}")(vp, len(v), int(discounted), r, t, C.byref(res))
+    return res.as_dict()
+
+
+def dev_vanilla_on_normals(X, opt, z, antithetic=False):
+    """The DEVICE vanilla formula with z[i] as path i's normal: (payoffs, result with fp64 sums)."""
+    z, zp = _arr(z, X)
+    out = np.zeros(len(z), dtype=NP[X])
+    r = OrcResult()
+    getattr(lib(), f"orc_dev_vanilla_on_normals_{X}")(opt["s"], opt["k"], opt["r"], opt["v"], opt["t"], zp, len(z),
+                                                      int(antithetic), out.ctypes.data_as(C.POINTER(CT[X])), C.byref(r))
+    return out, r.as_dict()
+
+
+def dev_basket_on_normals(X, b, g, mode=0):
+    """The DEVICE basket formulas with g[i, a] as path i's normal for asset a (drawing order)."""
+    nn = len(b["s"])
+    g, gp = _arr(np.asarray(g).reshape(-1), X)
+    n_paths = len(g) // nn
+    keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
+    out = np.zeros(n_paths, dtype=NP[X])
+    r = OrcResult()
+    getattr(lib(), f"orc_dev_basket_on_normals_{X}")(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], gp, n_paths,
+                                                     mode, out.ctypes.data_as(C.POINTER(CT[X])), C.byref(r))
+    return out, r.as_dict()
+
+
+def dev_cva_on_normals(X, c, z, flags=0, antithetic=False):
+    """The DEVICE CVA loop with z[i, j-1] as path i's normal at date j; flags: CVA_HOST_ORDER | CVA_REF_DP | CVA_REF_T0."""
+    z, zp = _arr(np.asarray(z).reshape(-1), X)
+    n_paths = len(z) // c["n_grid"]
+    out = np.zeros(n_paths, dtype=NP[X])
+    r = OrcResult()
+    getattr(lib(), f"orc_dev_cva_on_normals_{X}")(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"], c["lgd"], c["n_grid"],
+                                                  zp, n_paths, int(antithetic), flags, out.ctypes.data_as(C.POINTER(CT[X])),
+                                                  C.byref(r))
+    return out, r.as_dict()
 
 
 def dev_vanilla(X, opt, seed, first, n, want_paths=True, antithetic=False):
