@@ -151,6 +151,16 @@ int mc_context_set_generator(mc_context *ctx, int generator, uint64_t subsequenc
 int mc_xorwow_words(mc_context *ctx, uint64_t seed, uint64_t first_subsequence, uint32_t n_subsequences,
                     uint32_t words_each, uint32_t *h_out);
 
+/* Normals of the fp64 kernels.  MC_NORMALS_NATIVE (default): true fp64 normals, two per Philox block (52-bit uniforms,
+ * mc_math_f64.hpp).  MC_NORMALS_F32: the reference's own dp arithmetic -- `double z = curand_normal(...)`, a FLOAT normal
+ * widened to double (dp/MonteCarloKernel.cu:68,78,250): four normals per Philox block through the hardware
+ * fp32 transcendentals, everything downstream of the normal in fp64.  A different (coarser: 24-bit normals, |z| < 6.77)
+ * stream than the default, same path indexing; about 1.4-1.7x the paths/s on the 16-asset basket and the 256-date CVA
+ * (DESIGN.md).  Philox only; no effect on the _f32 entry points; the Greeks entry points refuse it.  Also selected at
+ * context creation by the environment variable MC_F64_NORMALS=f32 (how the legacy symbols get it). */
+enum { MC_NORMALS_NATIVE = 0, MC_NORMALS_F32 = 1 };
+int mc_context_set_normals(mc_context *ctx, int mode);
+
 /* Where a call's per-workgroup (sum, sum2) pairs are added up (replaces the reference's D2H copy and host loop
  * over blocks, dp/MonteCarloKernel.cu:405,416-419).  fused != 0 (default): inside the simulation kernel, by the
  * last workgroup to arrive -- one launch per call.  fused == 0: by a second, one-workgroup launch (the A/B
@@ -267,11 +277,43 @@ int mc_cva_paths_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
 int mc_cva_paths_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
                      uint64_t first_path, uint64_t n_paths, double *h_out);
 /* The normals of Philox blocks (unit = first_unit .. first_unit+n_units-1, block, domain):
- * 4 per unit in f32, 2 per unit in f64, written unit-major to the HOST array h_out. */
+ * 4 per unit in f32, 2 per unit in f64 (4 under MC_NORMALS_F32), written unit-major to the HOST array h_out. */
 int mc_normals_f32(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,
                    uint64_t n_units, uint32_t block, float *h_out);
 int mc_normals_f64(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,
                    uint64_t n_units, uint32_t block, double *h_out);
+
+/* ---- test hooks: the simulation kernels on a caller-supplied normal stream -------------------------------------
+ * NOT part of the drop-in surface; speed irrelevant.  They run the pricing call's own simulation kernel for that size --
+ * payoff, per-lane sums and fp32 flushes, DPP/LDS reduction, last-arriver final reduction -- instantiated with a
+ * generator policy that READS the normals from HBM instead of drawing them, so that the reference's normal stream
+ * (glibc rand() + Box-Muller, MonteCarloHost.c:111-121) can be pushed through the HIP path and the result compared with
+ * numbers the compiled reference printed (tests/test_gpu_from_normals.py, tests/golden/ref_mc.json).
+ *   h_normals  HOST array.  vanilla: n_paths values, path i uses h_normals[i].  basket: n_paths * opt->n, path i's
+ *              normals in drawing order (MonteCarloHost.c:150-161).  CVA: n_paths * n_grid, date j of path i at
+ *              [i * n_grid + j - 1].
+ *   h_values   HOST array of n_paths per-path values (undiscounted), or NULL.
+ *   flags      MC_FROM_NORMALS_NO_VOL (basket): the diffusion without the volatility -- the model the reference's dp
+ *              CPU path computes (dp/MonteCarloHost.c:180); only its goldens need it.
+ *              MC_FROM_NORMALS_HOST_ORDER (CVA): the reference CPU loop's ordering, exposure of date j at the spot of
+ *              date j - 1 (dp/MonteCarloHost.c:254-261).
+ * Kernels: vanilla -- the hot kernels (whole units) + the masked kernel (a partial last unit, per-path values);
+ * basket -- 3 and 4 assets: the kernel-argument kernels, 16: the tiled kernels, otherwise the generic kernel;
+ * CVA -- cva_kernel.  Plain estimator, at most 2^26 paths. */
+#define MC_FROM_NORMALS_NO_VOL 1
+#define MC_FROM_NORMALS_HOST_ORDER 2
+int mc_vanilla_from_normals_f32(mc_context *ctx, const mc_option_f32 *opt, const float *h_normals, uint64_t n_paths,
+                                float *h_values, mc_result *out);
+int mc_vanilla_from_normals_f64(mc_context *ctx, const mc_option_f64 *opt, const double *h_normals, uint64_t n_paths,
+                                double *h_values, mc_result *out);
+int mc_basket_from_normals_f32(mc_context *ctx, const mc_basket_f32 *opt, const float *h_normals, uint64_t n_paths,
+                               int flags, float *h_values, mc_result *out);
+int mc_basket_from_normals_f64(mc_context *ctx, const mc_basket_f64 *opt, const double *h_normals, uint64_t n_paths,
+                               int flags, double *h_values, mc_result *out);
+int mc_cva_from_normals_f32(mc_context *ctx, const mc_cva_f32 *cva, const float *h_normals, uint64_t n_paths,
+                            int flags, float *h_values, mc_result *out);
+int mc_cva_from_normals_f64(mc_context *ctx, const mc_cva_f64 *cva, const double *h_normals, uint64_t n_paths,
+                            int flags, double *h_values, mc_result *out);
 
 /* ---- host-side helpers -------------------------------------------------------------- */
 /* Closing formulas of dp/MonteCarloKernel.cu:420-423 (discount = exp(-rT)) and :466-468

@@ -19,6 +19,7 @@ DOMAIN_VANILLA, DOMAIN_BASKET, DOMAIN_CVA = 1, 2, 3
 MAX_ASSETS = 16          # register-resident basket kernels
 MAX_ASSETS_GENERIC = 64  # LDS-staged generic kernel beyond that
 NPB = {"f32": 4, "f64": 2}
+FROM_NORMALS_NO_VOL, FROM_NORMALS_HOST_ORDER = 1, 2   # flags of the mc_*_from_normals_* test hooks
 CT = {"f32": C.c_float, "f64": C.c_double}
 
 
@@ -74,11 +75,12 @@ CVA = {"f32": CvaF32, "f64": CvaF64}
 
 # every symbol include/mc_mi355x.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = ["mc_last_error", "mc_device_count", "mc_context_create", "mc_context_destroy", "mc_context_device",
-           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read", "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing", "mc_context_order", "mc_context_idle", "mc_context_set_generator", "mc_xorwow_words", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
+           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read", "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing", "mc_context_order", "mc_context_idle", "mc_context_set_generator", "mc_context_set_normals", "mc_xorwow_words", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
 for _x in ("f32", "f64"):
     for _p in ("vanilla", "basket", "cva"):
         EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]
     EXPORTS.append(f"mc_normals_{_x}")
+    EXPORTS += [f"mc_{_p}_from_normals_{_x}" for _p in ("vanilla", "basket", "cva")]   # test hooks
     EXPORTS += [f"mc_vanilla_greeks_run_{_x}", f"mc_vanilla_greeks_lr_run_{_x}", f"mc_basket_greeks_run_{_x}", f"mc_cva_greeks_run_{_x}"]
 
 
@@ -103,6 +105,7 @@ def _declare(L: C.CDLL) -> C.CDLL:
     L.mc_context_order.argtypes = [ctx, C.c_void_p]
     L.mc_context_idle.argtypes = [ctx]
     L.mc_context_set_generator.argtypes = [ctx, C.c_int, C.c_uint64]
+    L.mc_context_set_normals.argtypes = [ctx, C.c_int]
     L.mc_xorwow_words.argtypes = [ctx, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     for X in ("f32", "f64"):
         getattr(L, f"mc_basket_control_mean_{X}").argtypes = [C.POINTER(BASKET[X]), C.POINTER(C.c_double)]
@@ -122,6 +125,9 @@ def _declare(L: C.CDLL) -> C.CDLL:
             getattr(L, f"mc_{prod}_run_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, C.POINTER(Result)]
             getattr(L, f"mc_{prod}_paths_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, RP]
         getattr(L, f"mc_normals_{X}").argtypes = [ctx, u64, C.c_uint32, u64, u64, C.c_uint32, RP]
+        getattr(L, f"mc_vanilla_from_normals_{X}").argtypes = [ctx, C.POINTER(OPTION[X]), RP, u64, RP, C.POINTER(Result)]
+        getattr(L, f"mc_basket_from_normals_{X}").argtypes = [ctx, C.POINTER(BASKET[X]), RP, u64, C.c_int, RP, C.POINTER(Result)]
+        getattr(L, f"mc_cva_from_normals_{X}").argtypes = [ctx, C.POINTER(CVA[X]), RP, u64, C.c_int, RP, C.POINTER(Result)]
         getattr(L, f"mc_vanilla_greeks_run_{X}").argtypes = [ctx, C.POINTER(OPTION[X]), u64, u64, u64, C.POINTER(Greeks)]
         getattr(L, f"mc_vanilla_greeks_lr_run_{X}").argtypes = [ctx, C.POINTER(OPTION[X]), u64, u64, u64, C.POINTER(Greeks)]
         getattr(L, f"mc_basket_greeks_run_{X}").argtypes = [ctx, C.POINTER(BASKET[X]), u64, u64, u64, C.POINTER(Result), C.POINTER(Result),

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mc_mi355x.h"
@@ -81,6 +82,13 @@ struct mc_context {
     uint32_t *d_xorwow_jump = nullptr;   // jump matrices A^(2^67 2^i), i < XORWOW_JUMP_BITS
     bool xorwow_valid = false;           // d_xorwow holds the states of (xorwow_seed, xorwow_state_base)
     uint64_t xorwow_seed = 0, xorwow_state_base = 0;
+    bool normals_f32 = false;     // fp64 kernels draw fp32 normals, widened (the reference's dp arithmetic): GenPhiloxF32N
+    // external normals (tests only, mc_*_from_normals_*): set around one enqueue
+    const void *ext = nullptr;    // device array, ext_per_unit Reals per unit
+    uint32_t ext_per_unit = 0;
+    int ext_flags = 0;
+    void *d_ext = nullptr;        // the context's buffer for them, grown on demand
+    size_t d_ext_bytes = 0;
     bool antithetic = false;      // estimator: plain (reference) or antithetic variates
     bool control = false;         // baskets: geometric-basket control variate
     // sampled device timing of the simulation kernels (mc_context_profile)
@@ -166,6 +174,8 @@ static int context_allocate(mc_context *c)
     HIPCHK(hipEventCreateWithFlags(&c->last_use, hipEventDisableTiming));
     if (const char *e = getenv("MC_FINISH"))   // "kernel": the two-launch form (A/B baseline); default: fused
         c->fused = strcmp(e, "kernel") != 0;
+    if (const char *e = getenv("MC_F64_NORMALS"))   // "f32": the reference's dp arithmetic (mc_context_set_normals)
+        c->normals_f32 = strcmp(e, "f32") == 0;
     return MC_OK;
 }
 
@@ -221,6 +231,7 @@ extern "C" void mc_context_destroy(mc_context *c)
     (void)hipHostFree(c->h_triple);
     (void)hipHostFree(c->h_direct);
     (void)hipFree(c->d_out);
+    (void)hipFree(c->d_ext);
     (void)hipFree(c->d_table);
     (void)hipHostFree(c->h_table);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -251,6 +262,14 @@ extern "C" int mc_context_set_antithetic(mc_context *c, int on)
     if (!c)
         return fail(MC_ERR_INVALID, "NULL context");
     c->antithetic = on != 0;
+    return MC_OK;
+}
+
+extern "C" int mc_context_set_normals(mc_context *c, int mode)
+{
+    if (!c || (mode != MC_NORMALS_NATIVE && mode != MC_NORMALS_F32))
+        return fail(MC_ERR_INVALID, "mc_context_set_normals: bad argument");
+    c->normals_f32 = mode == MC_NORMALS_F32;
     return MC_OK;
 }
 
@@ -361,6 +380,54 @@ static Work make_work(uint64_t seed, const Segment &s, uint64_t first_path, uint
     w.xorwow = nullptr;
     w.ext = nullptr;
     w.ext_per_unit = 0;
+    return w;
+}
+
+// Which generator policy (mc_rng.hpp) a launch runs with, and the dispatch from that run-time choice to the kernel
+// instantiation: f(gen_tag<Gen>) is instantiated only for the policies in ALLOW -- each kernel family is compiled for the
+// generators it supports and nothing else.
+enum GenSel { GEN_PHILOX = 1, GEN_XORWOW = 2, GEN_F32N = 4, GEN_EXTERNAL = 8 };
+template <class G> struct gen_tag { using type = G; };
+static GenSel gen_of(const mc_context *c, const Work &w, size_t real_bytes)
+{
+    if (w.ext) return GEN_EXTERNAL;
+    if (w.xorwow) return GEN_XORWOW;
+    return (real_bytes == 8 && c->normals_f32) ? GEN_F32N : GEN_PHILOX;
+}
+template <unsigned ALLOW, class F>
+static int with_gen(GenSel g, F f)
+{
+    if constexpr ((ALLOW & GEN_PHILOX) != 0)
+        if (g == GEN_PHILOX) { f(gen_tag<GenPhilox>{}); return MC_OK; }
+    if constexpr ((ALLOW & GEN_XORWOW) != 0)
+        if (g == GEN_XORWOW) { f(gen_tag<GenXorwow>{}); return MC_OK; }
+    if constexpr ((ALLOW & GEN_F32N) != 0)
+        if (g == GEN_F32N) { f(gen_tag<GenPhiloxF32N>{}); return MC_OK; }
+    if constexpr ((ALLOW & GEN_EXTERNAL) != 0)
+        if (g == GEN_EXTERNAL) { f(gen_tag<GenExternal>{}); return MC_OK; }
+    return fail(MC_ERR_UNSUPPORTED, "this kernel is not compiled for the selected generator / estimator combination");
+}
+// plain / antithetic x generator; the external-normals policy (tests) exists for the plain estimator only
+template <unsigned ALLOW, class F>
+static int with_anti_gen(bool anti, GenSel g, F f)
+{
+    if (anti)
+        return with_gen<(ALLOW & ~(unsigned)GEN_EXTERNAL)>(g, [&](auto tag) { f(std::true_type{}, tag); });
+    return with_gen<ALLOW>(g, [&](auto tag) { f(std::false_type{}, tag); });
+}
+// normals one block yields for precision Real under the context's settings (GenPhiloxF32N: 4 in fp64 too)
+template <class Real> static uint64_t npb_of(const mc_context *c) { return (sizeof(Real) == 8 && !c->normals_f32) ? 2 : 4; }
+
+// the Work of a launch, with the context's generator inputs attached
+static Work context_work(const mc_context *c, uint64_t seed, const Segment &s, uint64_t first_path, uint64_t end_path)
+{
+    Work w = make_work(seed, s, first_path, end_path);
+    if (c->ext) {
+        w.ext = c->ext;
+        w.ext_per_unit = c->ext_per_unit;
+    } else if (c->rng == MC_RNG_XORWOW) {
+        w.xorwow = c->d_xorwow;
+    }
     return w;
 }
 
@@ -686,18 +753,12 @@ template <class Real> struct VanillaTraits;
 template <> struct VanillaTraits<float> {
     using Opt = VanillaF32;
     using In = mc_option_f32;
-    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
-                           hipStream_t st)
+    static int launch_hot(mc_context *c, ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
+                          hipStream_t st)
     {
-        if (w.xorwow) {
-            if (anti)
-                launch_sim(prof, vanilla_f32_kernel<true, GenXorwow>, grid, st, tail, k, w);
-            else
-                launch_sim(prof, vanilla_f32_kernel<false, GenXorwow>, grid, st, tail, k, w);
-        } else if (anti)
-            launch_sim(prof, vanilla_f32_kernel<true>, grid, st, tail, k, w);
-        else
-            launch_sim(prof, vanilla_f32_kernel<false>, grid, st, tail, k, w);
+        return with_anti_gen<GEN_PHILOX | GEN_XORWOW | GEN_EXTERNAL>(anti, gen_of(c, w, 4), [&](auto a, auto tag) {
+            launch_sim(prof, vanilla_f32_kernel<decltype(a)::value, typename decltype(tag)::type>, grid, st, tail, k, w);
+        });
     }
     static int prepare(const In &o, Opt &k_, double &scale1, double &scale2)
     {
@@ -728,18 +789,12 @@ template <> struct VanillaTraits<float> {
 template <> struct VanillaTraits<double> {
     using Opt = VanillaF64;
     using In = mc_option_f64;
-    static void launch_hot(ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
-                           hipStream_t st)
+    static int launch_hot(mc_context *c, ProfileScope &prof, bool anti, const Opt &k, const Work &w, const Tail &tail, int grid,
+                          hipStream_t st)
     {
-        if (w.xorwow) {
-            if (anti)
-                launch_sim(prof, vanilla_kernel<Opt, double, true, GenXorwow>, grid, st, tail, k, w);
-            else
-                launch_sim(prof, vanilla_kernel<Opt, double, false, GenXorwow>, grid, st, tail, k, w);
-        } else if (anti)
-            launch_sim(prof, vanilla_kernel<Opt, double, true>, grid, st, tail, k, w);
-        else
-            launch_sim(prof, vanilla_kernel<Opt, double, false>, grid, st, tail, k, w);
+        return with_anti_gen<GEN_PHILOX | GEN_XORWOW | GEN_F32N | GEN_EXTERNAL>(anti, gen_of(c, w, 8), [&](auto a, auto tag) {
+            launch_sim(prof, vanilla_kernel<Opt, double, decltype(a)::value, typename decltype(tag)::type>, grid, st, tail, k, w);
+        });
     }
     static int prepare(const In &o, Opt &k, double &scale1, double &scale2)
     {
@@ -756,6 +811,18 @@ template <> struct VanillaTraits<double> {
     }
 };
 
+// The masked (generic) vanilla kernel of a launch: every generator, both estimators
+template <class Real>
+static int launch_vanilla_masked(mc_context *c, bool anti, const typename VanillaTraits<Real>::Opt &k, const Work &w, const Tail &t,
+                                 int grid, hipStream_t st, Real *out, Real out_scale)
+{
+    using Opt = typename VanillaTraits<Real>::Opt;
+    constexpr unsigned ALLOW = sizeof(Real) == 8 ? (GEN_PHILOX | GEN_XORWOW | GEN_F32N | GEN_EXTERNAL) : (GEN_PHILOX | GEN_XORWOW | GEN_EXTERNAL);
+    return with_anti_gen<ALLOW>(anti, gen_of(c, w, sizeof(Real)), [&](auto a, auto tag) {
+        vanilla_masked_kernel<Opt, Real, decltype(a)::value, typename decltype(tag)::type><<<grid, GROUP, 0, st>>>(t, k, w, out, out_scale);
+    });
+}
+
 // Enqueue simulation + reduction of paths [first, first+n).  out != nullptr additionally stores
 // every payoff (device buffer of n Reals) and forces the masked kernel for all units.
 template <class Real>
@@ -763,7 +830,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
                            uint64_t first, uint64_t n, double *d_triple, hipStream_t st, Real *out)
 {
     using T = VanillaTraits<Real>;
-    constexpr uint64_t NPB = GenPhilox::npb<Real>();
+    const uint64_t NPB = npb_of<Real>(c);   // paths per unit
     typename T::Opt k;
     double scale1, scale2;
     if (int rc = T::prepare(*opt, k, scale1, scale2))
@@ -773,27 +840,26 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         scale1 *= 0.5;
         scale2 *= 0.25;
     }
-    const auto masked = anti ? vanilla_masked_kernel<typename T::Opt, Real, true> : vanilla_masked_kernel<typename T::Opt, Real, false>;
     if (int rc = begin_call(c, st)) return rc;
     const uint64_t end = first + n;
-    if (c->rng == MC_RNG_XORWOW) {
+    if (c->rng == MC_RNG_XORWOW && !c->ext) {
+        if (sizeof(Real) == 8 && c->normals_f32)
+            return fail(MC_ERR_UNSUPPORTED, "fp32 normals in the fp64 kernels are implemented for the Philox generator");
         // one masked launch over every unit the range touches (no separate edge launches: a lane's sequence would
-        // restart in them); the masked kernel is the generic form, the only one compiled for both generators
-        const auto xw = anti ? vanilla_masked_kernel<typename T::Opt, Real, true, GenXorwow> : vanilla_masked_kernel<typename T::Opt, Real, false, GenXorwow>;
+        // restart in them); the masked kernel is the generic form
         std::vector<Segment> one;
         const uint64_t u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
         if (int rc = plan_segments(u0, u1 - u0, one)) return rc;
         if (int rc = xorwow_one_segment(one)) return rc;
         if (int rc = xorwow_ready(c, seed, st)) return rc;
-        Work w = make_work(seed, one[0], first, end);
-        w.xorwow = c->d_xorwow;
+        const Work w = context_work(c, seed, one[0], first, end);
         const int g = grid_for(c, one[0].count);
         Tail t = make_tail(c, g, scale1, scale2, n, d_triple);
         if (!out && first % NPB == 0 && end % NPB == 0) {   // whole units only (what the legacy symbols ask for): the hot kernel,
             ProfileScope prof(c);                           // same lanes, same draws, same sums up to fp32 partial-sum order
-            T::launch_hot(prof, anti, k, w, t, g, st);
-        } else
-            xw<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
+            if (int rc = T::launch_hot(c, prof, anti, k, w, t, g, st)) return rc;
+        } else if (int rc = launch_vanilla_masked<Real>(c, anti, k, w, t, g, st, out, (Real)scale1))
+            return rc;
         return finish_call(c, t, g, st);
     }
     std::vector<Segment> segs;
@@ -812,6 +878,8 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         has_head = (first % NPB) != 0;
         has_tail = (end % NPB) != 0 && !(has_head && tail_unit == head);
     }
+    if (c->ext && (segs.size() > 1 || first != 0))
+        return fail(MC_ERR_INVALID, "external normals: one segment starting at path 0");
     const auto grid = [&](uint32_t units) { return out ? grid_for(c, units) : grid_for_vanilla(c, units); };
     int total = (has_head ? 1 : 0) + (has_tail ? 1 : 0);
     for (const Segment &s : segs)
@@ -819,21 +887,23 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     Tail t = make_tail(c, total, scale1, scale2, n, d_triple);
     int slot = 0;
     for (const Segment &s : segs) {
-        const Work w = make_work(seed, s, first, end);
+        const Work w = context_work(c, seed, s, first, end);
         const int g = grid(s.count);
         t.slot_base = t.ticket_base = (uint32_t)slot;
-        if (out)
-            masked<<<g, GROUP, 0, st>>>(t, k, w, out, (Real)scale1);
-        else
-            T::launch_hot(prof, anti, k, w, t, g, st);
+        if (out) {
+            if (int rc = launch_vanilla_masked<Real>(c, anti, k, w, t, g, st, out, (Real)scale1)) return rc;
+        } else if (int rc = T::launch_hot(c, prof, anti, k, w, t, g, st))
+            return rc;
         slot += g;
     }
     for (int e = 0; e < 2; ++e) {
         if (!(e == 0 ? has_head : has_tail))
             continue;
-        const Work w = make_work(seed, Segment{e == 0 ? head : tail_unit, 1u}, first, end);
+        Work w = context_work(c, seed, Segment{e == 0 ? head : tail_unit, 1u}, first, end);
+        if (w.ext)   // the external array is indexed from the launch's first unit
+            w.ext = static_cast<const Real *>(w.ext) + w.unit_lo * (uint64_t)w.ext_per_unit;
         t.slot_base = t.ticket_base = (uint32_t)slot;
-        masked<<<1, GROUP, 0, st>>>(t, k, w, nullptr, (Real)1);
+        if (int rc = launch_vanilla_masked<Real>(c, anti, k, w, t, 1, st, (Real *)nullptr, (Real)1)) return rc;
         slot += 1;
     }
     return finish_call(c, t, total, st);
@@ -887,8 +957,8 @@ static int planes_run(mc_context *c, int planes, int grid_y, uint64_t unit0, uin
 {
     const auto wall0 = std::chrono::steady_clock::now();
     hipStream_t st = c->stream;
-    if (c->rng != MC_RNG_PHILOX)
-        return fail(MC_ERR_UNSUPPORTED, "greeks: implemented for the Philox generator only");
+    if (c->rng != MC_RNG_PHILOX || c->normals_f32)
+        return fail(MC_ERR_UNSUPPORTED, "greeks: implemented for the Philox generator with native normals only");
     if (int rc = begin_call(c, st)) return rc;
     if (int rc = ensure_planes(c, planes)) return rc;
     std::vector<Segment> segs;
@@ -994,25 +1064,32 @@ template <> struct BasketIn<double> { using type = mc_basket_f64; };
 template <class Real> static constexpr double exp_scale() { return 1.0; }
 template <> constexpr double exp_scale<float>() { return 1.4426950408889634074; }  // log2(e): E = 2^x
 
-// the kernel of each precision: f32 = two paths per lane in packed halves, f64 = one path per lane
+// the kernel of each precision: f32 = two paths per lane in packed halves, f64 = one path per lane.  Generators: Philox;
+// fp32 normals widened (fp64, up to the default static limit of 8 assets); external normals for the sizes the bridge
+// tests use (3 = the reference's N, 4 = BASELINE C3).
 template <int NA>
-static void basket_launch_kernel(ProfileScope &prof, bool anti, const BasketArgs<float, NA> &k, const Work &w,
-                                 const Tail &tail, float *out, double scale, int grid, hipStream_t st)
+static int basket_launch_kernel(mc_context *c, ProfileScope &prof, bool anti, const BasketArgs<float, NA> &k, const Work &w,
+                                const Tail &tail, float *out, double scale, int grid, hipStream_t st)
 {
-    if (anti)
-        launch_sim(prof, basket_f32_kernel<NA, true>, grid, st, tail, k, w, out, (float)scale);
-    else
-        launch_sim(prof, basket_f32_kernel<NA, false>, grid, st, tail, k, w, out, (float)scale);
+    constexpr unsigned ALLOW = GEN_PHILOX | ((NA == 3 || NA == 4) ? GEN_EXTERNAL : 0);
+    return with_anti_gen<ALLOW>(anti, gen_of(c, w, 4), [&](auto a, auto tag) {
+        launch_sim(prof, basket_f32_kernel<NA, decltype(a)::value, typename decltype(tag)::type>, grid, st, tail, k, w, out, (float)scale);
+    });
 }
 template <int NA>
-static void basket_launch_kernel(ProfileScope &prof, bool anti, const BasketArgs<double, NA> &k, const Work &w,
-                                 const Tail &tail, double *out, double, int grid, hipStream_t st)
+static int basket_launch_kernel(mc_context *c, ProfileScope &prof, bool anti, const BasketArgs<double, NA> &k, const Work &w,
+                                const Tail &tail, double *out, double, int grid, hipStream_t st)
 {
-    if (anti)
-        launch_sim(prof, basket_kernel<double, NA, true>, grid, st, tail, k, w, out);
-    else
-        launch_sim(prof, basket_kernel<double, NA, false>, grid, st, tail, k, w, out);
+    constexpr unsigned ALLOW = GEN_PHILOX | (NA <= 8 ? GEN_F32N : 0) | ((NA == 3 || NA == 4) ? GEN_EXTERNAL : 0);
+    return with_anti_gen<ALLOW>(anti, gen_of(c, w, 8), [&](auto a, auto tag) {
+        launch_sim(prof, basket_kernel<double, NA, decltype(a)::value, typename decltype(tag)::type>, grid, st, tail, k, w, out);
+    });
 }
+
+// The volatility that multiplies the correlated normals.  MC_FROM_NORMALS_NO_VOL (bridge tests only) replaces it by 1: the
+// reference's dp CPU path forms the diffusion without it (dp/MonteCarloHost.c:180), and its goldens can
+// only be met on that model.  The drift keeps the true volatility, as it does there.
+static double diffusion_vol(const mc_context *c, double v) { return (c->ext && (c->ext_flags & MC_FROM_NORMALS_NO_VOL)) ? 1.0 : v; }
 
 template <class Real, int NA>
 static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
@@ -1026,9 +1103,10 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     double m[NA][NA], base[NA], coef[NA];
     for (int a = 0; a < NA; ++a) {
         const double va = (double)o.v[a];
+        const double vd = diffusion_vol(c, va);   // va, except under the bridge tests' reference-CPU-bug switch
         for (int b = 0; b <= a; ++b)
-            m[a][b] = va * sqrt_t * (double)o.p[a * NA + b] * sc;
-        base[a] = (((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc;
+            m[a][b] = vd * sqrt_t * (double)o.p[a * NA + b] * sc;
+        base[a] = (((double)o.r - 0.5 * va * va) * (double)o.t + vd * sqrt_t * (double)o.d[a]) * sc;
         coef[a] = (double)o.w[a] * (double)o.s[a];
         double bound = std::fabs(base[a]);
         for (int b = 0; b <= a; ++b)
@@ -1087,10 +1165,11 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     Tail t = make_tail(c, total, out_scale, out_scale * out_scale, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
-        const Work w = make_work(seed, s, 0, 0);
+        const Work w = context_work(c, seed, s, 0, 0);
         const int g = grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
         t.slot_base = t.ticket_base = (uint32_t)slot;
-        basket_launch_kernel<NA>(prof, c->antithetic, k, w, t, out ? out + done : (Real *)nullptr, out_scale, g, st);
+        if (int rc = basket_launch_kernel<NA>(c, prof, c->antithetic, k, w, t, out ? out + done : (Real *)nullptr, out_scale, g, st))
+            return rc;
         slot += g;
         done += s.count;
     }
@@ -1159,7 +1238,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
             for (int lane = 0; lane < 64; ++lane) {
                 const int a = lane & 15, b = 2 * (lane >> 4) + (s4 & 1) + 8 * (s4 >> 1);
                 if (a < n && b <= a)
-                    host[n_tiles + 3 * (size_t)np + 64 * s4 + lane] = (Real)((double)o.v[a] * sqrt_t * (double)o.p[a * n + b] * sc);
+                    host[n_tiles + 3 * (size_t)np + 64 * s4 + lane] = (Real)(diffusion_vol(c, (double)o.v[a]) * sqrt_t * (double)o.p[a * n + b] * sc);
             }
     size_t t = 0;
     for (int A = 0; A < nb; ++A)
@@ -1168,15 +1247,15 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
                 for (int r = 0; r < 4; ++r) {
                     const int a = 4 * A + r, b = 4 * c4 + j;
                     if (a < n && b <= a)
-                        host[t + 4 * j + r] = (Real)((double)o.v[a] * sqrt_t * (double)o.p[a * n + b] * sc);
+                        host[t + 4 * j + r] = (Real)(diffusion_vol(c, (double)o.v[a]) * sqrt_t * (double)o.p[a * n + b] * sc);
                 }
     for (int a = 0; a < n; ++a) {
-        const double va = (double)o.v[a];
-        host[n_tiles + a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + va * sqrt_t * (double)o.d[a]) * sc);
+        const double va = (double)o.v[a], vd = diffusion_vol(c, va);
+        host[n_tiles + a] = (Real)((((double)o.r - 0.5 * va * va) * (double)o.t + vd * sqrt_t * (double)o.d[a]) * sc);
         host[n_tiles + np + a] = (Real)((double)o.w[a] * (double)o.s[a]);
         double bound = std::fabs((double)host[n_tiles + a]);
         for (int b = 0; b <= a; ++b)
-            bound += std::fabs((double)o.v[a] * sqrt_t * (double)o.p[a * n + b] * sc) * Z_MAX_F64;
+            bound += std::fabs(vd * sqrt_t * (double)o.p[a * n + b] * sc) * Z_MAX_F64;
         if (!exponent_in_range(bound / sc))
             return fail(MC_ERR_INVALID, "basket: asset %d's drift and volatility put its terminal price outside the range of a double", a);
     }
@@ -1204,40 +1283,68 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     k.strike = o.k;
     k.cg = (Real)cg_dyn;
     k.cv = c->control ? 1 : 0;
+    // Pick the kernel.  `gen` = the generator policy of this call; families and what they are compiled for:
+    //   generic one-path-per-lane (basket_dyn_kernel)      every generator, any n
+    //   fp64 tiled (9..32)                                 Philox, fp32-normals-widened, external (16 only: BASELINE C4)
+    //   fp32 tiled (13..32), fp32 generic pairs            Philox, external (16 only)
+    //   fp64 matrix-core (13..16, opt-in)                  Philox
+    const bool anti = c->antithetic;
+    const Work probe = context_work(c, seed, segs[0], 0, 0);
+    const GenSel gen = gen_of(c, probe, sizeof(Real));
+    using Kernel = void (*)(const Tail, const BasketDyn<Real>, const Work, Real *);
+    Kernel kernel = nullptr;
     size_t lds = (size_t)np * GROUP * sizeof(Real);
-    auto kernel = c->antithetic ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
     bool pairs = false;  // two paths per lane
-    const bool xorwow = c->rng == MC_RNG_XORWOW;
-    if (xorwow) {   // one path per lane, normals in the lane's LDS column, any n
-        kernel = c->antithetic ? basket_dyn_kernel<Real, true, GenXorwow> : basket_dyn_kernel<Real, false, GenXorwow>;
+    const bool tiled_ok = n >= basket_tiled_min() && n <= 32 && (gen == GEN_PHILOX || gen == GEN_F32N || (gen == GEN_EXTERNAL && n == 16));
+    int rc = MC_OK;
+    if (gen == GEN_XORWOW || (gen == GEN_EXTERNAL && !tiled_ok) || (gen == GEN_F32N && !tiled_ok)) {
+        // one path per lane, normals in the lane's LDS column, any n
+        rc = with_anti_gen<GEN_XORWOW | GEN_EXTERNAL | (sizeof(Real) == 8 ? GEN_F32N : 0)>(anti, gen, [&](auto a, auto tag) {
+            kernel = basket_dyn_kernel<Real, decltype(a)::value, typename decltype(tag)::type>;
+        });
     } else if constexpr (sizeof(Real) == 4) {
         pairs = true;
-        if (n >= 13 && n >= basket_tiled_min() && n <= 32) {  // normals in registers, no dynamic LDS
+        if (n >= 13 && tiled_ok) {  // normals in registers, no dynamic LDS
             lds = 0;
             switch (n <= 14 ? n : np) {  // 13, 14: own kernels; 15..32: one per multiple of 4 (zero-padded buffer)
-#define MC_CASE(NA) case NA: kernel = c->antithetic ? basket_tiled_f32_kernel<NA, true> : basket_tiled_f32_kernel<NA, false>; break;
+#define MC_CASE(NA) case NA: kernel = anti ? basket_tiled_f32_kernel<NA, true> : basket_tiled_f32_kernel<NA, false>; break;
                 MC_CASE(13) MC_CASE(14) MC_CASE(16) MC_CASE(20) MC_CASE(24) MC_CASE(28) MC_CASE(32)
 #undef MC_CASE
             }
+            if (gen == GEN_EXTERNAL)
+                kernel = anti ? nullptr : basket_tiled_f32_kernel<16, false, GenExternal>;
         } else {
-            kernel = c->antithetic ? basket_dyn_f32_kernel<true> : basket_dyn_f32_kernel<false>;
+            kernel = anti ? basket_dyn_f32_kernel<true> : basket_dyn_f32_kernel<false>;
             lds *= 2;  // the lane's column holds packed pairs
         }
-    } else if (sizeof(Real) == 8 && with_a4 && basket_mfma()) {  // fp64, 13..16 assets: the mat-vec on the matrix cores
+    } else if (with_a4 && basket_mfma() && gen == GEN_PHILOX) {  // fp64, 13..16 assets: the mat-vec on the matrix cores
         lds = 0;
         if constexpr (sizeof(Real) == 8)
-            kernel = c->antithetic ? basket_mfma_f64_kernel<true> : basket_mfma_f64_kernel<false>;
-    } else if (sizeof(Real) == 8 && n >= basket_tiled_min() && n <= 32) {  // fp64: normals in registers, no dynamic LDS
+            kernel = anti ? basket_mfma_f64_kernel<true> : basket_mfma_f64_kernel<false>;
+    } else if (tiled_ok) {  // fp64: normals in registers, no dynamic LDS
         lds = 0;
         // 9..16 assets: one kernel per size; 17..32: one per multiple of 4 (the buffer is zero-padded to whole tiles,
         // padded rows carry coef = 0 and padded columns multiply real normals by 0)
-        switch (n <= 16 ? n : np) {
-#define MC_CASE(NA) case NA: kernel = c->antithetic ? basket_tiled_kernel<Real, NA, true> : basket_tiled_kernel<Real, NA, false>; break;
-            MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
-            MC_CASE(20) MC_CASE(24) MC_CASE(28) MC_CASE(32)
+        if constexpr (sizeof(Real) == 8) {
+            switch (n <= 16 ? n : np) {
+#define MC_CASE(NA)                                                                                                               \
+    case NA:                                                                                                                      \
+        kernel = gen == GEN_F32N ? (anti ? basket_tiled_kernel<double, NA, true, GenPhiloxF32N> : basket_tiled_kernel<double, NA, false, GenPhiloxF32N>) \
+                                 : (anti ? basket_tiled_kernel<double, NA, true> : basket_tiled_kernel<double, NA, false>);       \
+        break;
+                MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
+                MC_CASE(20) MC_CASE(24) MC_CASE(28) MC_CASE(32)
 #undef MC_CASE
+            }
+            if (gen == GEN_EXTERNAL)
+                kernel = anti ? nullptr : basket_tiled_kernel<double, 16, false, GenExternal>;
         }
+    } else {
+        kernel = anti ? basket_dyn_kernel<Real, true> : basket_dyn_kernel<Real, false>;
     }
+    if (rc) return rc;
+    if (!kernel)
+        return fail(MC_ERR_UNSUPPORTED, "basket: no kernel for this generator / estimator / size combination");
     if (lds)
         HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int total = 0, slot = 0;
@@ -1246,9 +1353,7 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     Tail tail = make_tail(c, total, 1.0, 1.0, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
-        Work w = make_work(seed, s, 0, 0);
-        if (xorwow)
-            w.xorwow = c->d_xorwow;
+        const Work w = context_work(c, seed, s, 0, 0);
         const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
         tail.slot_base = tail.ticket_base = (uint32_t)slot;
         launch_sim_lds(prof, kernel, g, lds, st, tail, k, w, out ? out + done : (Real *)nullptr);
@@ -1273,12 +1378,22 @@ static int basket_enqueue(mc_context *c, const typename BasketIn<Real>::type *o,
     if (int rc = plan_segments(first, n, segs)) return rc;
     int rc = MC_OK;
     ProfileScope prof(c);
-    if (c->rng == MC_RNG_XORWOW) {   // the generic kernel is the one compiled for both generators
+    if (c->ext && (segs.size() > 1 || first != 0))
+        return fail(MC_ERR_INVALID, "external normals: one segment starting at path 0");
+    if (c->rng == MC_RNG_XORWOW && !c->ext) {   // the generic kernel is the one compiled for both generators
+        if (sizeof(Real) == 8 && c->normals_f32)
+            return fail(MC_ERR_UNSUPPORTED, "fp32 normals in the fp64 kernels are implemented for the Philox generator");
         if (int rc2 = xorwow_one_segment(segs)) return rc2;
         if (int rc2 = xorwow_ready(c, seed, st)) return rc2;
         return basket_launch_dyn<Real>(c, prof, *o, seed, segs, st, out, n, d_triple);
     }
-    switch (o->n <= basket_static_max<Real>() ? o->n : 0) {
+    // kernel-argument / LDS-staged kernels up to the static limit; the policies beyond Philox exist for some sizes only
+    int static_max = basket_static_max<Real>();
+    if (sizeof(Real) == 8 && c->normals_f32 && static_max > 8)
+        static_max = 8;
+    if (c->ext)
+        static_max = (o->n == 3 || o->n == 4) ? o->n : 0;
+    switch (o->n <= static_max ? o->n : 0) {
 #define MC_CASE(NA) case NA: rc = basket_launch_n<Real, NA>(c, prof, *o, seed, segs, st, out, n, d_triple); break;
         MC_CASE(1) MC_CASE(2) MC_CASE(3) MC_CASE(4) MC_CASE(5) MC_CASE(6) MC_CASE(7) MC_CASE(8)
         MC_CASE(9) MC_CASE(10) MC_CASE(11) MC_CASE(12) MC_CASE(13) MC_CASE(14) MC_CASE(15) MC_CASE(16)
@@ -1300,8 +1415,11 @@ template <> struct CvaIn<double> { using type = mc_cva_f64; };
 // Per-date table, fp64 on the host, rounded once to Real.  Residual maturities follow the
 // reference's rule: t -= dt in Real arithmetic, dates with t < 0 contribute nothing
 // (dp/MonteCarloKernel.cu:234,249-256).
+// lag = 1 (bridge tests only, MC_FROM_NORMALS_HOST_ORDER): the reference CPU loop's ordering -- the exposure of date j
+// is priced at the spot of date j - 1 (dp/MonteCarloHost.c:254-261); the caller then feeds the kernel the
+// path's normals delayed by one date, so that its running sum W is the lagged one.
 template <class Real>
-static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaStep<Real>> &tab, std::vector<Real> &extra,
+static int build_cva_table(const typename CvaIn<Real>::type &v, int lag, std::vector<CvaStep<Real>> &tab, std::vector<Real> &extra,
                            CvaArgs<Real> &args)
 {
     const auto &o = v.option;
@@ -1331,7 +1449,7 @@ static int build_cva_table(const typename CvaIn<Real>::type &v, std::vector<CvaS
         const double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
         CvaStep<Real> s;
         s.dp = (Real)(-std::exp(-lam * t_prev) * std::expm1(-lam * (t_now - t_prev)));
-        const double ln_sj = ln_s0 + (double)j * (double)step_drift;  // + step_vol * W_j on the device
+        const double ln_sj = ln_s0 + (double)(j - lag) * (double)step_drift;  // + step_vol * W_j on the device
         s.xk = (Real)(ln_sj * sc);
         if (tau > 0) {
             const double sig = (double)o.v * std::sqrt(tau);
@@ -1368,9 +1486,10 @@ template <class Real>
 static int cva_table_ready(mc_context *c, const typename CvaIn<Real>::type *v, hipStream_t st, CvaArgs<Real> &args)
 {
     // the table depends only on the inputs: rebuild and re-upload only when they change
-    const double key_vals[9] = {(double)v->defint, (double)v->lgd, (double)v->option.s, (double)v->option.k,
-                                (double)v->option.r, (double)v->option.v, (double)v->option.t,
-                                (double)v->n_grid, (double)sizeof(Real)};
+    const int lag = (c->ext && (c->ext_flags & MC_FROM_NORMALS_HOST_ORDER)) ? 1 : 0;
+    const double key_vals[10] = {(double)v->defint, (double)v->lgd, (double)v->option.s, (double)v->option.k,
+                                 (double)v->option.r, (double)v->option.v, (double)v->option.t,
+                                 (double)v->n_grid, (double)sizeof(Real), (double)lag};
     std::vector<char> key(sizeof key_vals);
     memcpy(key.data(), key_vals, sizeof key_vals);
     if (key == c->table_key && c->cva_args.size() == sizeof args) {   // same inputs as the table in HBM: nothing to rebuild
@@ -1379,7 +1498,7 @@ static int cva_table_ready(mc_context *c, const typename CvaIn<Real>::type *v, h
     }
     static thread_local std::vector<CvaStep<Real>> tab;
     static thread_local std::vector<Real> extra, blob;
-    if (int rc = build_cva_table<Real>(*v, tab, extra, args)) return rc;
+    if (int rc = build_cva_table<Real>(*v, lag, tab, extra, args)) return rc;
     // one blob: the per-date rows | fp32 only: the rows of date pairs, field by field | the Greeks kernel's extra columns
     const size_t step_reals = tab.size() * (sizeof(CvaStep<Real>) / sizeof(Real));
     const size_t pair_reals = sizeof(Real) == 4 ? (size_t)12 * (args.n_bs / 2) : 0;
@@ -1421,25 +1540,24 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     Tail t = make_tail(c, total, 1.0, 1.0, n, d_triple);
     uint64_t done = 0;
     ProfileScope prof(c);
-    const bool xorwow = c->rng == MC_RNG_XORWOW;
-    if (xorwow) {
+    if (c->ext && (segs.size() > 1 || first != 0))
+        return fail(MC_ERR_INVALID, "external normals: one segment starting at path 0");
+    if (c->rng == MC_RNG_XORWOW && !c->ext) {
+        if (sizeof(Real) == 8 && c->normals_f32)
+            return fail(MC_ERR_UNSUPPORTED, "fp32 normals in the fp64 kernels are implemented for the Philox generator");
         if (int rc = xorwow_one_segment(segs)) return rc;
         if (int rc = xorwow_ready(c, seed, st)) return rc;
     }
     for (const Segment &s : segs) {
-        Work w = make_work(seed, s, 0, 0);
+        const Work w = context_work(c, seed, s, 0, 0);
         const int g = grid_for(c, s.count);
         t.slot_base = t.ticket_base = (uint32_t)slot;
-        if (xorwow) {
-            w.xorwow = c->d_xorwow;
-            if (c->antithetic)
-                launch_sim(prof, cva_kernel<Real, true, GenXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
-            else
-                launch_sim(prof, cva_kernel<Real, false, GenXorwow>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
-        } else if (c->antithetic)
-            launch_sim(prof, cva_kernel<Real, true>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
-        else
-            launch_sim(prof, cva_kernel<Real, false>, g, st, t, args, w, out ? out + done : (Real *)nullptr);
+        Real *dst = out ? out + done : (Real *)nullptr;
+        constexpr unsigned ALLOW = GEN_PHILOX | GEN_XORWOW | GEN_EXTERNAL | (sizeof(Real) == 8 ? GEN_F32N : 0);
+        if (int rc = with_anti_gen<ALLOW>(c->antithetic, gen_of(c, w, sizeof(Real)), [&](auto a, auto tag) {
+                launch_sim(prof, cva_kernel<Real, decltype(a)::value, typename decltype(tag)::type>, g, st, t, args, w, dst);
+            }))
+            return rc;
         slot += g;
         done += s.count;
     }
@@ -1632,6 +1750,92 @@ static int dump_sync(mc_context *c, uint64_t n, Real *h_out, Enq enqueue)
     return MC_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Test hooks: the simulation kernels on a caller-supplied normal stream (include/mc_mi355x.h "test hooks")
+// ---------------------------------------------------------------------------------------
+// Uploads the normals into the context's buffer (zero-padded to `padded` Reals), runs `enqueue` with the external-normals
+// policy switched on, synchronously, and -- when h_values is given -- once more through the per-path dump path.
+template <class Real, class Enq>
+static int from_normals_run(mc_context *c, const Real *h_normals, size_t count, size_t padded, uint32_t per_unit, int flags,
+                            uint64_t n, double discount, Real *h_values, mc_result *out, Enq enqueue)
+{
+    if (!h_normals)
+        return fail(MC_ERR_INVALID, "NULL normals");
+    if (n > MAX_DUMP_PATHS || padded > (size_t)1 << 31)
+        return fail(MC_ERR_INVALID, "from_normals: at most 2^26 paths and 2^31 normals");
+    if (c->antithetic || c->control || c->rng != MC_RNG_PHILOX || c->normals_f32)
+        return fail(MC_ERR_UNSUPPORTED, "from_normals: plain estimator with the context's default settings only");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bytes = padded * sizeof(Real);
+    if (c->d_ext_bytes < bytes) {
+        if (int rc = quiesce(c)) return rc;
+        if (c->d_ext) HIPCHK(hipFree(c->d_ext));
+        c->d_ext = nullptr, c->d_ext_bytes = 0;
+        HIPCHK(hipMalloc(&c->d_ext, bytes));
+        c->d_ext_bytes = bytes;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));   // a previous call's kernels may still read the buffer
+    if (padded > count)
+        HIPCHK(hipMemsetAsync(c->d_ext, 0, bytes, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_ext, h_normals, count * sizeof(Real), hipMemcpyHostToDevice, c->stream));
+    c->ext = c->d_ext, c->ext_per_unit = per_unit, c->ext_flags = flags;
+    int rc = run_sync(c, n, discount, out, [&](hipStream_t st, double *t) { return enqueue(st, t, (Real *)nullptr); });
+    if (rc == MC_OK && h_values)
+        rc = dump_sync<Real>(c, n, h_values, [&](hipStream_t st, double *t, Real *d) { return enqueue(st, t, d); });
+    c->ext = nullptr, c->ext_per_unit = 0, c->ext_flags = 0;
+    c->table_key.clear();   // a table built under the test switches must not be reused by a pricing call
+    return rc;
+}
+
+#define MC_DEFINE_FROM_NORMALS(X, Real)                                                                       \
+    extern "C" int mc_vanilla_from_normals_##X(mc_context *c, const mc_option_##X *o, const Real *h_normals,  \
+                                               uint64_t n, Real *h_values, mc_result *out)                    \
+    {                                                                                                         \
+        if (int rc = check_common(c, o, 0, n, out)) return rc;                                                \
+        const uint64_t NPB = GenPhilox::npb<Real>(), units = (n + NPB - 1) / NPB;                             \
+        return from_normals_run<Real>(c, h_normals, n, units * NPB, (uint32_t)NPB, 0, n,                      \
+                                      std::exp(-(double)o->r * (double)o->t), h_values, out,                  \
+                                      [&](hipStream_t st, double *t, Real *d) {                               \
+                                          return vanilla_enqueue<Real>(c, o, 0, 0, n, t, st, d);              \
+                                      });                                                                     \
+    }                                                                                                         \
+    extern "C" int mc_basket_from_normals_##X(mc_context *c, const mc_basket_##X *o, const Real *h_normals,   \
+                                              uint64_t n, int flags, Real *h_values, mc_result *out)          \
+    {                                                                                                         \
+        if (int rc = check_common(c, o, 0, n, out)) return rc;                                                \
+        if (o->n < 1 || o->n > MC_MAX_ASSETS_GENERIC) return fail(MC_ERR_INVALID, "basket: bad n");           \
+        /* the two-paths-per-lane kernels read the pair's second unit even where it does not exist: pad */    \
+        const size_t count = (size_t)n * (size_t)o->n;                                                        \
+        return from_normals_run<Real>(c, h_normals, count, count + (size_t)o->n, (uint32_t)o->n,              \
+                                      flags & MC_FROM_NORMALS_NO_VOL, n, std::exp(-(double)o->r * (double)o->t), \
+                                      h_values, out, [&](hipStream_t st, double *t, Real *d) {                \
+                                          return basket_enqueue<Real>(c, o, 0, 0, n, t, st, d);               \
+                                      });                                                                     \
+    }                                                                                                         \
+    extern "C" int mc_cva_from_normals_##X(mc_context *c, const mc_cva_##X *o, const Real *h_normals,         \
+                                           uint64_t n, int flags, Real *h_values, mc_result *out)             \
+    {                                                                                                         \
+        if (int rc = check_common(c, o, 0, n, out)) return rc;                                                \
+        if (o->n_grid < 1 || o->n_grid > (1 << 20)) return fail(MC_ERR_INVALID, "cva: bad n_grid");           \
+        const size_t g = (size_t)o->n_grid, count = (size_t)n * g;                                            \
+        const Real *src = h_normals;                                                                          \
+        std::vector<Real> delayed;                                                                            \
+        if (flags & MC_FROM_NORMALS_HOST_ORDER) { /* date j sees the normals of dates 1 .. j-1 */             \
+            if (!h_normals) return fail(MC_ERR_INVALID, "NULL normals");                                      \
+            delayed.resize(count);                                                                            \
+            for (uint64_t i = 0; i < n; ++i) {                                                                \
+                delayed[i * g] = 0;                                                                           \
+                for (size_t j = 1; j < g; ++j)                                                                \
+                    delayed[i * g + j] = h_normals[i * g + j - 1];                                            \
+            }                                                                                                 \
+            src = delayed.data();                                                                             \
+        }                                                                                                     \
+        return from_normals_run<Real>(c, src, count, count, (uint32_t)o->n_grid, flags & MC_FROM_NORMALS_HOST_ORDER, \
+                                      n, 1.0, h_values, out, [&](hipStream_t st, double *t, Real *d) {        \
+                                          return cva_enqueue<Real>(c, o, 0, 0, n, t, st, d);                  \
+                                      });                                                                     \
+    }
+
 #define MC_DEFINE_PRODUCT(X, Real)                                                                           \
     extern "C" int mc_vanilla_launch_##X(mc_context *c, const mc_option_##X *o, uint64_t seed, uint64_t first, \
                                          uint64_t n, double *d_triple, void *stream)                         \
@@ -1711,14 +1915,17 @@ static int dump_sync(mc_context *c, uint64_t n, Real *h_out, Enq enqueue)
                                   uint64_t n_units, uint32_t block, Real *h_out)                             \
     {                                                                                                        \
         if (int rc = check_common(c, h_out, first_unit, n_units, h_out)) return rc;                          \
-        constexpr uint64_t NPB = GenPhilox::npb<Real>();                                                           \
+        const uint64_t NPB = npb_of<Real>(c);                                                                \
         return dump_sync<Real>(c, n_units * NPB, h_out, [&](hipStream_t st, double *, Real *d) -> int {      \
             std::vector<Segment> segs;                                                                       \
             if (int rc = plan_segments(first_unit, n_units, segs)) return rc;                                \
             uint64_t done = 0;                                                                               \
             for (const Segment &s : segs) {                                                                  \
                 const Work w = make_work(seed, s, 0, 0);                                                     \
-                normals_kernel<Real><<<grid_for(c, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
+                if (sizeof(Real) == 8 && c->normals_f32)                                                     \
+                    normals_kernel<Real, GenPhiloxF32N><<<grid_for(c, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
+                else                                                                                         \
+                    normals_kernel<Real><<<grid_for(c, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
                 done += s.count;                                                                             \
             }                                                                                                \
             HIPCHK(hipGetLastError());                                                                       \
@@ -1728,3 +1935,5 @@ static int dump_sync(mc_context *c, uint64_t n, Real *h_out, Enq enqueue)
 
 MC_DEFINE_PRODUCT(f32, float)
 MC_DEFINE_PRODUCT(f64, double)
+MC_DEFINE_FROM_NORMALS(f32, float)
+MC_DEFINE_FROM_NORMALS(f64, double)

@@ -171,6 +171,12 @@ class Engine:
         """'philox' (default; counter-based) or 'xorwow' (the reference's generator, one sequence per lane)."""
         check(lib().mc_context_set_generator(self._ctx, {"philox": 0, "xorwow": 1}[name], subsequence_base))
 
+    def set_normals(self, mode: str):
+        """fp64 kernels: 'native' (default; true fp64 normals) or 'f32' (the reference's dp arithmetic: a float normal
+        widened to double, four per Philox block)."""
+        check(lib().mc_context_set_normals(self._ctx, {"native": 0, "f32": 1}[mode]))
+        self._normals_f32 = mode == "f32"
+
     def xorwow_words(self, seed, first_subsequence, n_subsequences, words_each):
         out = np.empty((n_subsequences, words_each), dtype=np.uint32)
         check(lib().mc_xorwow_words(self._ctx, seed, first_subsequence, n_subsequences, words_each,
@@ -268,10 +274,42 @@ class Engine:
         return self._paths("cva", precision, _as_cva(precision, c), seed, first_path, n_paths)
 
     def normals(self, seed, domain, first_unit, n_units, block=0, precision="f64"):
-        out = np.empty(n_units * _lib.NPB[precision], dtype=NP[precision])
+        npb = 4 if (precision == "f32" or getattr(self, "_normals_f32", False)) else 2
+        out = np.empty(n_units * npb, dtype=NP[precision])
         check(getattr(lib(), f"mc_normals_{precision}")(self._ctx, seed, domain, first_unit, n_units, block,
                                                          out.ctypes.data_as(C.POINTER(_lib.CT[precision]))))
-        return out.reshape(n_units, _lib.NPB[precision])
+        return out.reshape(n_units, npb)
+
+    # ---- test hooks: the simulation kernels on a caller-supplied normal stream -----------------------
+    def _from_normals(self, prod, X, struct, normals, n_paths, flags, want_values):
+        z = np.ascontiguousarray(normals, dtype=NP[X]).reshape(-1)
+        P = C.POINTER(_lib.CT[X])
+        vals = np.empty(n_paths, dtype=NP[X]) if want_values else None
+        r = _lib.Result()
+        f = getattr(lib(), f"mc_{prod}_from_normals_{X}")
+        args = [self._ctx, C.byref(struct), z.ctypes.data_as(P), n_paths]
+        if prod != "vanilla":
+            args.append(flags)
+        args += [vals.ctypes.data_as(P) if want_values else None, C.byref(r)]
+        check(f(*args))
+        return _estimate(r), vals
+
+    def vanilla_from_normals(self, opt, normals, precision="f64", want_values=True):
+        """(Estimate, per-path payoffs): the vanilla hot kernel with normals[i] as path i's normal."""
+        z = np.asarray(normals).reshape(-1)
+        return self._from_normals("vanilla", precision, _as_option(precision, opt), z, len(z), 0, want_values)
+
+    def basket_from_normals(self, b, normals, precision="f64", no_vol=False, want_values=True):
+        """normals[i, a]: path i, asset a, in drawing order.  no_vol: the reference dp CPU path's model (goldens only)."""
+        h = _BasketHolder(precision, b)
+        z = np.asarray(normals).reshape(-1, h.n)
+        return self._from_normals("basket", precision, h.struct, z, z.shape[0], _lib.FROM_NORMALS_NO_VOL if no_vol else 0, want_values)
+
+    def cva_from_normals(self, c, normals, precision="f64", host_order=False, want_values=True):
+        """normals[i, j - 1]: path i, date j.  host_order: the reference CPU loop's lagged exposure (goldens only)."""
+        st = _as_cva(precision, c)
+        z = np.asarray(normals).reshape(-1, st.n_grid)
+        return self._from_normals("cva", precision, st, z, z.shape[0], _lib.FROM_NORMALS_HOST_ORDER if host_order else 0, want_values)
 
 
 # ---- host helpers (no GPU needed) -----------------------------------------------------------
