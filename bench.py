@@ -67,7 +67,27 @@ def workloads(mc):
         "basket16_f64": ("basket", "f64", lambda: basket_inputs(mc, 16, "f64"), 125 * 10 ** 6, f_basket(16), "Basket call, 16 correlated assets, 1e9/8 paths per GPU, fp64 (BASELINE configs[3])"),
         "cva256_f64": ("cva", "f64", CVA, 1250000, 60.0 * 256 + 5, "CVA on vanilla call, 256 dates x 1e7/8 paths per GPU, fp64 (BASELINE configs[4])"),
         "cva256_f32": ("cva", "f32", CVA, 1250000, 60.0 * 256 + 5, "CVA on vanilla call, 256 dates x 1e7/8 paths per GPU, fp32"),
+        # the fp64 kernels on fp32 normals widened to double -- the reference's own dp arithmetic (dp/MonteCarloKernel.cu:68,78,250),
+        # opt-in: mc_context_set_normals(ctx, MC_NORMALS_F32).  Normal generation counts 6.5 flop per normal either way.
+        "vanilla_f64_n32": ("vanilla", "f64", VAN, 10 ** 8, 15.5, "European vanilla call, 1e8 paths, fp64 on fp32 normals (reference dp arithmetic)"),
+        "basket16_f64_n32": ("basket", "f64", lambda: basket_inputs(mc, 16, "f64"), 125 * 10 ** 6, f_basket(16), "Basket call, 16 assets, 1e9/8 paths per GPU, fp64 on fp32 normals (reference dp arithmetic)"),
+        "cva256_f64_n32": ("cva", "f64", CVA, 1250000, 60.0 * 256 + 5, "CVA, 256 dates x 1e7/8 paths per GPU, fp64 on fp32 normals (reference dp arithmetic)"),
     }
+
+
+def workload_settings(name):
+    """Engine settings a workload runs under (besides the defaults)."""
+    return {"normals": "f32"} if name.endswith("_n32") else {}
+
+
+def kernel_sources_sha256():
+    """Stamp of the device code the committed PMC counts were taken from: sha256 over the kernel headers, in this order
+    (tools/summarize_pmc.py writes it into profiles/pmc_traffic.json, bench.py compares)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mc_kernels.hpp", "mc_rng.hpp", "mc_math_f64.hpp", "mc_reduce.hpp"):
+        h.update(open(os.path.join(ROOT, "montecarlocuda_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
 
 
 def kernel_name(prod, X, inputs):
@@ -263,6 +283,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--regions", type=int, default=5,
+                    help="the K-step timed region is repeated this many times back to back (fresh path ranges each time, one "
+                         "pre-heat before the first); ms_per_step and value are the MEDIAN region's, min and max are reported: a "
+                         "20-step region is 1 ms, one sample of it moves by +-4 % between runs")
     ap.add_argument("--workload", default="vanilla_f32")
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
@@ -324,15 +348,18 @@ def main():
     torch.cuda.set_device(local)
     grouped = dist.is_initialized()   # one process per GPU under torch.distributed.run (RCCL), also for N=1
     engines = [mc.Engine(local, args.blocks) for _ in range(max(1, args.streams))]
+    settings = workload_settings(args.workload)
     for e_ in engines:
         e_.set_finish(args.finish == "fused")
+        if "normals" in settings:
+            e_.set_normals(settings["normals"])
     eng = engines[0]
     prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
     if callable(inputs):
         inputs = inputs()
     if args.paths:
         paths = args.paths
-    K, W = args.steps, args.warmup
+    K, W, R = args.steps, args.warmup, max(1, args.regions)
     struct, keep = eng.prepared(prod, X, inputs)
     seed = mc.MC_DEFAULT_SEED
     # Launch streams: each context's own non-blocking stream (raw hipStream_t handles; torch never sees them) or
@@ -347,7 +374,7 @@ def main():
         launch_streams = [s_.cuda_stream for s_ in pool]
     assert all(h != 0 for h in launch_streams) and stream.cuda_stream != 0
     structs = [e.prepared(prod, X, inputs) for e in engines]
-    triples = torch.zeros((K + W, 3), dtype=torch.float64, device="cuda")
+    triples = torch.zeros((W + R * K, 3), dtype=torch.float64, device="cuda")
     works = []
 
     pending = [0, 0]   # [first step not yet all-reduced, one past the last launched step]
@@ -428,29 +455,38 @@ def main():
     for i in range(W):
         step(i)
     drain()
-    eng.profile(1 if K < 100 else args.profile_every)   # short runs: every launch of the first context is sampled
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(W, W + K):
-        step(i)
-    t_enqueued = time.perf_counter()
-    drain(host_sync=not grouped)   # N > 1: RCCL's barrier queues right behind the last bucket's all-reduce
-    t_drained = time.perf_counter()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    for w in works:          # complete since the barrier (same RCCL stream, earlier in order): orders torch's stream, costs nothing
-        w.wait()
-    works.clear()
-    host_side = {"enqueue_K_steps_ms": (t_enqueued - t0) * 1e3, "drain_ms": (t_drained - t_enqueued) * 1e3,
-                 "closing_barrier_ms": (t0 + elapsed - t_drained) * 1e3,
-                 "what": "host wall-clock inside the timed region of this rank: launching the K steps (asynchronous), the last bucket's "
-                         "all-reduce + waits, the closing barrier + synchronize"}
+    eng.profile(1 if R * K < 100 else args.profile_every)   # short runs: every launch of the first context is sampled
+    # R timed regions of exactly K steps each, back to back: barrier + synchronize, K steps, drain, barrier + synchronize,
+    # MAX over ranks -- the contract's bracket, repeated.  ms_per_step / value come from the MEDIAN region.
+    region_s, host_sides = [], []
+    for r_ in range(R):
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(W + r_ * K, W + (r_ + 1) * K):
+            step(i)
+        t_enqueued = time.perf_counter()
+        drain(host_sync=not grouped)   # N > 1: RCCL's barrier queues right behind the last bucket's all-reduce
+        t_drained = time.perf_counter()
+        barrier()
+        el = time.perf_counter() - t0
+        for w in works:          # complete since the barrier (same RCCL stream, earlier in order): orders torch's stream, costs nothing
+            w.wait()
+        works.clear()
+        host_sides.append({"enqueue_K_steps_ms": (t_enqueued - t0) * 1e3, "drain_ms": (t_drained - t_enqueued) * 1e3,
+                           "closing_barrier_ms": (t0 + el - t_drained) * 1e3})
+        region_s.append(el)
     samples, kernel_ms_total = eng.profile_read()
     eng.profile(0)
     if grouped:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        t = torch.tensor(region_s, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        region_s = [float(x) for x in t.tolist()]
+    order = sorted(range(R), key=lambda i_: region_s[i_])
+    median_region = order[(R - 1) // 2]
+    elapsed = region_s[median_region]
+    host_side = dict(host_sides[median_region],
+                     what="host wall-clock inside the median timed region of this rank: launching the K steps (asynchronous), the last "
+                          "bucket's all-reduce + waits, the closing barrier + synchronize")
 
     # The dominant kernel alone on the device (outside the timed region): with 2 streams the timed launches
     # overlap their neighbours, which stretches every per-kernel duration.
@@ -460,7 +496,7 @@ def main():
         solo = torch.zeros((n_ex, 3), dtype=torch.float64, device="cuda")
         eng.profile(1)
         for i in range(n_ex):
-            eng.launch(prod, X, structs[0][0], seed, (W + K + i) * step_total + shard_first, shard_count, solo[i].data_ptr(),
+            eng.launch(prod, X, structs[0][0], seed, (W + R * K + i) * step_total + shard_first, shard_count, solo[i].data_ptr(),
                        launch_streams[0])
         torch.cuda.synchronize()
         ex_samples, ex_ms = eng.profile_read()
@@ -516,7 +552,7 @@ def main():
             r, t_ = float(np.float32(r)), float(np.float32(t_))
         disc = 1.0 if prod == "cva" else math.exp(-r * t_)
         price, ci = mc.closing(tot[0], tot[1], int(tot[2]), disc)
-        assert int(tot[2]) == K * step_total, (tot[2], K * step_total)
+        assert int(tot[2]) == R * K * step_total, (tot[2], R * K * step_total)
         units_per_step = step_total
         value = units_per_step * K / elapsed
         # ---- roofline of the dominant kernel (the simulation kernel) -------------------------------------------
@@ -539,19 +575,25 @@ def main():
                 committed = json.load(open(pmc)).get(args.workload, {})
             except Exception:
                 committed = {}
+        # the committed counts describe the kernels they were taken from: stale once the kernel headers change
+        traffic_stale = bool(committed) and committed.get("kernel_sources_sha256") != kernel_sources_sha256()
         out = {
             "metric": "Monte Carlo paths/sec", "value": value, "unit": "paths/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": X, "data": "synthetic", "timed_region_s": elapsed, "timed_region_host": host_side,
+            "regions": R, "ms_per_step_min": min(region_s) / K * 1e3, "ms_per_step_max": max(region_s) / K * 1e3,
+            "region_ms_per_step": [x / K * 1e3 for x in region_s],
+            "region_note": "R back-to-back timed regions of exactly K steps each (barrier + synchronize on both sides, max over ranks); "
+                           "ms_per_step, value and timed_region_s are the median region's",
             "config": {"workload": desc, "paths_per_gpu_per_step": shard_count, "global_paths_per_step": units_per_step,
                        "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
                        "grid": f"{eng.blocks}x256", "streams": len(engines), "stream_source": args.stream_source,
-                       "finish": args.finish, "preheat_ms": round(preheat_ms, 1)},
+                       "finish": args.finish, "preheat_ms": round(preheat_ms, 1), **({"engine_settings": settings} if settings else {})},
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
             "roofline": {"bound": "valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": (ach / peak) if ach else None,
-                         "traffic": committed.get("hbm_bytes_per_launch"),
+                         "traffic": committed.get("hbm_bytes_per_launch"), "traffic_stale": traffic_stale,
                          "hbm_gbps": (committed["hbm_bytes_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
                                       / kernel_s / 1e9) if committed.get("hbm_bytes_per_launch") and kernel_s else None,
                          "hbm_frac_of_8TBps": (committed["hbm_bytes_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
@@ -576,7 +618,10 @@ def main():
         # committed PMC instruction counts of this kernel (wave-instructions per launch: all VALU, fp32 transcendentals,
         # fp64 rcp/sqrt) and the issue costs tools/ubench measured on MI355X: 4.1 cycles per VALU instruction of a
         # wave64 next to multiplies, 8.1 per fp32 transcendental, 16.1 per v_rcp/sqrt_f64; 1024 SIMDs at 2.39 GHz.
-        if committed.get("valu_insts_per_launch") and kernel_s:
+        if traffic_stale:
+            out["roofline"]["traffic_stale_note"] = ("the kernel headers changed since profiles/pmc_traffic.json was collected "
+                                                     "(tools/collect_pmc.sh + tools/summarize_pmc.py): traffic is the old kernels', issue_frac is withheld")
+        if committed.get("valu_insts_per_launch") and kernel_s and not traffic_stale:
             v_all = committed["valu_insts_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
             t32 = committed.get("trans_f32_per_launch", 0.0) * shard_count / committed.get("paths_per_launch", shard_count)
             t64 = committed.get("trans_f64_per_launch", 0.0) * shard_count / committed.get("paths_per_launch", shard_count)

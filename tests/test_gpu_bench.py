@@ -36,7 +36,10 @@ def test_bench_contract_single_gpu():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 40 and d["warmup"] == 4 and d["unit"] == "paths/s" and d["dtype"] == "f32"
     assert d["vs_baseline"] is None and d["higher_is_better"] is True and d["scaling"] == "weak" and "workload" in d["config"]
-    assert d["paths_priced"] == 40 * 10 ** 8 and d["value"] > 1e11
+    assert d["regions"] == 5 and d["paths_priced"] == 5 * 40 * 10 ** 8 and d["value"] > 1e11
+    # the reported step time is the median of the five regions
+    assert len(d["region_ms_per_step"]) == 5 and d["ms_per_step"] == sorted(d["region_ms_per_step"])[2]
+    assert d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
     assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]
     r = d["roofline"]
     assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3 and 0 < r["frac"] < 1
@@ -47,7 +50,11 @@ def test_bench_contract_single_gpu():
     assert 40 < r["avg_kernel_us"] < 70 and r["in_region"]["kernel_samples"] >= 8
     assert r["in_region"]["avg_kernel_us"] >= r["avg_kernel_us"] * 0.95
     assert 0 < r["effective"]["frac"] < 1 and d["timed_region_s"] == pytest.approx(d["ms_per_step"] * 40e-3, rel=1e-9)
-    assert "not measured in this run" in r["traffic_source"] and 0.5 < r["issue_frac"] < 1.1
+    assert "not measured in this run" in r["traffic_source"]
+    if r["traffic_stale"]:     # the kernel headers changed since the committed PMC passes: the instruction-count model is withheld
+        assert "issue_frac" not in r and "traffic_stale_note" in r
+    else:
+        assert 0.5 < r["issue_frac"] < 1.1
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 1e6
     assert abs(d["fp64"]["price"] - BS) < 0.05
@@ -69,11 +76,11 @@ def test_bench_contract_single_gpu():
 def test_bench_two_ranks_share_the_gpu(scaling):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling,
-           "--steps", "30", "--warmup", "3", "--cpu-seconds", "0", "--fp64-steps", "4", "--strong-reps", "2"]
+           "--steps", "30", "--warmup", "3", "--regions", "2", "--cpu-seconds", "0", "--fp64-steps", "4", "--strong-reps", "2"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _json_line(out.stdout)
-    total = 30 * 10 ** 8 * (2 if scaling == "weak" else 1)
+    total = 2 * 30 * 10 ** 8 * (2 if scaling == "weak" else 1)     # two regions of 30 steps
     assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["paths_priced"] == total
     assert d["config"]["paths_per_gpu_per_step"] == (10 ** 8 if scaling == "weak" else 5 * 10 ** 7)
     assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]      # every path counted exactly once across ranks
@@ -94,6 +101,6 @@ def test_bench_rccl_plumbing_world_of_one():
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0, out.stderr[-3000:]
     d = _json_line(out.stdout)
-    assert d["n_gpus"] == 1 and d["paths_priced"] == 60 * 10 ** 8
+    assert d["n_gpus"] == 1 and d["regions"] == 5 and d["paths_priced"] == 5 * 60 * 10 ** 8
     assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]
     assert d["value"] > 1e11

@@ -17,7 +17,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 w = sys.argv[1] if len(sys.argv) > 1 else "vanilla_f32"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 base = os.path.join(ROOT, "gpurun_out", f"pmc_{w}")
 acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
 files = []
@@ -66,6 +66,8 @@ if main and "FETCH_SIZE" in summary[main[0]]:
     d = json.load(open(j)) if os.path.exists(j) else {}
     keep = {k: v for k, v in d.get(w, {}).items() if k.startswith("valu_busy")}   # filled by tools/clock_probe.py runs
     paths = {"vanilla": 10 ** 8, "basket4": 10 ** 8, "basket16": 125 * 10 ** 6, "cva256": 1250000}[w.split("_")[0]]
+    sys.path.insert(0, ROOT)
+    from bench import kernel_sources_sha256   # the stamp bench.py compares: stale counts are flagged, not used
     d[w] = {"kernel": main[0], "fetch_bytes_raw": a["FETCH_SIZE"] * 1024, "write_bytes": a["WRITE_SIZE"] * 1024,
             "hbm_bytes_per_launch": 2 * a["FETCH_SIZE"] * 1024 + a["WRITE_SIZE"] * 1024,
             "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts wide reads at half); per simulation-kernel launch",
@@ -73,5 +75,5 @@ if main and "FETCH_SIZE" in summary[main[0]]:
             # wave-instructions per launch, for bench.py's issue-slot model (roofline.issue_frac)
             "paths_per_launch": paths, "valu_insts_per_launch": a.get("SQ_INSTS_VALU"),
             "trans_f32_per_launch": a.get("SQ_INSTS_VALU_TRANS_F32", 0.0), "trans_f64_per_launch": a.get("SQ_INSTS_VALU_TRANS_F64", 0.0),
-            "waves_per_launch": a.get("SQ_WAVES"), **keep}
+            "waves_per_launch": a.get("SQ_WAVES"), "kernel_sources_sha256": kernel_sources_sha256(), **keep}
     json.dump(d, open(j, "w"), indent=1)
