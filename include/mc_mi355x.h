@@ -202,6 +202,17 @@ int mc_cva_launch_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
  * a host synchronisation.  A no-op when `stream` is the stream of the last call. */
 int mc_context_order(mc_context *ctx, void *stream);
 
+/* Results of asynchronous launches straight into pinned host memory (what include/mc_multi.h reads its devices back with).
+ * mc_context_arm_direct: the NEXT mc_*_launch_* call on `ctx` also has its last workgroup store {sum, sum2, n} into a
+ * pinned, host-coherent slot the context owns -- n last, with system-scope release semantics.  *slot = the slot's host
+ * address; its word 2 is preset to -1 (n is never negative): poll `(*slot)[2] != -1` from user space, then read the
+ * three doubles.  No D2H copy command, no event, no sleeping synchronize; d_triple is still written.  One armed launch in
+ * flight per context; needs the fused final reduction (the default).
+ * mc_context_publish: enqueues on `stream` a one-lane kernel that copies the three doubles at d_src (device memory: e.g.
+ * the output of an all-reduce enqueued on that stream before it) into a second slot of the context, same protocol. */
+int mc_context_arm_direct(mc_context *ctx, const volatile double **slot);
+int mc_context_publish(mc_context *ctx, const double *d_src, void *stream, const volatile double **slot);
+
 /* 1 when everything `ctx` has enqueued has completed, 0 while some of it is pending, -1 on error (hipStreamQuery of the
  * stream of its last call): a host may poll this from user space instead of sleeping in a synchronize. */
 int mc_context_idle(mc_context *ctx);

@@ -75,7 +75,7 @@ CVA = {"f32": CvaF32, "f64": CvaF64}
 
 # every symbol include/mc_mi355x.h declares (tests/test_abi.py checks the .so exports them all)
 EXPORTS = ["mc_last_error", "mc_device_count", "mc_context_create", "mc_context_destroy", "mc_context_device",
-           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read", "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing", "mc_context_order", "mc_context_idle", "mc_context_set_generator", "mc_context_set_normals", "mc_xorwow_words", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
+           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read", "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing", "mc_context_order", "mc_context_idle", "mc_context_arm_direct", "mc_context_publish", "mc_context_set_generator", "mc_context_set_normals", "mc_xorwow_words", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
 for _x in ("f32", "f64"):
     for _p in ("vanilla", "basket", "cva"):
         EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]

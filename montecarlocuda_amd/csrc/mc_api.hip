@@ -61,9 +61,11 @@ struct mc_context {
     double *g_triples = nullptr;  // one triple per plane
     int g_planes = 0;
     double *h_triple = nullptr;   // pinned
-    double *h_direct = nullptr;   // pinned + host-coherent: the kernel writes the triple of a synchronous call straight here
+    double *h_direct = nullptr;   // pinned + host-coherent, 3 slots of 4 doubles: [0] the triple of a synchronous call, written by
+                                  // its last workgroup; [1] the same for an ARMED launch (mc_context_arm_direct); [2] mc_context_publish
     double *d_direct = nullptr;   // device address of h_direct
-    double *direct_target = nullptr;   // what the Tail of the call being enqueued carries (set by run_sync around its enqueue)
+    double *direct_target = nullptr;   // what the Tail of the call being enqueued carries (set around the enqueue)
+    bool armed = false;           // the next mc_*_launch_* delivers its triple to slot [1]
     bool timing = true;           // synchronous calls bracket their kernels with HIP events (mc_result.kernel_ms)
     void *d_out = nullptr;        // per-path dump buffer (tests), grown on demand
     size_t d_out_bytes = 0;
@@ -166,7 +168,7 @@ static int context_allocate(mc_context *c)
     HIPCHK(hipMemset(c->tickets, 0, sizeof(uint32_t) * TICKET_WORDS));
     HIPCHK(hipMalloc(&c->d_triple, 3 * sizeof(double)));
     HIPCHK(hipHostMalloc(&c->h_triple, 3 * sizeof(double), hipHostMallocDefault));
-    HIPCHK(hipHostMalloc(&c->h_direct, 4 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostMalloc(&c->h_direct, 12 * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void **)&c->d_direct, c->h_direct, 0));
     HIPCHK(hipEventCreate(&c->ev0));
     HIPCHK(hipEventCreate(&c->ev1));
@@ -530,6 +532,61 @@ extern "C" int mc_context_idle(mc_context *c)
     const hipError_t e = hipStreamQuery(c->last_stream);
     return e == hipSuccess ? 1 : (e == hipErrorNotReady ? 0 : -1);
 }
+
+// ---- results straight into pinned host memory for the asynchronous launch API (the multi-GPU library's read-back) ----
+static constexpr double DIRECT_SENTINEL = -1.0;   // n_paths is never negative
+
+// Arms the context: the NEXT mc_*_launch_* call also has its last workgroup store {sum, sum2, n} into a pinned,
+// host-coherent slot the context owns (n last, with system-scope release semantics).  *slot = its host address; word 2
+// is preset to -1, so a host thread polls `(*slot)[2] != -1` from user space and then reads the triple -- no D2H copy
+// command, no event, no sleeping synchronize.  One armed launch in flight per context.
+extern "C" int mc_context_arm_direct(mc_context *c, const volatile double **slot)
+{
+    if (!c || !slot)
+        return fail(MC_ERR_INVALID, "mc_context_arm_direct: bad argument");
+    if (!c->fused)
+        return fail(MC_ERR_UNSUPPORTED, "direct delivery needs the fused final reduction (MC_FINISH=kernel is set)");
+    volatile double *s = c->h_direct + 4;
+    s[2] = DIRECT_SENTINEL;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    c->armed = true;
+    *slot = s;
+    return MC_OK;
+}
+
+// Enqueues on `stream` a one-lane kernel that copies the three doubles at d_src (device memory, e.g. the output of an
+// all-reduce enqueued before it on that stream) into another pinned slot of the context, same protocol as above.
+extern "C" int mc_context_publish(mc_context *c, const double *d_src, void *stream, const volatile double **slot)
+{
+    if (!c || !d_src || !slot)
+        return fail(MC_ERR_INVALID, "mc_context_publish: bad argument");
+    HIPCHK(hipSetDevice(c->device));
+    volatile double *s = c->h_direct + 8;
+    s[2] = DIRECT_SENTINEL;
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    publish_kernel<<<1, 1, 0, (hipStream_t)stream>>>(d_src, c->d_direct + 8);
+    HIPCHK(hipGetLastError());
+    *slot = s;
+    return MC_OK;
+}
+
+// moves the armed state into the enqueue that follows (the launch entry points construct one)
+struct ArmScope {
+    mc_context *c;
+    bool on;
+    explicit ArmScope(mc_context *ctx) : c(ctx), on(ctx && ctx->armed)
+    {
+        if (on) {
+            c->direct_target = c->d_direct + 4;
+            c->armed = false;
+        }
+    }
+    ~ArmScope()
+    {
+        if (on)
+            c->direct_target = nullptr;
+    }
+};
 
 static int finish_call(mc_context *c, const Tail &t, int total, hipStream_t st)
 {
@@ -1676,8 +1733,6 @@ extern "C" int mc_cva_greeks_run_f64(mc_context *c, const mc_cva_f64 *v, uint64_
 //   timing off (mc_context_set_timing(ctx, 0); the legacy symbols unless MC_VERBOSE is set): the last workgroup of the
 //     call writes the triple straight into pinned host memory (Tail.host_triple) and this thread polls the n word from
 //     user space: no event records, no copy command, no sleeping wait.  kernel_ms is reported as 0.
-static constexpr double DIRECT_SENTINEL = -1.0;   // n_paths is never negative
-
 template <class Enq>
 static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, Enq enqueue)
 {
@@ -1693,7 +1748,7 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         const int rc = enqueue(c->stream, c->d_triple);
         c->direct_target = nullptr;
         if (rc) return rc;
-        // poll from user space for the first 2 ms (the calls that care about 20 us are shorter than that), then hand the
+        // poll from user space for the first 50 ms (the calls that care about 20 us are shorter than that), then hand the
         // core back and wait in the runtime (also the way out when a kernel failed and never writes)
         bool seen = false;
         for (uint32_t spin = 0;; ++spin) {
@@ -1701,7 +1756,7 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
                 seen = true;
                 break;
             }
-            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - wall0 > std::chrono::milliseconds(2))
+            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - wall0 > std::chrono::milliseconds(50))
                 break;
             __builtin_ia32_pause();
         }
@@ -1841,18 +1896,21 @@ static int from_normals_run(mc_context *c, const Real *h_normals, size_t count, 
                                          uint64_t n, double *d_triple, void *stream)                         \
     {                                                                                                        \
         if (int rc = check_common(c, o, first, n, d_triple)) return rc;                                      \
+        ArmScope arm(c);                                                                                     \
         return vanilla_enqueue<Real>(c, o, seed, first, n, d_triple, pick_stream(c, stream), nullptr);       \
     }                                                                                                        \
     extern "C" int mc_basket_launch_##X(mc_context *c, const mc_basket_##X *o, uint64_t seed, uint64_t first, \
                                         uint64_t n, double *d_triple, void *stream)                          \
     {                                                                                                        \
         if (int rc = check_common(c, o, first, n, d_triple)) return rc;                                      \
+        ArmScope arm(c);                                                                                     \
         return basket_enqueue<Real>(c, o, seed, first, n, d_triple, pick_stream(c, stream), nullptr);        \
     }                                                                                                        \
     extern "C" int mc_cva_launch_##X(mc_context *c, const mc_cva_##X *o, uint64_t seed, uint64_t first,      \
                                      uint64_t n, double *d_triple, void *stream)                             \
     {                                                                                                        \
         if (int rc = check_common(c, o, first, n, d_triple)) return rc;                                      \
+        ArmScope arm(c);                                                                                     \
         return cva_enqueue<Real>(c, o, seed, first, n, d_triple, pick_stream(c, stream), nullptr);           \
     }                                                                                                        \
     extern "C" int mc_vanilla_run_##X(mc_context *c, const mc_option_##X *o, uint64_t seed, uint64_t first,  \

@@ -5,8 +5,10 @@
 // reference has no counterpart: it is single-device, default stream, synchronous; the entry points
 // fanned out here are dp/MonteCarloKernel.cu:483 (basket), :500 (vanilla), :517 (CVA).
 //
-// Host-only translation unit: no device code.  Everything a call enqueues -- G launches, one grouped all-reduce,
-// G + 1 small read-backs -- is asynchronous; the calling thread then waits for the G streams.
+// Host-only translation unit: no device code.  Everything a call enqueues -- G launches, one grouped all-reduce, one
+// one-lane publish kernel -- is asynchronous; the results come back through pinned host memory that the devices write
+// themselves and the calling thread polls (run_sharded).  NOTE: the grouped all-reduce has only ever run with a
+// communicator of ONE rank (one-GPU test boxes; RCCL refuses a repeated device): the G > 1 collective is unexercised.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -68,6 +70,7 @@ struct mc_multi {
     int reduce = MC_REDUCE_RCCL;
     bool control = false;
     bool timing = true;                        // two HIP events per device and call (mc_result.kernel_ms)
+    bool readback_copy = false;                // MC_MULTI_READBACK=copy: round 2's copy + synchronize read-back also with timing off (A/B)
     double last_reduce_error = 0.0;
 };
 
@@ -138,6 +141,8 @@ extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc
     }
     if (const char *e = getenv("MC_MULTI_REDUCE"))
         m->reduce = strcmp(e, "host") == 0 ? MC_REDUCE_HOST : MC_REDUCE_RCCL;
+    if (const char *e = getenv("MC_MULTI_READBACK"))
+        m->readback_copy = strcmp(e, "copy") == 0;
     if (int rc = multi_allocate(m, blocks)) {
         mc_multi_destroy(m);
         return rc;
@@ -216,7 +221,46 @@ static int ensure_comms(mc_multi *m)
     return MC_OK;
 }
 
-// launch(g, ctx, first, count, d_triple, stream) enqueues device g's shard
+// What a call has put in flight, so that EVERY way out of run_sharded -- error returns included -- leaves the handle
+// reusable: an open RCCL group is closed, every stream the call touched is drained (its kernels write d_send / the
+// pinned slots, which the next call reuses).
+struct InFlight {
+    mc_multi *m;
+    int touched = 0;        // streams 0 .. touched-1 have work of this call
+    bool group_open = false;
+    bool settled = false;
+    explicit InFlight(mc_multi *h) : m(h) {}
+    void settle()
+    {
+        if (settled)
+            return;
+        settled = true;
+        if (group_open)
+            (void)ncclGroupEnd();
+        for (int g = 0; g < touched; ++g) {
+            (void)hipSetDevice(m->devices[g]);
+            (void)hipStreamSynchronize(m->stream[g]);
+        }
+    }
+    ~InFlight() { settle(); }
+};
+
+static inline bool slot_ready(const volatile double *slot)
+{
+    return __atomic_load_n((const uint64_t *)(slot + 2), __ATOMIC_ACQUIRE) != 0xBFF0000000000000ull;   // bits of -1.0
+}
+
+// launch(g, ctx, first, count, d_triple, stream) enqueues device g's shard.
+//
+// Read-back.  With timing off (what the legacy symbols and the benchmarks use) nothing is copied and nothing sleeps:
+// every device's last workgroup stores its triple into a pinned host slot of its context (mc_context_arm_direct), the
+// all-reduced triple follows through a one-lane kernel behind the collective on device 0's stream
+// (mc_context_publish), and this thread polls the G (+ 1) flag words in ONE loop from user space.  Round 2 issued G + 1
+// hipMemcpyAsync and G serial hipStreamSynchronize calls instead.  Measured on one device, C5's shard of 8 (a 1.04 ms
+// kernel), wall minus the kernel's own duration per call (profiles/r03_multi_fixed_cost.log, tools/c/multi_cost.c; the
+// dispatch-bound events of the measurement itself cost ~10 us of it): host sum 13.8 us = the single-device floor (13.7),
+// RCCL over one rank + publish 21.8 us; round 2's form 23.7 / 28.6 us.  With timing on the event/copy/synchronize path
+// is kept: it is the one that can report kernel_ms.
 template <class Launch>
 static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount, double add_back, mc_result *out, Launch launch)
 {
@@ -227,51 +271,97 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     if (m->reduce == MC_REDUCE_RCCL)
         if (int rc = ensure_comms(m)) return rc;
     const auto wall0 = std::chrono::steady_clock::now();
+    InFlight fl(m);
+    bool direct = !m->timing && !m->readback_copy;
+    std::vector<const volatile double *> slot((size_t)G, nullptr);
+    const volatile double *rslot = nullptr;
     for (int g = 0; g < G; ++g) {
         uint64_t lo = 0, cnt = 0;
         mc_shard_range(n, g, G, &lo, &cnt);
         HIPCHK(hipSetDevice(m->devices[g]));
+        fl.touched = g + 1;
         if (m->timing) HIPCHK(hipEventRecord(m->ev0[g], m->stream[g]));
-        if (cnt)
+        if (cnt) {
+            if (direct && mc_context_arm_direct(m->ctx[g], &slot[g]) != MC_OK)
+                direct = false;   // e.g. MC_FINISH=kernel: fall back to copies for the whole call (g == 0: nothing armed yet)
             MCCHK(launch(g, m->ctx[g], first + lo, cnt, m->d_send[g], (void *)m->stream[g]));
-        else   // fewer paths than devices: this one contributes {0, 0, 0}
+        } else {  // fewer paths than devices: this one contributes {0, 0, 0}
             HIPCHK(hipMemsetAsync(m->d_send[g], 0, 3 * sizeof(double), m->stream[g]));
+        }
         if (m->timing) HIPCHK(hipEventRecord(m->ev1[g], m->stream[g]));
     }
     if (m->reduce == MC_REDUCE_RCCL) {
         NCCLCHK(ncclGroupStart());
+        fl.group_open = true;
         for (int g = 0; g < G; ++g)
             NCCLCHK(ncclAllReduce(m->d_send[g], m->d_recv[g], 3, ncclDouble, ncclSum, m->comm[g], m->stream[g]));
+        fl.group_open = false;
         NCCLCHK(ncclGroupEnd());
-    }
-    for (int g = 0; g < G; ++g) {
-        HIPCHK(hipSetDevice(m->devices[g]));
-        HIPCHK(hipMemcpyAsync(m->h_send + 3 * g, m->d_send[g], 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream[g]));
-        if (g == 0 && m->reduce == MC_REDUCE_RCCL)
-            HIPCHK(hipMemcpyAsync(m->h_recv, m->d_recv[0], 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream[0]));
+        if (direct) {
+            const int g = 0;
+            MCCHK(mc_context_publish(m->ctx[0], m->d_recv[0], (void *)m->stream[0], &rslot));
+        }
     }
     float kernel_ms = 0;
-    for (int g = 0; g < G; ++g) {
-        HIPCHK(hipSetDevice(m->devices[g]));
-        HIPCHK(hipStreamSynchronize(m->stream[g]));
-        float ms = 0;
-        if (m->timing) HIPCHK(hipEventElapsedTime(&ms, m->ev0[g], m->ev1[g]));
-        kernel_ms = ms > kernel_ms ? ms : kernel_ms;
-    }
-    // host sum in device order: the collective's cross-check, or the result itself
-    double host[3] = {0, 0, 0};
-    for (int g = 0; g < G; ++g)
+    double host[3] = {0, 0, 0}, reduced[3] = {0, 0, 0};
+    if (direct) {
+        // one polling loop over every flag word; after 50 ms (BASELINE's C4 and C5 shards take 1-40 ms) hand the core
+        // back and wait in the runtime, which is also the way out if a device faulted and will never write
+        bool all = false;
+        for (uint32_t spin = 0; !all; ++spin) {
+            all = !rslot || slot_ready(rslot);
+            for (int g = 0; g < G && all; ++g)
+                all = !slot[g] || slot_ready(slot[g]);
+            if (all)
+                break;
+            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - wall0 > std::chrono::milliseconds(50)) {
+                fl.settle();
+                all = !rslot || slot_ready(rslot);
+                for (int g = 0; g < G && all; ++g)
+                    all = !slot[g] || slot_ready(slot[g]);
+                if (!all)
+                    return fail(MC_ERR_HIP, "a device never delivered its result");
+                break;
+            }
+            __builtin_ia32_pause();
+        }
+        for (int g = 0; g < G; ++g)
+            for (int k = 0; k < 3; ++k)
+                host[k] += slot[g] ? slot[g][k] : 0.0;
+        for (int k = 0; k < 3 && rslot; ++k)
+            reduced[k] = rslot[k];
+        fl.touched = 0;   // everything the call enqueued has delivered: nothing left to drain
+    } else {
+        for (int g = 0; g < G; ++g) {
+            HIPCHK(hipSetDevice(m->devices[g]));
+            HIPCHK(hipMemcpyAsync(m->h_send + 3 * g, m->d_send[g], 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream[g]));
+            if (g == 0 && m->reduce == MC_REDUCE_RCCL)
+                HIPCHK(hipMemcpyAsync(m->h_recv, m->d_recv[0], 3 * sizeof(double), hipMemcpyDeviceToHost, m->stream[0]));
+        }
+        for (int g = 0; g < G; ++g) {
+            HIPCHK(hipSetDevice(m->devices[g]));
+            HIPCHK(hipStreamSynchronize(m->stream[g]));
+            float ms = 0;
+            if (m->timing) HIPCHK(hipEventElapsedTime(&ms, m->ev0[g], m->ev1[g]));
+            kernel_ms = ms > kernel_ms ? ms : kernel_ms;
+        }
+        fl.touched = 0;
+        // host sum in device order: the collective's cross-check, or the result itself
+        for (int g = 0; g < G; ++g)
+            for (int k = 0; k < 3; ++k)
+                host[k] += m->h_send[3 * g + k];
         for (int k = 0; k < 3; ++k)
-            host[k] += m->h_send[3 * g + k];
+            reduced[k] = m->h_recv[k];
+    }
     const double *tot = host;
     m->last_reduce_error = 0.0;
     if (m->reduce == MC_REDUCE_RCCL) {
-        tot = m->h_recv;
+        tot = reduced;
         for (int k = 0; k < 3; ++k) {
-            const double err = std::fabs(m->h_recv[k] - host[k]), ref = std::fabs(host[k]);
+            const double err = std::fabs(reduced[k] - host[k]), ref = std::fabs(host[k]);
             if (!(err <= 1e-12 * ref))
                 return fail(MC_ERR_HIP, "RCCL all-reduce disagrees with the host sum of the %d device triples: word %d %.17g vs %.17g",
-                            G, k, m->h_recv[k], host[k]);
+                            G, k, reduced[k], host[k]);
             if (k == 0 && ref > 0)
                 m->last_reduce_error = err / ref;
         }

@@ -230,4 +230,15 @@ __global__ __launch_bounds__(256) void finish_kernel(const double2 *__restrict__
     }
 }
 
+// One lane: three doubles from device memory into pinned host memory, the last one with system-scope release semantics --
+// how a result that some OTHER kernel produced (the RCCL all-reduce of the multi-GPU path) reaches a polling host thread
+// without a copy command and a sleeping synchronize (mc_api.hip: mc_context_publish).
+__global__ void publish_kernel(const double *__restrict__ src, double *host)
+{
+    gu64_t *h = (gu64_t *)host;
+    __hip_atomic_store(h, (unsigned long long)__double_as_longlong(src[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h + 1, (unsigned long long)__double_as_longlong(src[1]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(h + 2, (unsigned long long)__double_as_longlong(src[2]), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 }  // namespace mc

@@ -114,6 +114,31 @@ int main(void)
         }
         mc_context_set_antithetic(one, 0);
         CHECK(mc_multi_set_antithetic(m, 0));
+        /* the two read-back forms of run_sharded: events + copies + synchronize (timing on, used so far) and the pinned
+         * slots the devices write themselves, polled from user space (timing off).  Same kernels, same sums: same bits.
+         * Many short calls back to back: a slot's sentinel and the tickets are reset between calls. */
+        {
+            mc_result on, off;
+            CHECK(mc_multi_set_timing(m, 1));
+            CHECK(mc_multi_cva_run_f64(m, &c64, seed, first, n / 64, &on));
+            CHECK(mc_multi_set_timing(m, 0));
+            for (int rep = 0; rep < 200; ++rep) {
+                CHECK(mc_multi_cva_run_f64(m, &c64, seed, first, n / 64, &off));
+                if (off.sum != on.sum || off.sum2 != on.sum2 || off.n != on.n) {
+                    printf("MISMATCH direct read-back %s rep %d: %.17g vs %.17g\n", names[h], rep, off.sum, on.sum);
+                    ++failures;
+                    break;
+                }
+            }
+            CHECK(mc_multi_vanilla_run_f32(m, &v32, seed, first, 4099, &off));   /* a call of a few microseconds */
+            CHECK(mc_multi_set_timing(m, 1));
+            CHECK(mc_multi_vanilla_run_f32(m, &v32, seed, first, 4099, &on));
+            if (off.sum != on.sum || off.sum2 != on.sum2 || off.kernel_ms != 0.0f) {
+                printf("MISMATCH direct read-back %s, small call\n", names[h]);
+                ++failures;
+            }
+            printf("ok    read-back forms agree bit for bit on %s (200 direct calls)\n", names[h]);
+        }
         /* control variate: the closed-form mean is added back once, after the reduction */
         mc_context_set_control_variate(one, 1);
         CHECK(mc_multi_set_control_variate(m, 1));
