@@ -159,11 +159,16 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
     out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
 }
 
-static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, mc_real z[NPB])
+/* MC_F64_NORMALS=f32 (fp64 build only; read once per call): the GPU engine's MC_NORMALS_F32 mode -- FOUR fp32 normals per
+ * Philox block, widened to double, the reference's own dp arithmetic (dp/MonteCarloKernel.cu:68,78,250).  The scalar loops
+ * below then run with 4 normals per block (g_npb); the vectorised loops of host_simd.c are compiled for the native layout
+ * and are bypassed in this mode. */
+static int g_normals_f32;
+static int g_npb = NPB;   /* normals one block yields under the current mode */
+#define MAX_NPB 4
+
+static void block_normals_f32(const uint32_t x[4], float z[4])
 {
-    uint32_t x[4];
-    philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);  /* counter = {unit_hi, unit_lo, block, domain} */
-#ifdef MC_SINGLE_PRECISION
     for (int h = 0; h < 2; ++h) {
         const float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f);
         const uint32_t ub_bits = (x[2 * h + 1] >> 9) | 0x3f800000u;  /* angle in revolutions, in [1, 2): mc_rng.hpp angle_f32 */
@@ -174,7 +179,23 @@ static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_
         z[2 * h] = radius * (float)cos(ang);
         z[2 * h + 1] = radius * (float)sin(ang);
     }
+}
+
+/* z has room for MAX_NPB values; g_npb of them are written */
+static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, mc_real *z)
+{
+    uint32_t x[4];
+    philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);  /* counter = {unit_hi, unit_lo, block, domain} */
+#ifdef MC_SINGLE_PRECISION
+    block_normals_f32(x, z);
 #else
+    if (g_normals_f32) {
+        float f[4];
+        block_normals_f32(x, f);
+        for (int j = 0; j < 4; ++j)
+            z[j] = (double)f[j];
+        return;
+    }
     const double ua = ((double)(((uint64_t)x[1] << 20) | (x[0] >> 12)) + 0.5) * 0x1p-52;
     const double ub = ((double)(((uint64_t)x[3] << 20) | (x[2] >> 12)) + 0.5) * 0x1p-52;
     const double radius = sqrt(-2.0 * log(ua)), ang = 2.0 * M_PI * ub;
@@ -255,6 +276,10 @@ static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, doubl
     const uint64_t seed = seed_from_env();
     g_antithetic = getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC"));
     g_control = getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE"));
+#ifndef MC_SINGLE_PRECISION
+    g_normals_f32 = getenv("MC_F64_NORMALS") && !strcmp(getenv("MC_F64_NORMALS"), "f32");
+    g_npb = g_normals_f32 ? 4 : NPB;
+#endif
 #ifdef _OPENMP
     omp_set_num_threads(mc_host_threads());
 #endif
@@ -325,10 +350,11 @@ static void vanilla_chunk(const void *ctx, uint64_t seed, long long first, long 
     const mc_real drift = (mc_real)(((double)o->r - 0.5 * (double)o->v * (double)o->v) * (double)o->t);
     const mc_real vol = (mc_real)((double)o->v * sqrt((double)o->t));
     double s = 0, s2 = 0;
-    mc_real z[NPB];
+    mc_real z[MAX_NPB];
     uint64_t have = (uint64_t)-1;
     long long i0 = 0;
-    if (first % NPB == 0 && !getenv("MC_HOST_SCALAR")) {   /* whole batches of units: the vectorised form (host_simd.c) */
+    const uint64_t npb = (uint64_t)g_npb;
+    if (first % NPB == 0 && !getenv("MC_HOST_SCALAR") && !g_normals_f32) {   /* whole batches of units: the vectorised form (host_simd.c) */
         const long long units = (count / NPB) / SIMD_BATCH * SIMD_BATCH;
         if (units > 0) {
             double part[2];
@@ -338,13 +364,13 @@ static void vanilla_chunk(const void *ctx, uint64_t seed, long long first, long 
         }
     }
     for (long long i = i0; i < count; ++i) {
-        const uint64_t p = (uint64_t)(first + i), unit = p / NPB;
+        const uint64_t p = (uint64_t)(first + i), unit = p / npb;
         if (unit != have)
             block_normals(seed, MC_DOMAIN_VANILLA, unit, 0, z), have = unit;
-        const mc_real v = o->s * R_EXP(drift + vol * z[p % NPB]) - o->k;
+        const mc_real v = o->s * R_EXP(drift + vol * z[p % npb]) - o->k;
         mc_real payoff = v > 0 ? v : 0;
         if (g_antithetic) {
-            const mc_real vm = o->s * R_EXP(drift - vol * z[p % NPB]) - o->k;
+            const mc_real vm = o->s * R_EXP(drift - vol * z[p % npb]) - o->k;
             payoff = (mc_real)0.5 * (payoff + (vm > 0 ? vm : 0));
         }
         const double pay = (double)payoff;
@@ -358,21 +384,21 @@ static void basket_chunk(const void *ctx, uint64_t seed, long long first, long l
 {
     const MultiOptionData *o = (const MultiOptionData *)ctx;
     const mc_real sqrt_t = (mc_real)sqrt((double)o->t);
-    enum { NBLK = (N + NPB - 1) / NPB };
-    mc_real g[NBLK * NPB];
+    const int npb = g_npb, nblk = (N + npb - 1) / npb;
+    mc_real g[N + MAX_NPB];
     double s = 0, s2 = 0, wsum = 0;
     for (int a = 0; a < N; ++a)
         wsum += (double)o->w[a];
     long long i0 = 0;
-    if (!getenv("MC_HOST_SCALAR") && count >= SIMD_BATCH) {   /* whole batches of paths: the vectorised form (host_simd.c) */
+    if (!getenv("MC_HOST_SCALAR") && !g_normals_f32 && count >= SIMD_BATCH) {   /* whole batches of paths: the vectorised form (host_simd.c) */
         double part[2];
         i0 = count / SIMD_BATCH * SIMD_BATCH;
         simd()->basket(seed, (uint64_t)first, i0, &o->p[0][0], o->d, o->v, o->s, o->w, o->k, o->t, o->r, g_antithetic, g_control, part);
         s = part[0], s2 = part[1];
     }
     for (long long i = i0; i < count; ++i) {
-        for (int b = 0; b < NBLK; ++b)
-            block_normals(seed, MC_DOMAIN_BASKET, (uint64_t)(first + i), (uint32_t)b, g + b * NPB);
+        for (int b = 0; b < nblk; ++b)
+            block_normals(seed, MC_DOMAIN_BASKET, (uint64_t)(first + i), (uint32_t)b, g + b * npb);
         mc_real payoff = 0;
         for (int sign = 1; sign >= (g_antithetic ? -1 : 1); sign -= 2) {
             mc_real basket = 0, lg = (mc_real)log(wsum);
@@ -410,9 +436,10 @@ static void cva_chunk(const void *ctx, uint64_t seed, long long first, long long
     const mc_real step_drift = (mc_real)(((double)o->r - 0.5 * (double)o->v * (double)o->v) * (double)dt);
     const mc_real step_vol = (mc_real)((double)o->v * sqrt((double)dt));
     double s = 0, s2 = 0;
-    mc_real z[NPB];
+    mc_real z[MAX_NPB];
     long long i0 = 0;
-    if (!getenv("MC_HOST_SCALAR") && count >= SIMD_BATCH) {   /* whole batches of paths: the vectorised form (host_simd.c) */
+    const int npb = g_npb;
+    if (!getenv("MC_HOST_SCALAR") && !g_normals_f32 && count >= SIMD_BATCH) {   /* whole batches of paths: the vectorised form (host_simd.c) */
         double part[2];
         i0 = count / SIMD_BATCH * SIMD_BATCH;
         simd()->cva(seed, (uint64_t)first, i0, o->s, o->k, o->r, o->v, o->t, c->n, c->defInt, c->lgd, g_antithetic, part);
@@ -427,10 +454,10 @@ static void cva_chunk(const void *ctx, uint64_t seed, long long first, long long
             ttm -= dt;
             if (ttm >= 0) {
                 const int idx = j - 1;
-                if (idx % NPB == 0)
-                    block_normals(seed, MC_DOMAIN_CVA, (uint64_t)(first + i), (uint32_t)(idx / NPB), z);
-                spot = spot * R_EXP(step_drift + step_vol * z[idx % NPB]);
-                mirror = mirror * R_EXP(step_drift - step_vol * z[idx % NPB]);
+                if (idx % npb == 0)
+                    block_normals(seed, MC_DOMAIN_CVA, (uint64_t)(first + i), (uint32_t)(idx / npb), z);
+                spot = spot * R_EXP(step_drift + step_vol * z[idx % npb]);
+                mirror = mirror * R_EXP(step_drift - step_vol * z[idx % npb]);
                 for (int leg = 0; leg < (g_antithetic ? 2 : 1); ++leg) {
                     const mc_real sx = leg ? mirror : spot;
                     if (ttm == 0)

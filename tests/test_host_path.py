@@ -98,6 +98,40 @@ def test_host_monte_carlo_matches_oracle_on_the_engine_stream(po, X):
         assert float(v.Confidence) == pytest.approx(o["confidence"], rel=10 * tol)
 
 
+def test_f64_twin_on_fp32_normals_matches_oracle_mode(po, monkeypatch):
+    """MC_F64_NORMALS=f32: the CPU twin's fp64 entry points draw four fp32 normals per Philox block, widened -- the GPU
+    engine's MC_NORMALS_F32 mode (the reference's dp arithmetic, dp/MonteCarloKernel.cu:68,78,250).  Same libm on both
+    sides here, so the agreement with the oracle's mode is at the fp64 summation level."""
+    monkeypatch.setenv("MC_F64_NORMALS", "f32")
+    L, OptionData, MultiOptionData, OptionValue, CVA = load(po, "f64")
+    n = 70001
+    v = L.host_vanillaOpt(OptionData(*[VAN[k] for k in "skrvt"]), n)
+    with po.normals_f32():
+        _, o = po.dev_vanilla("f64", VAN, SEED, 0, n, want_paths=False)
+    _, native = po.dev_vanilla("f64", VAN, SEED, 0, n, want_paths=False)
+    assert float(v.Expected) == pytest.approx(o["expected"], rel=1e-12) and float(v.Confidence) == pytest.approx(o["confidence"], rel=1e-12)
+    assert abs(float(v.Expected) - native["expected"]) > 1e-6        # a different stream than the native one
+    Lf = po.chol("f64", [[1, .5, .5], [.5, 1, .5], [.5, .5, 1]])
+    b = dict(s=[100.0] * 3, v=[0.2, 0.3, 0.2], p=Lf.tolist(), d=[0.0, 0.01, -0.01], w=[1 / 3] * 3, k=100.0, t=1.0, r=0.048790164)
+    m = MultiOptionData()
+    for i in range(3):
+        m.s[i], m.v[i], m.d[i], m.w[i] = b["s"][i], b["v"][i], b["d"][i], b["w"][i]
+        for j in range(3):
+            m.p[i][j] = b["p"][i][j]
+    m.k, m.t, m.r = b["k"], b["t"], b["r"]
+    v = L.host_basketOpt(C.byref(m), 30001)
+    with po.normals_f32():
+        _, o = po.dev_basket("f64", b, SEED, 0, 30001, want_paths=False)
+    assert float(v.Expected) == pytest.approx(o["expected"], rel=1e-12) and float(v.Confidence) == pytest.approx(o["confidence"], rel=1e-12)
+    for n_grid in (3, 250, 256):
+        c = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6, n_grid=n_grid)
+        s = CVA(c["defint"], c["lgd"], 0, OptionData(*[c[k] for k in "skrvt"]), n_grid)
+        v = L.host_cvaEquityOption(C.byref(s), 1501)
+        with po.normals_f32():
+            _, o = po.dev_cva("f64", c, SEED, 0, 1501, want_paths=False)
+        assert float(v.Expected) == pytest.approx(o["expected"], rel=1e-12) and float(v.Confidence) == pytest.approx(o["confidence"], rel=1e-11)
+
+
 def test_result_does_not_depend_on_thread_count(po):
     """Fixed 65536-path chunks added in index order: 1 thread and all threads give the same bits."""
     code = ("import ctypes as C, sys; sys.path.insert(0, %r)\n"
