@@ -22,7 +22,7 @@
  * is not thread-safe: one host thread per context.  Several GPUs from one process: include/mc_multi.h.
  *
  * Random numbers: Philox4x32-10, key = 64-bit seed, counter = {unit_hi, unit_lo, block,
- * domain} (unit = 64-bit index of a path or of a Philox block of vanilla paths).  A path's normals depend only on
+ * domain} (unit = 64-bit index of a path or of a block of vanilla paths: 4 in f32, 8 in f64).  A path's normals depend only on
  * (seed, global path index), never on the launch geometry or on how a range is split over GPUs.  Layout per product:
  * DESIGN.md "RNG".  XORWOW, the reference's generator, is selectable: mc_context_set_generator.
  *
@@ -52,6 +52,12 @@ const char *mc_last_error(void);
 /* Default seed of the legacy entry points (the reference's device seed is fixed too:
  * dp/MonteCarloKernel.cu:289). */
 #define MC_DEFAULT_SEED 0x4D435F4D49333535ull
+
+/* Layout of the random streams (which counter yields which normal).  Results for a given seed are comparable only between
+ * builds of the same version.  1: rounds 1-2 (fp64: one Philox block = 2 normals).  2: the fp64 streams draw EIGHT normals
+ * from three consecutive Philox blocks -- 96 bits per Box-Muller pair: 52-bit radius, 44-bit angle;
+ * a vanilla fp64 unit is 8 paths.  The fp32 streams are unchanged. */
+#define MC_STREAM_VERSION 2
 
 /* Stream domains (Philox counter word 3). */
 #define MC_DOMAIN_VANILLA 1u
@@ -288,7 +294,8 @@ int mc_cva_paths_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
 int mc_cva_paths_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
                      uint64_t first_path, uint64_t n_paths, double *h_out);
 /* The normals of Philox blocks (unit = first_unit .. first_unit+n_units-1, block, domain):
- * 4 per unit in f32, 2 per unit in f64 (4 under MC_NORMALS_F32), written unit-major to the HOST array h_out. */
+ * 4 per unit in f32, 8 per unit in f64 (4 under MC_NORMALS_F32), written unit-major to the HOST array h_out.  In f64 block b
+ * of the stream is Philox blocks 3b .. 3b + 2 (MC_STREAM_VERSION 2). */
 int mc_normals_f32(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,
                    uint64_t n_units, uint32_t block, float *h_out);
 int mc_normals_f64(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,

@@ -18,7 +18,7 @@ MC_DEFAULT_SEED = 0x4D435F4D49333535
 DOMAIN_VANILLA, DOMAIN_BASKET, DOMAIN_CVA = 1, 2, 3
 MAX_ASSETS = 16          # register-resident basket kernels
 MAX_ASSETS_GENERIC = 64  # LDS-staged generic kernel beyond that
-NPB = {"f32": 4, "f64": 2}
+NPB = {"f32": 4, "f64": 8}   # normals per block of the stream (include/mc_mi355x.h: MC_STREAM_VERSION 2)
 FROM_NORMALS_NO_VOL, FROM_NORMALS_HOST_ORDER = 1, 2   # flags of the mc_*_from_normals_* test hooks
 CT = {"f32": C.c_float, "f64": C.c_double}
 

@@ -38,7 +38,7 @@
 #define R_LOG logf
 #define R_SQRT sqrtf
 #else
-#define NPB 2
+#define NPB 8   /* fp64 stream version 2: eight normals per block of three Philox blocks (mc_rng.hpp) */
 #define R_EXP exp
 #define R_LOG log
 #define R_SQRT sqrt
@@ -165,7 +165,7 @@ static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
  * and are bypassed in this mode. */
 static int g_normals_f32;
 static int g_npb = NPB;   /* normals one block yields under the current mode */
-#define MAX_NPB 4
+#define MAX_NPB 8
 
 static void block_normals_f32(const uint32_t x[4], float z[4])
 {
@@ -184,23 +184,35 @@ static void block_normals_f32(const uint32_t x[4], float z[4])
 /* z has room for MAX_NPB values; g_npb of them are written */
 static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, mc_real *z)
 {
+#ifdef MC_SINGLE_PRECISION
     uint32_t x[4];
     philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);  /* counter = {unit_hi, unit_lo, block, domain} */
-#ifdef MC_SINGLE_PRECISION
     block_normals_f32(x, z);
 #else
     if (g_normals_f32) {
+        uint32_t x[4];
         float f[4];
+        philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), x);
         block_normals_f32(x, f);
         for (int j = 0; j < 4; ++j)
             z[j] = (double)f[j];
         return;
     }
-    const double ua = ((double)(((uint64_t)x[1] << 20) | (x[0] >> 12)) + 0.5) * 0x1p-52;
-    const double ub = ((double)(((uint64_t)x[3] << 20) | (x[2] >> 12)) + 0.5) * 0x1p-52;
-    const double radius = sqrt(-2.0 * log(ua)), ang = 2.0 * M_PI * ub;
-    z[0] = radius * cos(ang);
-    z[1] = radius * sin(ang);
+    /* native fp64: block b = Philox blocks 3b .. 3b + 2 = twelve words, four Box-Muller pairs of 96 bits:
+     * pair p = (a, m, c) = W[3p .. 3p + 2]; radius from the 52 bits (a : top 20 of m), angle from the 44 bits
+     * (c : low 12 of m) as the top of a 52-bit fraction (mc_rng.hpp: words_to_normals; MC_STREAM_VERSION 2) */
+    uint32_t W[12];
+    philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, 3 * block, domain, (uint32_t)seed, (uint32_t)(seed >> 32), W);
+    philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, 3 * block + 1, domain, (uint32_t)seed, (uint32_t)(seed >> 32), W + 4);
+    philox4x32_10((uint32_t)(unit >> 32), (uint32_t)unit, 3 * block + 2, domain, (uint32_t)seed, (uint32_t)(seed >> 32), W + 8);
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t a = W[3 * p], m = W[3 * p + 1], c = W[3 * p + 2];
+        const double ua = ((double)(((uint64_t)a << 20) | (m >> 12)) + 0.5) * 0x1p-52;
+        const double ub = ((double)((((uint64_t)c << 12) | (m & 0xfffu)) << 8) + 0.5) * 0x1p-52;
+        const double radius = sqrt(-2.0 * log(ua)), ang = 2.0 * M_PI * ub;
+        z[2 * p] = radius * cos(ang);
+        z[2 * p + 1] = radius * sin(ang);
+    }
 #endif
 }
 

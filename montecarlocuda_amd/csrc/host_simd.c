@@ -22,7 +22,7 @@ typedef float real;
 #define NPB 4
 #else
 typedef double real;
-#define NPB 2
+#define NPB 8   /* fp64 stream version 2: eight normals per block of three Philox blocks (mc_rng.hpp) */
 #endif
 
 #define BATCH 256
@@ -75,10 +75,10 @@ static inline void philox_batch(uint64_t seed, uint64_t unit0, uint32_t block, u
 /* the NPB normals of BATCH consecutive units (block `block` of each): z[j][i] = normal j of unit unit0 + i */
 static inline void normals_batch(uint64_t seed, uint64_t unit0, uint32_t block, uint32_t domain, real z[NPB][BATCH])
 {
-    uint32_t w0[BATCH], w1[BATCH], w2[BATCH], w3[BATCH];
     real radius[BATCH], ang[BATCH];
-    philox_batch(seed, unit0, block, domain, w0, w1, w2, w3);
 #ifdef MC_SINGLE_PRECISION
+    uint32_t w0[BATCH], w1[BATCH], w2[BATCH], w3[BATCH];
+    philox_batch(seed, unit0, block, domain, w0, w1, w2, w3);
     for (int h = 0; h < 2; ++h) {
         const uint32_t *restrict wa = h ? w2 : w0, *restrict wb = h ? w3 : w1;
         real *restrict zc = z[2 * h], *restrict zs = z[2 * h + 1];
@@ -96,16 +96,25 @@ static inline void normals_batch(uint64_t seed, uint64_t unit0, uint32_t block, 
             zs[i] = radius[i] * sinf(ang[i]);
     }
 #else
-    for (int i = 0; i < BATCH; ++i) {
-        const double ua = ((double)(((uint64_t)w1[i] << 20) | (w0[i] >> 12)) + 0.5) * 0x1p-52;
-        const double ub = ((double)(((uint64_t)w3[i] << 20) | (w2[i] >> 12)) + 0.5) * 0x1p-52;
-        radius[i] = sqrt(-2.0 * log(ua));
-        ang[i] = 6.283185307179586477 * ub;
+    /* block b = Philox blocks 3b .. 3b + 2 = twelve words W[0..11] per unit; pair p = (a, m, c) = W[3p .. 3p + 2]:
+     * 52-bit radius uniform (a : top 20 of m), 44-bit angle (c : low 12 of m) on top of a 52-bit fraction */
+    static _Thread_local uint32_t W[12][BATCH];
+    for (int s = 0; s < 3; ++s)
+        philox_batch(seed, unit0, 3 * block + (uint32_t)s, domain, W[4 * s], W[4 * s + 1], W[4 * s + 2], W[4 * s + 3]);
+    for (int p = 0; p < 4; ++p) {
+        const uint32_t *restrict wa = W[3 * p], *restrict wm = W[3 * p + 1], *restrict wc = W[3 * p + 2];
+        for (int i = 0; i < BATCH; ++i) {
+            const double ua = ((double)(((uint64_t)wa[i] << 20) | (wm[i] >> 12)) + 0.5) * 0x1p-52;
+            const double ub = ((double)((((uint64_t)wc[i] << 12) | (wm[i] & 0xfffu)) << 8) + 0.5) * 0x1p-52;
+            radius[i] = sqrt(-2.0 * log(ua));
+            ang[i] = 6.283185307179586477 * ub;
+        }
+        real *restrict zc = z[2 * p], *restrict zs = z[2 * p + 1];
+        for (int i = 0; i < BATCH; ++i)
+            zc[i] = radius[i] * cos(ang[i]);
+        for (int i = 0; i < BATCH; ++i)
+            zs[i] = radius[i] * sin(ang[i]);
     }
-    for (int i = 0; i < BATCH; ++i)
-        z[0][i] = radius[i] * cos(ang[i]);
-    for (int i = 0; i < BATCH; ++i)
-        z[1][i] = radius[i] * sin(ang[i]);
 #endif
 }
 

@@ -418,7 +418,7 @@ static int with_anti_gen(bool anti, GenSel g, F f)
     return with_gen<ALLOW>(g, [&](auto tag) { f(std::false_type{}, tag); });
 }
 // normals one block yields for precision Real under the context's settings (GenPhiloxF32N: 4 in fp64 too)
-template <class Real> static uint64_t npb_of(const mc_context *c) { return (sizeof(Real) == 8 && !c->normals_f32) ? 2 : 4; }
+template <class Real> static uint64_t npb_of(const mc_context *c) { return (sizeof(Real) == 8 && !c->normals_f32) ? 8 : 4; }
 
 // the Work of a launch, with the context's generator inputs attached
 static Work context_work(const mc_context *c, uint64_t seed, const Segment &s, uint64_t first_path, uint64_t end_path)
@@ -1350,7 +1350,9 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     const GenSel gen = gen_of(c, probe, sizeof(Real));
     using Kernel = void (*)(const Tail, const BasketDyn<Real>, const Work, Real *);
     Kernel kernel = nullptr;
-    size_t lds = (size_t)np * GROUP * sizeof(Real);
+    // generic kernels: the lane's LDS column holds whole blocks of normals (4 per block in fp32 and under fp32 normals, 8 in fp64)
+    const size_t per_block = gen == GEN_F32N ? 4 : GenPhilox::npb<Real>();
+    size_t lds = ((size_t)np + per_block - 1) / per_block * per_block * GROUP * sizeof(Real);
     bool pairs = false;  // two paths per lane
     const bool tiled_ok = n >= basket_tiled_min() && n <= 32 && (gen == GEN_PHILOX || gen == GEN_F32N || (gen == GEN_EXTERNAL && n == 16));
     int rc = MC_OK;

@@ -3,7 +3,7 @@
 // Shape common to all three products (replaces the kernel skeleton of
 // dp/MonteCarloKernel.cu:133-177,179-220,222-283):
 //   * a persistent-style grid (blocks x 256 lanes) strides over "units" of work; a unit is one
-//     Philox block of vanilla paths (4 in f32, 2 in f64) or one whole basket / CVA path;
+//     block of vanilla paths (4 in f32 = one Philox block, 8 in f64 = three) or one whole basket / CVA path;
 //   * everything a lane needs is in registers: counter-based normals (mc_rng.hpp), per-lane fp64
 //     (sum, sum2) accumulators; wave-uniform constants never cost a VALU slot -- kernel arguments in
 //     SGPRs while they fit, otherwise LDS-staged (broadcast ds_read) or fetched tile by tile with
@@ -687,7 +687,7 @@ __global__ __launch_bounds__(GROUP) void basket_dyn_kernel(const Tail /* first a
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
     constexpr int NPB = Gen::template npb<Real>();
-    const int nb = (o.n + 3) >> 2, np = nb * 4, nblk = np / NPB;
+    const int nb = (o.n + 3) >> 2, np = nb * 4, nblk = (np + NPB - 1) / NPB;   // whole blocks: the column holds nblk * NPB normals
     // constant address space: wave-uniform reads become scalar loads (s_load_dwordx16 per tile) whatever the
     // compiler can or cannot prove about the kernel's global stores
     typedef const __attribute__((address_space(4))) Real *cptr;
@@ -999,6 +999,21 @@ __device__ __forceinline__ double sum_over_lane_groups(double p0, double p1, dou
     return r0 + r1;
 }
 
+// Pair q (a lane-dependent 0..3) of fp64 block `block` of a path: words W[3q .. 3q + 2] of the block's twelve
+// (mc_rng.hpp: words_to_normals).  They sit in Philox blocks 3 block + {0,0,1,2}[q] and 3 block + {0,1,2,2}[q]: two
+// Philox blocks per pair here (the other kernels, which use all four pairs of a lane's block, pay three per four pairs) --
+// one more reason this variant is not the default.
+__device__ __forceinline__ void mfma_pair_normals(GenPhilox &gen, const Work &w, uint32_t unit, uint32_t block, int q, double (&z)[2])
+{
+    const uint32_t ba = (3u * (uint32_t)q) >> 2, bb = (3u * (uint32_t)q + 2u) >> 2;
+    const u32x4 ra = gen.words(w, unit, 3u * block + ba, 2u /*MC_DOMAIN_BASKET*/);
+    const u32x4 rb = gen.words(w, unit, 3u * block + bb, 2u);
+    const uint32_t a = q == 0 ? ra.x : (q == 1 ? ra.w : (q == 2 ? ra.z : ra.y));   // W[3q]
+    const uint32_t m = q == 0 ? ra.y : (q == 1 ? rb.x : (q == 2 ? ra.w : ra.z));   // W[3q + 1]
+    const uint32_t c = q == 0 ? ra.z : (q == 1 ? rb.y : (q == 2 ? rb.x : rb.w));   // W[3q + 2]
+    pair_normals_f64(a, m, c, z[0], z[1]);
+}
+
 template <bool ANTI>
 __global__ __launch_bounds__(GROUP) void basket_mfma_f64_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketDyn<double> o, const Work w, double *__restrict__ out)
 {
@@ -1024,8 +1039,8 @@ __global__ __launch_bounds__(GROUP) void basket_mfma_f64_kernel(const Tail /* fi
         for (int c = 0; c < 4; ++c) {
             const uint32_t unit = w.unit_lo + i0 + 16u * c + j;
             double za[2], zb[2];
-            gen.normals(w, unit, (uint32_t)q, 2u /*MC_DOMAIN_BASKET*/, za);
-            gen.normals(w, unit, (uint32_t)q + 4u, 2u, zb);
+            mfma_pair_normals(gen, w, unit, 0u, q, za);   // columns 2q, 2q + 1:     pair q of the path's first fp64 block
+            mfma_pair_normals(gen, w, unit, 1u, q, zb);   // columns 2q + 8, 2q + 9: pair q of its second
             d4 x = {cb[0], cb[1], cb[2], cb[3]};
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], za[0], x, 0, 0, 0);
             x = __builtin_amdgcn_mfma_f64_16x16x4f64(A[1], za[1], x, 0, 0, 0);
@@ -1242,59 +1257,77 @@ __device__ __forceinline__ void cva_single_date(const CvaArgs<Real> &o, int j, i
     acc = fma_r(st.dp, ee, acc);
 }
 
-template <class Real, bool ANTI, class Gen>
-__device__ __forceinline__ Real cva_path(Gen &gen, const CvaArgs<Real> &o, const Work &w, uint32_t c0)
+// fp32: a block of four normals = two packed date pairs per trip of the date loop.
+template <bool ANTI, class Gen>
+__device__ __forceinline__ float cva_path(Gen &gen, const CvaArgs<float> &o, const Work &w, uint32_t c0)
 {
-    constexpr int NPB = Gen::template npb<Real>();
-    static_assert(NPB % 2 == 0, "dates are priced in pairs");
-    Real W = 0, acc = 0;
-    f2 acc2 = {0.0f, 0.0f};  // fp32: even / odd dates of the packed date pairs
-    Real z[NPB];
+    constexpr int NPB = Gen::template npb<float>();
+    static_assert(NPB == 4, "two packed date pairs per block");
+    float W = 0, acc = 0;
+    f2 acc2 = {0.0f, 0.0f};  // even / odd dates of the packed date pairs
+    float z[NPB];
     const int n_dates = o.n_bs + o.last_intrinsic;
-    Real bx_v = o.bx;   // in a vector register for the whole path: ln s = fma(W, bx, xk_j) then reads ONE scalar (xk_j)
-    if constexpr (sizeof(Real) == 8)
-        bx_v = to_vgpr(bx_v);
     for (int j0 = 0; j0 < n_dates; j0 += NPB) {
         gen.normals(w, c0, (uint32_t)(j0 / NPB), 3u /*MC_DOMAIN_CVA*/, z);
 #pragma unroll
         for (int h = 0; h < NPB / 2; ++h) {
             const int j = j0 + 2 * h;
             if (j + 1 < o.n_bs) {  // wave-uniform: both dates of this pair have a closed-form exposure
-                if constexpr (sizeof(Real) == 4) {
-                    // fp32: the pair's rows once more, field by field ({g, g'} ... {dp, dp'} adjacent: mc_api.hip), so the
-                    // two dates ride in the halves of every packed instruction (-8 % against packing d1, d2 of one date)
-                    const float *row = o.pairs + 12 * (j / 2);
-                    const f2 Wp = {W + z[2 * h], (W + z[2 * h]) + z[2 * h + 1]};
-                    W = Wp.y;
-                    const f2 bx = {o.bx, o.bx}, xk = {row[6], row[7]}, dp = {row[10], row[11]};
-                    f2 ee = bs_exposure_dates(pk_fma(Wp, bx, xk), Wp, row);
-                    if (ANTI)
-                        ee += bs_exposure_dates(pk_fma(-Wp, bx, xk), -Wp, row);
-                    acc2 = pk_fma(dp, ee, acc2);
-                } else {
-                    const CvaStep<double> sa = o.steps[j], sb = o.steps[j + 1];
-                    const double W_a = W + z[2 * h], W_b = W_a + z[2 * h + 1];
-                    W = W_b;
-                    double ee_a, ee_b;
-                    bs_exposure2(fma_scalar_addend(W_a, bx_v, sa.xk), W_a, sa, fma_scalar_addend(W_b, bx_v, sb.xk), W_b, sb, ee_a, ee_b);
-                    if (ANTI) {
-                        double em_a, em_b;
-                        bs_exposure2(fma_scalar_addend(-W_a, bx_v, sa.xk), -W_a, sa, fma_scalar_addend(-W_b, bx_v, sb.xk), -W_b, sb, em_a, em_b);
-                        ee_a += em_a;
-                        ee_b += em_b;
-                    }
-                    acc = fma_r(sa.dp, ee_a, acc);
-                    acc = fma_r(sb.dp, ee_b, acc);
-                }
+                // the pair's rows once more, field by field ({g, g'} ... {dp, dp'} adjacent: mc_api.hip), so the two dates
+                // ride in the halves of every packed instruction (-8 % against packing d1, d2 of one date)
+                const float *row = o.pairs + 12 * (j / 2);
+                const f2 Wp = {W + z[2 * h], (W + z[2 * h]) + z[2 * h + 1]};
+                W = Wp.y;
+                const f2 bx = {o.bx, o.bx}, xk = {row[6], row[7]}, dp = {row[10], row[11]};
+                f2 ee = bs_exposure_dates(pk_fma(Wp, bx, xk), Wp, row);
+                if (ANTI)
+                    ee += bs_exposure_dates(pk_fma(-Wp, bx, xk), -Wp, row);
+                acc2 = pk_fma(dp, ee, acc2);
             } else {
-                cva_single_date<Real, ANTI>(o, j, n_dates, z[2 * h], W, acc);
-                cva_single_date<Real, ANTI>(o, j + 1, n_dates, z[2 * h + 1], W, acc);
+                cva_single_date<float, ANTI>(o, j, n_dates, z[2 * h], W, acc);
+                cva_single_date<float, ANTI>(o, j + 1, n_dates, z[2 * h + 1], W, acc);
             }
         }
     }
-    if constexpr (sizeof(Real) == 4)
-        acc += acc2.x + acc2.y;
-    return acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);
+    acc += acc2.x + acc2.y;
+    return acc * (ANTI ? o.lgd * 0.5f : o.lgd);
+}
+
+// fp64: one Box-Muller pair = two dates per trip, drawn through the generator's pair cursor (mc_rng.hpp): the fp64 stream
+// hands out eight normals per block, and a date loop unrolled over all eight keeps four pairs of table rows in SGPRs (they
+// spill into VGPR lanes) and eight normals in VGPRs -- 129 VGPRs, 3 waves per SIMD; one pair per trip stays at round 2's 77.
+template <bool ANTI, class Gen>
+__device__ __forceinline__ double cva_path(Gen &gen, const CvaArgs<double> &o, const Work &w, uint32_t c0)
+{
+    double W = 0, acc = 0;
+    const int n_dates = o.n_bs + o.last_intrinsic;
+    const double bx_v = to_vgpr(o.bx);   // in a vector register for the whole path: ln s = fma(W, bx, xk_j) then reads ONE scalar (xk_j)
+    typename Gen::Carry carry;
+#pragma unroll 1
+    for (int j = 0; j < n_dates; j += 2) {
+        double z0, z1;
+        gen.pair(w, c0, 3u /*MC_DOMAIN_CVA*/, (uint32_t)(j >> 1), carry, z0, z1);
+        if (j + 1 < o.n_bs) {  // wave-uniform: both dates of this pair have a closed-form exposure
+            const CvaStep<double> sa = o.steps[j], sb = o.steps[j + 1];
+            const double W_a = W + z0, W_b = W_a + z1;
+            W = W_b;
+            double ee_a, ee_b;
+            bs_exposure2(fma_scalar_addend(W_a, bx_v, sa.xk), W_a, sa, fma_scalar_addend(W_b, bx_v, sb.xk), W_b, sb, ee_a, ee_b);
+            if (ANTI) {
+                double em_a, em_b;
+                bs_exposure2(fma_scalar_addend(-W_a, bx_v, sa.xk), -W_a, sa, fma_scalar_addend(-W_b, bx_v, sb.xk), -W_b, sb, em_a, em_b);
+                ee_a += em_a;
+                ee_b += em_b;
+            }
+            acc = fma_r(sa.dp, ee_a, acc);
+            acc = fma_r(sb.dp, ee_b, acc);
+        } else {
+            cva_single_date<double, ANTI>(o, j, n_dates, z0, W, acc);
+            cva_single_date<double, ANTI>(o, j + 1, n_dates, z1, W, acc);
+        }
+    }
+    gen.pairs_done((uint32_t)((n_dates + 1) >> 1));
+    return acc * (ANTI ? o.lgd * 0.5 : o.lgd);
 }
 
 template <class Real, bool ANTI, class Gen = GenPhilox>
@@ -1306,7 +1339,7 @@ __global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument
     double acc_s = 0.0, acc_q = 0.0;
     Gen gen(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
-        const Real p = cva_path<Real, ANTI>(gen, o, w, w.unit_lo + i);
+        const Real p = cva_path<ANTI>(gen, o, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests

@@ -8,8 +8,8 @@
 //
 // (unit = 64-bit index of the unit of work; why the LOW word sits in counter word 1: philox_unit below.)
 //
-// One Philox block gives four 32-bit words = 4 normals in f32 (one word per uniform) or
-// 2 normals in f64 (two words per uniform), by two-branch Box-Muller.  The oracle twin of
+// One Philox block gives four 32-bit words = 4 normals in f32 (one word per uniform); in f64 three Philox blocks
+// give 8 normals (96 bits per Box-Muller pair: words_to_normals below), by two-branch Box-Muller.  The oracle twin of
 // this file is oracle/mc_oracle_impl.h:orc_dev_normals (tests compare them word for word).
 //
 // WHERE a kernel's normals come from is a policy class (the `Gen` template parameter of every simulation kernel,
@@ -130,13 +130,33 @@ template <class Real> __device__ __forceinline__ void stage_tables()
         stage_f64_tables();
 }
 
-// All normals of one block of four words: 4 in f32 (one word per uniform), 2 in f64 (two words per uniform)
+// All normals of one fp32 block: four words, one word per uniform
 __device__ __forceinline__ void words_to_normals(const u32x4 r, float (&out)[4])
 {
     box_muller_f32(r.x, r.y, NEG_2LN2_F32, out[0], out[1]);
     box_muller_f32(r.z, r.w, NEG_2LN2_F32, out[2], out[3]);
 }
-__device__ __forceinline__ void words_to_normals(const u32x4 r, double (&out)[2]) { box_muller_f64(r, out[0], out[1]); }
+
+// fp64 (stream version 2, MC_STREAM_VERSION in mc_mi355x.h): a "block" of the fp64 stream is THREE consecutive Philox
+// blocks = 12 words = four Box-Muller pairs of 96 bits each, EIGHT normals (version 1 spent one Philox block of 128 bits
+// per pair and used 104 of them: 8 normals cost 4 Philox blocks, 35 VALU instructions each).  Pair p takes words
+// (a, m, c) = W[3p], W[3p + 1], W[3p + 2]:
+//     radius uniform   52 bits: (a : top 20 bits of m)                     u_a = (J + 1/2) 2^-52
+//     angle uniform    44 bits: (c : low 12 bits of m), as the top 44 bits of a 52-bit fraction with 8 zero bits below:
+//                               u_b = (J' 2^8 + 1/2) 2^-52 -- no bit is shared with the radius
+// so that both go through the same table-driven forms as before; the only extra instruction per pair is the shift that
+// moves m's low 12 bits into place.  z_{2p} = r cos 2 pi u_b, z_{2p+1} = r sin 2 pi u_b.
+__device__ __forceinline__ void pair_normals_f64(uint32_t a, uint32_t m, uint32_t c, double &z_cos, double &z_sin)
+{
+    box_muller_f64((u32x4){m, a, m << 20, c}, z_cos, z_sin);   // (lo, hi) of the radius, (lo, hi) of the angle
+}
+__device__ __forceinline__ void words_to_normals(const u32x4 r0, const u32x4 r1, const u32x4 r2, double (&out)[8])
+{
+    pair_normals_f64(r0.x, r0.y, r0.z, out[0], out[1]);
+    pair_normals_f64(r0.w, r1.x, r1.y, out[2], out[3]);
+    pair_normals_f64(r1.z, r1.w, r2.x, out[4], out[5]);
+    pair_normals_f64(r2.y, r2.z, r2.w, out[6], out[7]);
+}
 
 // ---- the unit of work a launch strides over (host side: mc_api.hip make_work) ----------------------------
 // `Work` describes one segment: units [unit_lo, unit_lo + n_units) with a common high word
@@ -190,22 +210,47 @@ typedef float f2 __attribute__((ext_vector_type(2)));  // one VGPR pair: v_pk_{f
 // compiled reference's outputs (tests/test_gpu_from_normals.py).  Indices beyond a unit's count read as 0.
 struct GenPhilox {
     static constexpr bool external = false;
-    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 2; }
+    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }
     __device__ __forceinline__ explicit GenPhilox(const Work &) {}
     __device__ __forceinline__ u32x4 words(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain)
     {
         return philox_unit(unit_lo, w.unit_hi, block, domain, w.seed_lo, w.seed_hi);
     }
-    template <class Real, int N>
-    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, Real (&z)[N])
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, float (&z)[4])
     {
         words_to_normals(words(w, unit_lo, block, domain), z);
     }
+    // fp64: block b of the stream = Philox blocks 3b, 3b + 1, 3b + 2 (a kernel that uses only some of the eight normals
+    // pays only for the Philox blocks those need: the rest is dead code after unrolling)
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, double (&z)[8])
+    {
+        words_to_normals(words(w, unit_lo, 3u * block, domain), words(w, unit_lo, 3u * block + 1u, domain),
+                         words(w, unit_lo, 3u * block + 2u, domain), z);
+    }
+    // fp64 PAIR CURSOR: the same stream one Box-Muller pair at a time, for a kernel that consumes a unit's pairs strictly in
+    // order (the CVA date loop: pair P = dates 2P + 1, 2P + 2) and cannot afford eight normals and twelve words live at once.
+    // P (wave-uniform) = 0, 1, 2, ... ; the words a Philox block yields beyond the current pair wait in `carry`:
+    // pairs 4b .. 4b + 3 cost Philox blocks 3b, 3b + 1, 3b + 2 and nothing.
+    struct Carry { uint32_t c0, c1, c2; };
+    __device__ __forceinline__ void pair(const Work &w, uint32_t unit_lo, uint32_t domain, uint32_t P, Carry &k, double &z0, double &z1)
+    {
+        const uint32_t b3 = 3u * (P >> 2);
+        uint32_t a, m, c;
+        switch (P & 3u) {
+        case 0: { const u32x4 r = words(w, unit_lo, b3, domain); a = r.x, m = r.y, c = r.z, k.c0 = r.w; break; }
+        case 1: { const u32x4 r = words(w, unit_lo, b3 + 1u, domain); a = k.c0, m = r.x, c = r.y, k.c0 = r.z, k.c1 = r.w; break; }
+        case 2: { const u32x4 r = words(w, unit_lo, b3 + 2u, domain); a = k.c0, m = k.c1, c = r.x, k.c0 = r.y, k.c1 = r.z, k.c2 = r.w; break; }
+        default: a = k.c0, m = k.c1, c = k.c2; break;
+        }
+        pair_normals_f64(a, m, c, z0, z1);
+    }
+    // after the last pair of a unit (`pairs` of them were drawn): nothing to do for a counter-based stream
+    __device__ __forceinline__ void pairs_done(uint32_t) {}
 };
 
 struct GenXorwow {
     static constexpr bool external = false;
-    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 2; }
+    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }
     uint32_t x0, x1, x2, x3, x4, d;
     __device__ __forceinline__ explicit GenXorwow(const uint32_t *states)
     {
@@ -227,10 +272,30 @@ struct GenXorwow {
         r.x = next(), r.y = next(), r.z = next(), r.w = next();
         return r;
     }
-    template <class Real, int N>
-    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, Real (&z)[N])
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, float (&z)[4])
     {
         words_to_normals(words(w, unit_lo, block, domain), z);
+    }
+    // fp64: the lane's next TWELVE words (always the whole block, used or not: the sequence must move on the same way)
+    __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, double (&z)[8])
+    {
+        const u32x4 r0 = words(w, unit_lo, block, domain), r1 = words(w, unit_lo, block, domain), r2 = words(w, unit_lo, block, domain);
+        words_to_normals(r0, r1, r2, z);
+    }
+    struct Carry {};
+    __device__ __forceinline__ void pair(const Work &, uint32_t, uint32_t, uint32_t, Carry &, double &z0, double &z1)
+    {
+        const uint32_t a = next(), m = next(), c = next();   // the next three words: twelve per four pairs, as normals() draws them
+        pair_normals_f64(a, m, c, z0, z1);
+    }
+    // a unit always consumes whole blocks of twelve words, like normals(): skip the pairs of the last block that were not drawn
+    __device__ __forceinline__ void pairs_done(uint32_t pairs)
+    {
+        for (uint32_t p = pairs; (p & 3u) != 0; ++p) {
+            (void)next();
+            (void)next();
+            (void)next();
+        }
     }
 };
 
@@ -249,11 +314,23 @@ struct GenPhiloxF32N : GenPhilox {
     {
         words_to_normals(words(w, unit_lo, block, domain), z);
     }
+    struct Carry { float z2, z3; };
+    __device__ __forceinline__ void pair(const Work &w, uint32_t unit_lo, uint32_t domain, uint32_t P, Carry &k, double &z0, double &z1)
+    {
+        if ((P & 1u) == 0) {
+            float f[4];
+            words_to_normals(words(w, unit_lo, P >> 1, domain), f);
+            z0 = (double)f[0], z1 = (double)f[1], k.z2 = f[2], k.z3 = f[3];
+        } else {
+            z0 = (double)k.z2, z1 = (double)k.z3;
+        }
+    }
+    __device__ __forceinline__ void pairs_done(uint32_t) {}
 };
 
 struct GenExternal {
     static constexpr bool external = true;
-    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 2; }
+    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }   // the native block sizes
     __device__ __forceinline__ explicit GenExternal(const Work &) {}
     template <class Real, int N>
     __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t, Real (&z)[N])
@@ -265,6 +342,14 @@ struct GenExternal {
             z[j] = idx < w.ext_per_unit ? p[idx] : (Real)0;
         }
     }
+    struct Carry {};
+    __device__ __forceinline__ void pair(const Work &w, uint32_t unit_lo, uint32_t, uint32_t P, Carry &, double &z0, double &z1)
+    {
+        const double *p = static_cast<const double *>(w.ext) + (size_t)(unit_lo - w.unit_lo) * w.ext_per_unit;
+        z0 = 2u * P < w.ext_per_unit ? p[2u * P] : 0.0;
+        z1 = 2u * P + 1u < w.ext_per_unit ? p[2u * P + 1u] : 0.0;
+    }
+    __device__ __forceinline__ void pairs_done(uint32_t) {}
 };
 
 // Start states of XORWOW lanes [0, lanes): the seeded state (5 xorshift words + Weyl word, prepared on the host)

@@ -274,7 +274,7 @@ class Engine:
         return self._paths("cva", precision, _as_cva(precision, c), seed, first_path, n_paths)
 
     def normals(self, seed, domain, first_unit, n_units, block=0, precision="f64"):
-        npb = 4 if (precision == "f32" or getattr(self, "_normals_f32", False)) else 2
+        npb = 4 if (precision == "f32" or getattr(self, "_normals_f32", False)) else 8
         out = np.empty(n_units * npb, dtype=NP[precision])
         check(getattr(lib(), f"mc_normals_{precision}")(self._ctx, seed, domain, first_unit, n_units, block,
                                                          out.ctypes.data_as(C.POINTER(_lib.CT[precision]))))

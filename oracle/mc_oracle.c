@@ -211,5 +211,5 @@ void orc_closing(double sum, double sum2, long long n, double discount, double *
 #define LOG_R log
 #define EXP_R exp
 #define ORC_IS_F32 0
-#define ORC_NPB 2
+#define ORC_NPB 8
 #include "mc_oracle_impl.h"

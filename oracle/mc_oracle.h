@@ -144,10 +144,10 @@ void orc_closing(double sum, double sum2, long long n, double discount,
 ORC_DECL(f32, float)
 ORC_DECL(f64, double)
 
-/* Number of normals one Philox block yields: 4 in f32 (one u32 per uniform), 2 in f64
- * (two u32 per uniform). */
+/* Normals per block of the stream: f32 4 (one Philox block, one u32 per uniform); f64 8 (THREE Philox blocks, 96 bits per
+ * Box-Muller pair: stream version 2, include/mc_mi355x.h MC_STREAM_VERSION). */
 #define ORC_NORMALS_PER_BLOCK_F32 4
-#define ORC_NORMALS_PER_BLOCK_F64 2
+#define ORC_NORMALS_PER_BLOCK_F64 8
 
 #ifdef __cplusplus
 }

@@ -277,15 +277,16 @@ void FN(orc_ref_close)(const REAL *values, int paths, int discounted, REAL r, RE
 /*  Product random stream (Philox4x32-10, counter-based) + reference DEVICE formulas       */
 /* ===================================================================================== */
 
-/* One Philox block -> NPB normals (NPB = 4 in f32, 2 in f64) by two-branch Box-Muller.
+/* One block of the stream -> NPB normals (f32: one Philox block, 4; f64: three Philox blocks, 8) by two-branch Box-Muller.
  *   counter = { unit_hi, unit_lo, block, domain },  key = { seed_lo, seed_hi }   (mc_rng.hpp: philox_unit)
- * f32: radius uniform u_a = fma(x, 2^-32, 2^-33) in (0,1], angle u_b = 1 + (x >> 9) 2^-23 revolutions;  f64: u = ((x_hi:x_lo >> 12) + 0.5) 2^-52 in (0,1)
+ * f32: radius uniform u_a = fma(x, 2^-32, 2^-33) in (0,1], angle u_b = 1 + (x >> 9) 2^-23 revolutions;  f64: see the body (8 normals from 3 Philox blocks)
  *   radius = sqrt(-2 ln u_a),  z_even = radius cos(2 pi u_b),  z_odd = radius sin(2 pi u_b)
  * The f32 radius is written with log2 (the HIP kernel's v_log_f32 is a base-2 log). */
 static void FN(dev_normals_native)(uint64_t seed, uint32_t domain, uint64_t unit, uint32_t block, REAL *z)
 {
     uint32_t x[4];
-    orc_block_words(seed, domain, unit, block, x);   /* Philox(counter, key), or the owning lane's XORWOW sequence */
+    /* Philox(counter, key), or the owning lane's XORWOW sequence; fp64 draws the block's other eight words below */
+    orc_block_words(seed, domain, unit, ORC_IS_F32 ? block : 3 * block, x);
 #if ORC_IS_F32
     for (int h = 0; h < 2; h++) {
         float ua = fmaf((float)x[2 * h], 0x1p-32f, 0x1p-33f);
@@ -299,14 +300,25 @@ static void FN(dev_normals_native)(uint64_t seed, uint32_t domain, uint64_t unit
         z[2 * h + 1] = radius * (float)sin(ang);
     }
 #else
-    uint64_t ka = ((uint64_t)x[1] << 20) | (x[0] >> 12);
-    uint64_t kb = ((uint64_t)x[3] << 20) | (x[2] >> 12);
-    double ua = ((double)ka + 0.5) * 0x1p-52;
-    double ub = ((double)kb + 0.5) * 0x1p-52;
-    double radius = sqrt(-2.0 * log(ua));
-    double ang = 2.0 * M_PI * ub;
-    z[0] = radius * cos(ang);
-    z[1] = radius * sin(ang);
+    /* fp64, stream version 2: block b = Philox blocks 3b, 3b + 1, 3b + 2 = twelve words W[0..11] = four Box-Muller pairs of
+     * 96 bits (mc_rng.hpp: words_to_normals).  Pair p: a = W[3p], m = W[3p + 1], c = W[3p + 2];
+     *   radius uniform  u_a = (J + 1/2) 2^-52,      J  = (a << 20) | (m >> 12)              52 bits
+     *   angle uniform   u_b = (J' 2^8 + 1/2) 2^-52, J' = (c << 12) | (m & 0xfff)            44 bits */
+    uint32_t W[12];
+    memcpy(W, x, sizeof x);
+    orc_block_words(seed, domain, unit, 3 * block + 1, W + 4);
+    orc_block_words(seed, domain, unit, 3 * block + 2, W + 8);
+    for (int p = 0; p < 4; p++) {
+        uint32_t a = W[3 * p], m = W[3 * p + 1], c = W[3 * p + 2];
+        uint64_t ka = ((uint64_t)a << 20) | (m >> 12);
+        uint64_t kb = (((uint64_t)c << 12) | (m & 0xfffu)) << 8;
+        double ua = ((double)ka + 0.5) * 0x1p-52;
+        double ub = ((double)kb + 0.5) * 0x1p-52;
+        double radius = sqrt(-2.0 * log(ua));
+        double ang = 2.0 * M_PI * ub;
+        z[2 * p] = radius * cos(ang);
+        z[2 * p + 1] = radius * sin(ang);
+    }
 #endif
 }
 
@@ -348,7 +360,7 @@ typedef struct {
     uint64_t have_unit;
     uint32_t have_block;
     int have;
-    REAL z[4];
+    REAL z[8];
 } FN(nsrc);
 
 static FN(nsrc) FN(nsrc_stream)(uint64_t seed, uint32_t domain)
@@ -629,8 +641,8 @@ void FN(orc_dev_basket)(int n, const REAL *s, const REAL *v, const REAL *p, cons
 {
     const int npb = FN(orc_dev_npb)();
     int n_draw = (n + npb - 1) / npb * npb;
-    if (orc_xorwow_active())
-        n_draw = 4 * ((n + 3) / 4);
+    if (orc_xorwow_active())   /* the generic kernel pads n to a multiple of 4, then to whole blocks: the lane's sequence moves on */
+        n_draw = (4 * ((n + 3) / 4) + npb - 1) / npb * npb;
     FN(nsrc) src = FN(nsrc_stream)(seed, ORC_DOMAIN_BASKET);
     FN(dev_basket_core)(n, s, v, p, d, w, k, t, r, &src, n_draw, first_path, n_paths, mode & 3, payoffs, out);
 }

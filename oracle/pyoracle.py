@@ -25,7 +25,7 @@ LIB_PATH = os.path.join(HERE, "liboracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 
 DOMAIN_VANILLA, DOMAIN_BASKET, DOMAIN_CVA = 1, 2, 3
-NPB = {"f32": 4, "f64": 2}
+NPB = {"f32": 4, "f64": 8}   # normals per block of the stream (f64: three Philox blocks, stream version 2)
 CT = {"f32": C.c_float, "f64": C.c_double}
 NP = {"f32": np.float32, "f64": np.float64}
 
@@ -239,12 +239,12 @@ def host_cva(X, c, paths, seed):
 
 
 def dev_npb(X):
-    """Normals per block the orc_dev_* family of precision X currently draws (4; 2 in native fp64)."""
+    """Normals per block the orc_dev_* family of precision X currently draws (4; 8 in native fp64)."""
     return int(getattr(lib(), f"orc_dev_npb_{X}")())
 
 
 def dev_normals(X, seed, domain, unit, block):
-    out = np.zeros(4, dtype=NP[X])
+    out = np.zeros(8, dtype=NP[X])
     getattr(lib(), f"orc_dev_normals_{X}")(seed, domain, unit, block,
                                            out.ctypes.data_as(C.POINTER(CT[X])))
     return out[:dev_npb(X)].copy()
