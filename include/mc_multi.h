@@ -52,6 +52,8 @@ mc_context *mc_multi_context(mc_multi *m, int i);
 /* estimator switches, applied to every device (mc_context_set_antithetic / _control_variate) */
 int mc_multi_set_antithetic(mc_multi *m, int on);
 int mc_multi_set_control_variate(mc_multi *m, int on);
+/* normals of the fp64 kernels on every device (mc_context_set_normals: MC_NORMALS_NATIVE or MC_NORMALS_F32) */
+int mc_multi_set_normals(mc_multi *m, int mode);
 /* generator of every device (mc_context_set_generator); under MC_RNG_XORWOW device g's lanes run the subsequences
  * subsequence_base + (lanes of devices 0..g-1) + lane, so that no two lanes of the job share a sequence */
 int mc_multi_set_generator(mc_multi *m, int generator, uint64_t subsequence_base);

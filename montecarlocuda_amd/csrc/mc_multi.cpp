@@ -173,6 +173,14 @@ extern "C" int mc_multi_set_control_variate(mc_multi *m, int on)
     m->control = on != 0;
     return MC_OK;
 }
+extern "C" int mc_multi_set_normals(mc_multi *m, int mode)
+{
+    if (!m) return fail(MC_ERR_INVALID, "NULL handle");
+    for (size_t g = 0; g < m->ctx.size(); ++g)
+        if (mc_context_set_normals(m->ctx[g], mode) != MC_OK)
+            return fail(MC_ERR_INVALID, "device %d: %s", m->devices[g], mc_last_error());
+    return MC_OK;
+}
 // XORWOW runs one sequence per lane: device g's lanes take the subsequences after those of devices 0 .. g-1, so no two
 // lanes of the job share one (with Philox there is nothing to partition: the counter is the global path index).
 extern "C" int mc_multi_set_generator(mc_multi *m, int generator, uint64_t subsequence_base)

@@ -58,7 +58,7 @@ text = "\n".join(lines)
 print(text)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{w}.txt"), "w").write(
-    f"# rocprofv3 --pmc passes of `python3 bench.py --workload {w} --steps 20 --warmup 2` (tools/collect_pmc.sh)\n" + text + "\n")
+    f"# rocprofv3 --pmc passes of `python3 bench.py --workload {w} --steps 20 --warmup 2 --regions 1` (tools/collect_pmc.sh)\n" + text + "\n")
 main = [k for k in summary if "finish" not in k and "masked" not in k]
 if main and "FETCH_SIZE" in summary[main[0]]:
     a = summary[main[0]]
