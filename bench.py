@@ -16,9 +16,14 @@ triple).  Steps rotate over `--streams` (default 2) independent context/stream p
 pricing call's launch gap, ramp and tail overlap the next call's kernel -- fixed per-call costs
 (~7 us of a ~57 us lone call) are hidden, each call is still one full launch.
 The triples of `--bucket` consecutive steps are all-reduced as ONE message (fewer, larger
-collectives: a 24-byte all-reduce is pure latency), asynchronously on RCCL's stream while the
-launch streams keep simulating; every bucket is waited for inside the timed region.
+collectives: a 24-byte all-reduce is pure latency), asynchronously to the launch streams, which
+keep simulating; every bucket is waited for inside the timed region.
 Before the W warm-up steps the same kernel runs untimed for --preheat-ms (clock ramp; reported).
+The timed region of exactly K steps is repeated --regions (5) times back to back, each bracketed by
+barrier + torch.cuda.synchronize() on both sides with the MAX over ranks taken; ms_per_step, value
+and timed_region_s are the MEDIAN region's (min / max / all regions reported beside them).  At N > 1
+over RCCL the barrier that closes a region is the all-reduce of its last bucket of triples (an
+all-reduce is a barrier; --closing barrier adds a separate dist.barrier()).
 
 Reported besides the contract fields:
   roofline      dominant kernel (the simulation kernel): achieved = algorithmic flop per launch (SURVEY 8d:
@@ -329,6 +334,10 @@ def main():
     ap.add_argument("--collective", default="sync", choices=["sync", "async"],
                     help="N > 1, RCCL: the bucket all-reduce as a synchronous-mode collective on torch's current stream (default) or "
                          "async_op=True on the process group's internal stream")
+    ap.add_argument("--closing", default="collective", choices=["collective", "barrier"],
+                    help="N > 1 over RCCL: what closes a timed region.  collective (default): the all-reduce of the region's last "
+                         "bucket of triples, which is a barrier (no rank's completes before every rank has entered it), then "
+                         "torch.cuda.synchronize().  barrier: that all-reduce, then a separate dist.barrier(), then the synchronize")
     ap.add_argument("--bucket", type=int, default=25,
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
@@ -408,12 +417,13 @@ def main():
         shard_first, shard_count = rank * paths, paths
         step_total = world * paths
 
-    def step(i):
+    def step(i, last_of_region=False):
         first = i * step_total + shard_first
         e = i % len(engines)
         engines[e].launch(prod, X, structs[e][0], seed, first, shard_count, triples[i].data_ptr(), launch_streams[e])
         pending[1] = i + 1
-        if pending[1] - pending[0] >= max(1, args.bucket):
+        # a region's last step never flushes here: its bucket is flushed by the region's closing collective (below)
+        if pending[1] - pending[0] >= max(1, args.bucket) and not last_of_region:
             flush_bucket()
 
     def drain(host_sync=True):
@@ -437,6 +447,21 @@ def main():
         if grouped:
             dist.barrier(device_ids=[local]) if args.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
+
+    # N > 1 over RCCL: the barrier that closes a timed region IS the all-reduce of the region's last bucket of triples.
+    # An all-reduce is a barrier -- no rank's copy completes before every rank has entered it, and a rank enters it only
+    # behind its own last step (mc_context_order) -- so `all-reduce; torch.cuda.synchronize()` is the contract's
+    # "barrier + synchronize" with one collective instead of two (dist.barrier() is itself a one-element all-reduce:
+    # ~30 us more per region, 3 % of the driver's 20-step region).  --closing barrier restores the separate one.
+    closing_is_collective = grouped and args.backend == "nccl" and args.closing == "collective" and args.collective == "sync"
+
+    def close_region():
+        if closing_is_collective:
+            flush_bucket()               # >= 1 step pending: step() never flushes a region's last step
+            torch.cuda.synchronize()     # launch streams, torch's stream (the all-reduce), everything
+        else:
+            drain(host_sync=not grouped)   # N > 1: RCCL's barrier queues right behind the last bucket's all-reduce
+            barrier()
 
     preheat_ms = 0.0
     if args.preheat_ms > 0:
@@ -462,18 +487,17 @@ def main():
     for r_ in range(R):
         barrier()
         t0 = time.perf_counter()
-        for i in range(W + r_ * K, W + (r_ + 1) * K):
-            step(i)
+        last = W + (r_ + 1) * K - 1
+        for i in range(W + r_ * K, last + 1):
+            step(i, last_of_region=(i == last))
         t_enqueued = time.perf_counter()
-        drain(host_sync=not grouped)   # N > 1: RCCL's barrier queues right behind the last bucket's all-reduce
+        close_region()
         t_drained = time.perf_counter()
-        barrier()
         el = time.perf_counter() - t0
         for w in works:          # complete since the barrier (same RCCL stream, earlier in order): orders torch's stream, costs nothing
             w.wait()
         works.clear()
-        host_sides.append({"enqueue_K_steps_ms": (t_enqueued - t0) * 1e3, "drain_ms": (t_drained - t_enqueued) * 1e3,
-                           "closing_barrier_ms": (t0 + el - t_drained) * 1e3})
+        host_sides.append({"enqueue_K_steps_ms": (t_enqueued - t0) * 1e3, "close_region_ms": (t_drained - t_enqueued) * 1e3})
         region_s.append(el)
     samples, kernel_ms_total = eng.profile_read()
     eng.profile(0)
@@ -485,8 +509,8 @@ def main():
     median_region = order[(R - 1) // 2]
     elapsed = region_s[median_region]
     host_side = dict(host_sides[median_region],
-                     what="host wall-clock inside the median timed region of this rank: launching the K steps (asynchronous), the last "
-                          "bucket's all-reduce + waits, the closing barrier + synchronize")
+                     what="host wall-clock inside the median timed region of this rank: launching the K steps (asynchronous), then "
+                          "closing the region (last bucket's all-reduce = the closing barrier at N > 1, and the synchronize)")
 
     # The dominant kernel alone on the device (outside the timed region): with 2 streams the timed launches
     # overlap their neighbours, which stretches every per-kernel duration.
@@ -589,7 +613,10 @@ def main():
                        "parallelism": f"path-sharded x{world}, all-reduce of the fp64 (sum,sum2,n) triples, {args.bucket} steps per message",
                        "rng": "Philox4x32-10 + Box-Muller, counter = global path index", "seed": hex(seed),
                        "grid": f"{eng.blocks}x256", "streams": len(engines), "stream_source": args.stream_source,
-                       "finish": args.finish, "preheat_ms": round(preheat_ms, 1), **({"engine_settings": settings} if settings else {})},
+                       "finish": args.finish, "preheat_ms": round(preheat_ms, 1),
+                       "region_bracket": ("opening: dist.barrier + torch.cuda.synchronize; closing: all-reduce of the last bucket of triples "
+                                          "(a barrier by construction) + torch.cuda.synchronize" if closing_is_collective else
+                                          "barrier + torch.cuda.synchronize on both sides"), **({"engine_settings": settings} if settings else {})},
             "price": price, "confidence_95": ci, "paths_priced": int(tot[2]),
             "roofline": {"bound": "valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": (ach / peak) if ach else None,
