@@ -218,16 +218,26 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
         for r_ in range(-2, reps):
             barrier()
             t0 = time.perf_counter()
-            # launch, RCCL and the read-back all on torch's current stream (a handle torch owns): no hop between streams
+            # launch, RCCL and the read-back all on torch's current stream (a handle torch owns): no hop between streams.
+            # The result comes back the way libmc_multi reads its devices: the last workgroup (N = 1) or a one-lane kernel
+            # behind the all-reduce (RCCL) stores the triple into pinned host memory and this thread polls it from user
+            # space -- no copy command, no sleeping synchronize (mc_context_arm_direct / mc_context_publish).
+            direct = count > 0 and (not grouped or backend == "nccl")
+            slot = eng.arm_direct() if (direct and not grouped) else None
             if count:
                 eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), stream.cuda_stream)
             else:
                 out.zero_()
             if grouped and backend == "nccl":
                 dist.all_reduce(out, op=dist.ReduceOp.SUM)      # RCCL, ordered behind the launch (current stream)
-            pinned.copy_(out, non_blocking=True)                # 24 bytes into pinned host memory
-            stream.synchronize()
-            host = pinned.clone()
+                if direct:
+                    slot = eng.publish(out.data_ptr(), stream.cuda_stream)
+            if slot is not None:
+                host = torch.tensor(eng.wait_slot(slot), dtype=torch.float64)
+            else:
+                pinned.copy_(out, non_blocking=True)            # 24 bytes into pinned host memory
+                stream.synchronize()
+                host = pinned.clone()
             if grouped and backend != "nccl":
                 dist.all_reduce(host, op=dist.ReduceOp.SUM)
             dt = time.perf_counter() - t0

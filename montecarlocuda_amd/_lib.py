@@ -104,6 +104,8 @@ def _declare(L: C.CDLL) -> C.CDLL:
     L.mc_context_set_timing.argtypes = [ctx, C.c_int]
     L.mc_context_order.argtypes = [ctx, C.c_void_p]
     L.mc_context_idle.argtypes = [ctx]
+    L.mc_context_arm_direct.argtypes = [ctx, C.POINTER(C.POINTER(C.c_double))]
+    L.mc_context_publish.argtypes = [ctx, C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(C.c_double))]
     L.mc_context_set_generator.argtypes = [ctx, C.c_int, C.c_uint64]
     L.mc_context_set_normals.argtypes = [ctx, C.c_int]
     L.mc_xorwow_words.argtypes = [ctx, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]

@@ -158,6 +158,32 @@ class Engine:
             raise _lib.McError("mc_context_idle failed")
         return r == 1
 
+    def arm_direct(self):
+        """The NEXT launch() also delivers its triple into a pinned host slot (mc_context_arm_direct).  Returns the slot
+        (ctypes pointer to 3 doubles, word 2 preset to -1): poll with wait_slot()."""
+        slot = C.POINTER(C.c_double)()
+        check(lib().mc_context_arm_direct(self._ctx, C.byref(slot)))
+        return slot
+
+    def publish(self, d_src_ptr: int, stream: int):
+        """Enqueue on `stream` the copy of the 3 doubles at device address d_src_ptr into a pinned host slot
+        (mc_context_publish): how a triple that another kernel produced -- an all-reduce -- reaches a polling host."""
+        slot = C.POINTER(C.c_double)()
+        check(lib().mc_context_publish(self._ctx, C.c_void_p(d_src_ptr), C.c_void_p(stream), C.byref(slot)))
+        return slot
+
+    @staticmethod
+    def wait_slot(slot, timeout_s: float = 30.0):
+        """Poll a slot from user space until its n word is written; returns (sum, sum2, n)."""
+        import time
+        t0 = time.perf_counter()
+        spins = 0
+        while slot[2] == -1.0:
+            spins += 1
+            if (spins & 0xFFFF) == 0 and time.perf_counter() - t0 > timeout_s:
+                raise _lib.McError("the device never delivered the result")
+        return slot[0], slot[1], slot[2]
+
     def set_timing(self, on: bool):
         """Synchronous calls: HIP events + copy + synchronize (kernel_ms reported; default) or, off, the result written
         straight to pinned host memory and polled from user space (kernel_ms = 0, ~10 us less per call)."""
