@@ -42,6 +42,7 @@ using namespace mc;
 // context
 // ---------------------------------------------------------------------------------------
 static constexpr int MAX_SEGMENTS = 8;  // per call: segments of <= 2^31 units, same high word
+static constexpr int MAX_GRID_SCALE = 6; // the heaviest kernels launch up to this many times the context's `blocks` (grid_for)
 
 struct mc_context {
     int device = 0;
@@ -163,7 +164,7 @@ static int quiesce(mc_context *c)
 static int context_allocate(mc_context *c)
 {
     HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIPCHK(hipMalloc(&c->partials, sizeof(double2) * ((size_t)MAX_SEGMENTS * c->blocks + 2)));
+    HIPCHK(hipMalloc(&c->partials, sizeof(double2) * ((size_t)MAX_SEGMENTS * c->blocks * MAX_GRID_SCALE + 2)));
     HIPCHK(hipMalloc(&c->tickets, sizeof(uint32_t) * TICKET_WORDS));
     HIPCHK(hipMemset(c->tickets, 0, sizeof(uint32_t) * TICKET_WORDS));
     HIPCHK(hipMalloc(&c->d_triple, 3 * sizeof(double)));
@@ -433,11 +434,23 @@ static Work context_work(const mc_context *c, uint64_t seed, const Segment &s, u
     return w;
 }
 
-static int grid_for(const mc_context *c, uint32_t n_units)
+// Workgroups of a launch over n_units units: one lane per unit until the grid reaches `scale` x the context's `blocks`
+// (default 8 per CU = 2048), grid-stride beyond.  `scale` (halves: 2 = 1x) grows with the weight of a unit.  All workgroups
+// of a launch do equal work, but they do not finish together (CUs and XCDs run at slightly different rates, and a kernel
+// whose registers admit only 4-6 workgroups per CU runs the grid in several rounds): more, smaller workgroups even that
+// out.  Measured at the BASELINE sizes, grids of 4 ... 64 per CU interleaved in one process
+// (tools/grid_sweep_all.py, profiles/r03_grid_sweep.log), kernel time against 8 per CU:
+//     vanilla f32, basket f32 <= 12 assets    8 per CU is the optimum (16: +1...3 %)
+//     vanilla f64, CVA f64 / f32             12 per CU: -1.0 / -1.9 / -1.7 %  (flat beyond; vanilla worse from 32)
+//     tiled basket f32 (13..32 assets)       24 per CU: -1.8 %
+//     tiled basket f64 (9..32 assets)        48 per CU: -4.2 %  (C4's kernel: still improving slowly at 64)
+// The XORWOW policy keeps 1x (its per-lane states are sized by `blocks`), so do the secondary (Greeks) kernels.
+static int grid_for(const mc_context *c, uint32_t n_units, int scale_halves = 2)
 {
-    uint64_t need = ((uint64_t)n_units + GROUP - 1) / GROUP;
-    return (int)(need < (uint64_t)c->blocks ? (need ? need : 1) : c->blocks);
+    const uint64_t need = ((uint64_t)n_units + GROUP - 1) / GROUP, cap = (uint64_t)c->blocks * (uint64_t)scale_halves / 2;
+    return (int)(need < cap ? (need ? need : 1) : cap);
 }
+constexpr int GRID_SCALE_VANILLA_F64 = 3, GRID_SCALE_CVA = 3, GRID_SCALE_TILED_F32 = 6, GRID_SCALE_TILED_F64 = 2 * MAX_GRID_SCALE;
 
 // Vanilla launches whose units are cheap (4 or 2 paths each): a SMALL call is dominated by what grows with the grid --
 // dispatch, one pair and one ticket per workgroup, the last arriver's sum over the pairs -- not by the simulation.  So a
@@ -455,9 +468,9 @@ static int vanilla_units_per_lane()
     }();
     return v;
 }
-static int grid_for_vanilla(const mc_context *c, uint32_t n_units)
+static int grid_for_vanilla(const mc_context *c, uint32_t n_units, int scale_halves)
 {
-    const int full = grid_for(c, n_units);
+    const int full = grid_for(c, n_units, scale_halves);
     const uint64_t per = (uint64_t)GROUP * (uint64_t)vanilla_units_per_lane();
     uint64_t want = ((uint64_t)n_units + per - 1) / per;
     const uint64_t floor_wgs = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256);
@@ -937,7 +950,8 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     }
     if (c->ext && (segs.size() > 1 || first != 0))
         return fail(MC_ERR_INVALID, "external normals: one segment starting at path 0");
-    const auto grid = [&](uint32_t units) { return out ? grid_for(c, units) : grid_for_vanilla(c, units); };
+    const int scale = (sizeof(Real) == 8 && !c->ext) ? GRID_SCALE_VANILLA_F64 : 2;
+    const auto grid = [&](uint32_t units) { return out ? grid_for(c, units) : grid_for_vanilla(c, units, scale); };
     int total = (has_head ? 1 : 0) + (has_tail ? 1 : 0);
     for (const Segment &s : segs)
         total += grid(s.count);
@@ -1406,14 +1420,16 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
         return fail(MC_ERR_UNSUPPORTED, "basket: no kernel for this generator / estimator / size combination");
     if (lds)
         HIPCHK(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // the tiled (register-resident) kernels launch more, smaller workgroups (grid_for); the generic ones keep 1x
+    const int scale = (lds == 0 && tiled_ok && gen != GEN_XORWOW) ? (sizeof(Real) == 8 ? GRID_SCALE_TILED_F64 : GRID_SCALE_TILED_F32) : 2;
     int total = 0, slot = 0;
     for (const Segment &s : segs)
-        total += grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
+        total += grid_for(c, pairs ? (s.count + 1) / 2 : s.count, scale);
     Tail tail = make_tail(c, total, 1.0, 1.0, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = context_work(c, seed, s, 0, 0);
-        const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count);
+        const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count, scale);
         tail.slot_base = tail.ticket_base = (uint32_t)slot;
         launch_sim_lds(prof, kernel, g, lds, st, tail, k, w, out ? out + done : (Real *)nullptr);
         slot += g;
@@ -1593,9 +1609,10 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     if (int rc = cva_table_ready<Real>(c, v, st, args)) return rc;
     std::vector<Segment> segs;
     if (int rc = plan_segments(first, n, segs)) return rc;
+    const int scale = (c->rng == MC_RNG_XORWOW && !c->ext) ? 2 : GRID_SCALE_CVA;
     int total = 0, slot = 0;
     for (const Segment &s : segs)
-        total += grid_for(c, s.count);
+        total += grid_for(c, s.count, scale);
     Tail t = make_tail(c, total, 1.0, 1.0, n, d_triple);
     uint64_t done = 0;
     ProfileScope prof(c);
@@ -1609,7 +1626,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     }
     for (const Segment &s : segs) {
         const Work w = context_work(c, seed, s, 0, 0);
-        const int g = grid_for(c, s.count);
+        const int g = grid_for(c, s.count, scale);
         t.slot_base = t.ticket_base = (uint32_t)slot;
         Real *dst = out ? out + done : (Real *)nullptr;
         constexpr unsigned ALLOW = GEN_PHILOX | GEN_XORWOW | GEN_EXTERNAL | (sizeof(Real) == 8 ? GEN_F32N : 0);
