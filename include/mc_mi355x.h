@@ -213,7 +213,8 @@ int mc_context_order(mc_context *ctx, void *stream);
  * pinned, host-coherent slot the context owns -- n last, with system-scope release semantics.  *slot = the slot's host
  * address; its word 2 is preset to -1 (n is never negative): poll `(*slot)[2] != -1` from user space, then read the
  * three doubles.  No D2H copy command, no event, no sleeping synchronize; d_triple is still written.  One armed launch in
- * flight per context; needs the fused final reduction (the default).
+ * flight per context; a synchronous mc_*_run_* call before the launch cancels the arming; needs the fused final
+ * reduction (the default).
  * mc_context_publish: enqueues on `stream` a one-lane kernel that copies the three doubles at d_src (device memory: e.g.
  * the output of an all-reduce enqueued on that stream before it) into a second slot of the context, same protocol. */
 int mc_context_arm_direct(mc_context *ctx, const volatile double **slot);

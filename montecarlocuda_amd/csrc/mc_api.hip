@@ -1757,6 +1757,7 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
 {
     const auto wall0 = std::chrono::steady_clock::now();
     HIPCHK(hipSetDevice(c->device));
+    c->armed = false;   // mc_context_arm_direct applies to the next mc_*_launch_* only: a synchronous call in between cancels it
     float ms = 0;
     const double *h = c->h_triple;
     if (!c->timing && c->fused) {

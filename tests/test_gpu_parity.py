@@ -490,6 +490,41 @@ def test_async_launches_are_graph_capturable(mc):
     eng.close()
 
 
+def test_armed_launch_and_publish_deliver_into_pinned_slots(mc):
+    """mc_context_arm_direct / mc_context_publish (what libmc_multi and bench.py's strong rows read results back with):
+    the next asynchronous launch's last workgroup stores the triple into pinned host memory, a one-lane kernel does the
+    same for any device triple; the host polls the n word.  Bits equal the synchronous call's; the sentinel is reset per
+    call; a synchronous call in between cancels a pending arming."""
+    torch = pytest.importorskip("torch")
+    eng = mc.Engine(0)
+    out = torch.zeros(3, dtype=torch.float64, device="cuda")
+    for prod, X, inputs, n in (("vanilla", "f32", VAN, 10 ** 6 + 3), ("basket", "f64", basket_inputs(mc, 16, "f64"), 30001),
+                               ("cva", "f64", dict(CVA0, n_grid=64), 5000)):
+        ref = getattr(eng, prod)(inputs, n, SEED, 7, X)
+        struct, keep = eng.prepared(prod, X, inputs)
+        for rep in range(40):
+            slot = eng.arm_direct()
+            assert slot[2] == -1.0
+            eng.launch(prod, X, struct, SEED, 7, n, out.data_ptr(), eng.stream)
+            s, q, cnt = eng.wait_slot(slot)
+            assert (s, q, cnt) == (ref.sum, ref.sum2, float(n))
+        torch.cuda.synchronize()
+        assert out.tolist() == [ref.sum, ref.sum2, float(n)]          # d_triple is written as well
+        pub = eng.publish(out.data_ptr(), eng.stream)
+        assert eng.wait_slot(pub) == (ref.sum, ref.sum2, float(n))
+    # an arming followed by a synchronous call is cancelled: the later launch must not touch the slot
+    slot = eng.arm_direct()
+    eng.vanilla(VAN, 4096, SEED, 0, "f32")
+    struct, keep = eng.prepared("vanilla", "f32", VAN)
+    eng.launch("vanilla", "f32", struct, SEED, 0, 4096, out.data_ptr(), eng.stream)
+    torch.cuda.synchronize()
+    assert slot[2] == -1.0
+    eng.set_finish(False)     # the two-launch form has no last arriver to do it
+    with pytest.raises(mc.McError, match="fused"):
+        eng.arm_direct()
+    eng.close()
+
+
 @pytest.mark.parametrize("X", ["f32", "f64"])
 @pytest.mark.parametrize("n_assets", [17, 24, 30, 33, 64])
 def test_generic_basket_beyond_compiled_sizes(mc, eng, po, X, n_assets):
