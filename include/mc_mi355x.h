@@ -334,6 +334,36 @@ int mc_cva_from_normals_f32(mc_context *ctx, const mc_cva_f32 *cva, const float 
 int mc_cva_from_normals_f64(mc_context *ctx, const mc_cva_f64 *cva, const double *h_normals, uint64_t n_paths,
                             int flags, double *h_values, mc_result *out);
 
+/* ---- compatibility mode: the reference's launch geometry and per-thread XORWOW streams ---------------------------
+ * The reference's result depends on (numBlocks, numThreads): dp/MonteCarloKernel.cu:285-290 gives every thread of the
+ * launch its own cuRAND XORWOW state, curand_init(seed = blockIdx.x + gridDim.x, subsequence = threadIdx.x, offset 0);
+ * thread t of a block prices paths t, t + numThreads, ... < N_PATH of that block (:146,191,240) and draws its normals
+ * with curand_normal() one after the other (two words per Box-Muller pair, the second member kept for the next call;
+ * :68,78,250 -- in the dp build the float normal is widened to double).  These calls reproduce that sample: same seeding
+ * geometry, same thread-to-path assignment, same per-thread order of the draws -- a CVA path draws for the dates whose
+ * `t -= dt` is still >= 0 (:249) -- with the generator and Box-Muller of rocRAND/hipRAND (rocrand_xorwow.h,
+ * rocrand_normal.h), i.e. what a HIP build of the reference draws on this GPU, bit for bit (tests/test_gpu_grid.py).
+ * cuRAND itself seeds XORWOW with other constants and is not in this image: equality with an NVIDIA run of the reference
+ * is NOT claimed ("parity unpinned").
+ *   n = num_blocks * paths_per_block paths are priced (the reference's numBlocks * (sims / numBlocks)).
+ * The normals of the call are first written to HBM (one Real per draw) and then priced by the same simulation kernels as
+ * mc_*_run_* through the external-normals policy; a compatibility path, not a fast one.  Plain estimator only; the
+ * context's generator / normals settings are ignored.  num_threads <= 1024, at most 2^24 threads and 2^31 paths. */
+int mc_vanilla_run_grid_f32(mc_context *ctx, const mc_option_f32 *opt, int num_blocks, int num_threads,
+                            uint64_t paths_per_block, mc_result *out);
+int mc_vanilla_run_grid_f64(mc_context *ctx, const mc_option_f64 *opt, int num_blocks, int num_threads,
+                            uint64_t paths_per_block, mc_result *out);
+int mc_basket_run_grid_f32(mc_context *ctx, const mc_basket_f32 *opt, int num_blocks, int num_threads,
+                           uint64_t paths_per_block, mc_result *out);
+int mc_basket_run_grid_f64(mc_context *ctx, const mc_basket_f64 *opt, int num_blocks, int num_threads,
+                           uint64_t paths_per_block, mc_result *out);
+int mc_cva_run_grid_f32(mc_context *ctx, const mc_cva_f32 *cva, int num_blocks, int num_threads,
+                        uint64_t paths_per_block, mc_result *out);
+int mc_cva_run_grid_f64(mc_context *ctx, const mc_cva_f64 *cva, int num_blocks, int num_threads,
+                        uint64_t paths_per_block, mc_result *out);
+/* The first `count` normals of every thread's stream: h_out[(b * num_threads + t) * count + k] (tests). */
+int mc_grid_normals(mc_context *ctx, int num_blocks, int num_threads, uint32_t count, float *h_out);
+
 /* ---- host-side helpers -------------------------------------------------------------- */
 /* Closing formulas of dp/MonteCarloKernel.cu:420-423 (discount = exp(-rT)) and :466-468
  * (discount = 1), in fp64, from an (all-reduced) triple. */

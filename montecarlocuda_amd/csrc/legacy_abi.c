@@ -21,6 +21,9 @@
  * MC_DEVICES="0,1,2,3" or "all" (every call is sharded over these GPUs of the node and closed by one RCCL
  * all-reduce of the triple: include/mc_multi.h; libmc_multi.so -- and with it RCCL -- is loaded only then),
  * MC_RNG=xorwow (the reference's generator instead of Philox: mc_context_set_generator),
+ * MC_RNG=xorwow_grid (the reference's generator AND its launch geometry: numBlocks and numThreads then shape the sample
+ * as they do in the reference -- one XORWOW state per thread seeded blockIdx + gridDim, thread t pricing paths
+ * t, t + numThreads, ... of its block; mc_*_run_grid_*, include/mc_mi355x.h; one GPU, MC_SEED is not used),
  * MC_ANTITHETIC=1 (antithetic-variates estimator instead of the reference's plain one),
  * MC_CONTROL_VARIATE=1 (dev_basketOpt only: geometric-basket control variate).
  */
@@ -169,6 +172,19 @@ static mc_context *context(void)
     return g_ctx;
 }
 
+/* MC_RNG=xorwow_grid: the calls go through mc_*_run_grid_* with the caller's (numBlocks, numThreads) */
+static int grid_mode(void)
+{
+    const char *r = getenv("MC_RNG");
+    if (!r || strcmp(r, "xorwow_grid"))
+        return 0;
+    if (getenv("MC_DEVICES")) {
+        fprintf(stderr, "Error: MC_RNG=xorwow_grid reproduces a single-GPU launch of the reference; unset MC_DEVICES\n");
+        exit(1);
+    }
+    return 1;
+}
+
 static uint64_t seed(void)
 {
     const char *s = getenv("MC_SEED");
@@ -198,10 +214,15 @@ static OptionValue finish(const mc_result *r, const char *what)
 
 OptionValue dev_vanillaOpt(OptionData *opt, int numBlocks, int numThreads, int sims)
 {
-    (void)numThreads;
+    (void)numThreads;   /* shapes the sample only under MC_RNG=xorwow_grid */
     const api_option o = {opt->s, opt->k, opt->r, opt->v, opt->t};
     mc_result r;
     const uint64_t n = path_count(numBlocks, sims);
+    if (grid_mode()) {
+        if (API(mc_vanilla_run_grid)(context(), &o, numBlocks, numThreads, n / (uint64_t)numBlocks, &r) != MC_OK)
+            die("in dev_vanillaOpt");
+        return finish(&r, "dev_vanillaOpt");
+    }
     if ((multi() ? multi_vanilla(g_multi, &o, seed(), 0, n, &r) : API(mc_vanilla_run)(context(), &o, seed(), 0, n, &r)) != MC_OK)
         die("in dev_vanillaOpt");
     return finish(&r, "dev_vanillaOpt");
@@ -209,11 +230,16 @@ OptionValue dev_vanillaOpt(OptionData *opt, int numBlocks, int numThreads, int s
 
 OptionValue dev_basketOpt(MultiOptionData *option, int numBlocks, int numThreads, int sims)
 {
-    (void)numThreads;
+    (void)numThreads;   /* shapes the sample only under MC_RNG=xorwow_grid */
     const api_basket b = {N, option->s, option->v, &option->p[0][0], option->d, option->w,
                           option->k, option->t, option->r};
     mc_result r;
     const uint64_t n = path_count(numBlocks, sims);
+    if (grid_mode()) {
+        if (API(mc_basket_run_grid)(context(), &b, numBlocks, numThreads, n / (uint64_t)numBlocks, &r) != MC_OK)
+            die("in dev_basketOpt");
+        return finish(&r, "dev_basketOpt");
+    }
     if ((multi() ? multi_basket(g_multi, &b, seed(), 0, n, &r) : API(mc_basket_run)(context(), &b, seed(), 0, n, &r)) != MC_OK)
         die("in dev_basketOpt");
     return finish(&r, "dev_basketOpt");
@@ -221,11 +247,16 @@ OptionValue dev_basketOpt(MultiOptionData *option, int numBlocks, int numThreads
 
 OptionValue dev_cvaEquityOption(CVA *cva, int numBlocks, int numThreads, int sims)
 {
-    (void)numThreads;
+    (void)numThreads;   /* shapes the sample only under MC_RNG=xorwow_grid */
     const api_cva c = {cva->defInt, cva->lgd,
                        {cva->option.s, cva->option.k, cva->option.r, cva->option.v, cva->option.t}, cva->n};
     mc_result r;
     const uint64_t n = path_count(numBlocks, sims);
+    if (grid_mode()) {
+        if (API(mc_cva_run_grid)(context(), &c, numBlocks, numThreads, n / (uint64_t)numBlocks, &r) != MC_OK)
+            die("in dev_cvaEquityOption");
+        return finish(&r, "dev_cvaEquityOption");
+    }
     if ((multi() ? multi_cva(g_multi, &c, seed(), 0, n, &r) : API(mc_cva_run)(context(), &c, seed(), 0, n, &r)) != MC_OK)
         die("in dev_cvaEquityOption");
     return finish(&r, "dev_cvaEquityOption");

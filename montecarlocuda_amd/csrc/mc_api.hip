@@ -85,6 +85,8 @@ struct mc_context {
     uint32_t *d_xorwow_jump = nullptr;   // jump matrices A^(2^67 2^i), i < XORWOW_JUMP_BITS
     bool xorwow_valid = false;           // d_xorwow holds the states of (xorwow_seed, xorwow_state_base)
     uint64_t xorwow_seed = 0, xorwow_state_base = 0;
+    uint32_t *d_grid_states = nullptr;   // launch-geometry mode: one start state per (block, thread) of the cached geometry
+    int grid_blocks = 0, grid_threads = 0;
     bool normals_f32 = false;     // fp64 kernels draw fp32 normals, widened (the reference's dp arithmetic): GenPhiloxF32N
     // external normals (tests only, mc_*_from_normals_*): set around one enqueue
     const void *ext = nullptr;    // device array, ext_per_unit Reals per unit
@@ -227,6 +229,7 @@ extern "C" void mc_context_destroy(mc_context *c)
     (void)hipFree(c->tickets);
     (void)hipFree(c->d_xorwow);
     (void)hipFree(c->d_xorwow_jump);
+    (void)hipFree(c->d_grid_states);
     if (c->last_use) (void)hipEventDestroy(c->last_use);
     (void)hipFree(c->d_triple);
     (void)hipFree(c->g_pairs);
@@ -675,22 +678,23 @@ const std::vector<uint32_t> &xorwow_jump_table()
 }
 }  // namespace
 
-// Start states of `lanes` XORWOW lanes for (seed, base) into `states` (device), enqueued on st.
-static int xorwow_fill(mc_context *c, uint64_t seed, uint64_t base, uint32_t lanes, uint32_t *states, hipStream_t st)
+static int xorwow_jump_ready(mc_context *c)
 {
-    if (base + lanes > (1ull << XORWOW_JUMP_BITS) || base + lanes < base)
-        return fail(MC_ERR_INVALID, "XORWOW: subsequence numbers must stay below 2^%d", XORWOW_JUMP_BITS);
     if (!c->d_xorwow_jump) {
         const std::vector<uint32_t> &t = xorwow_jump_table();
         HIPCHK(hipMalloc(&c->d_xorwow_jump, t.size() * sizeof(uint32_t)));
         HIPCHK(hipMemcpy(c->d_xorwow_jump, t.data(), t.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    // rocRAND's seeding (rocrand_xorwow.h, xorwow_engine constructor): fixed start words scrambled with the seed halves
-    uint32_t x[5] = {123456789u, 362436069u, 521288629u, 88675123u, 5783321u}, d = 6615241u;
-    const uint32_t s0 = (uint32_t)seed ^ 0x2c7f967fu, s1 = (uint32_t)(seed >> 32) ^ 0xa03697cbu;
-    const uint32_t t0 = 1228688033u * s0, t1 = 2073658381u * s1;
-    x[0] += t0, x[1] ^= t0, x[2] += t1, x[3] ^= t1, x[4] += t0, d += t1 + t0;
-    xorwow_init_kernel<<<(lanes + 255) / 256, 256, 0, st>>>(c->d_xorwow_jump, x[0], x[1], x[2], x[3], x[4], d, base, lanes, states);
+    return MC_OK;
+}
+
+// Start states of `lanes` XORWOW lanes for (seed, base) into `states` (device), enqueued on st.
+static int xorwow_fill(mc_context *c, uint64_t seed, uint64_t base, uint32_t lanes, uint32_t *states, hipStream_t st)
+{
+    if (base + lanes > (1ull << XORWOW_JUMP_BITS) || base + lanes < base)
+        return fail(MC_ERR_INVALID, "XORWOW: subsequence numbers must stay below 2^%d", XORWOW_JUMP_BITS);
+    if (int rc = xorwow_jump_ready(c)) return rc;
+    xorwow_init_kernel<<<(lanes + 255) / 256, 256, 0, st>>>(c->d_xorwow_jump, seed, base, lanes, states);
     HIPCHK(hipGetLastError());
     return MC_OK;
 }
@@ -1830,6 +1834,23 @@ static int dump_sync(mc_context *c, uint64_t n, Real *h_out, Enq enqueue)
 // ---------------------------------------------------------------------------------------
 // Uploads the normals into the context's buffer (zero-padded to `padded` Reals), runs `enqueue` with the external-normals
 // policy switched on, synchronously, and -- when h_values is given -- once more through the per-path dump path.
+// the context's external-normals buffer, at least `bytes`, with no earlier kernel still reading it
+static int ensure_ext(mc_context *c, size_t bytes)
+{
+    if (c->d_ext_bytes < bytes) {
+        if (int rc = quiesce(c)) return rc;
+        if (c->d_ext) HIPCHK(hipFree(c->d_ext));
+        c->d_ext = nullptr, c->d_ext_bytes = 0;
+        if (hipMalloc(&c->d_ext, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(MC_ERR_HIP, "external normals: cannot allocate %zu bytes of device memory", bytes);
+        }
+        c->d_ext_bytes = bytes;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));   // a previous call's kernels may still read the buffer
+    return MC_OK;
+}
+
 template <class Real, class Enq>
 static int from_normals_run(mc_context *c, const Real *h_normals, size_t count, size_t padded, uint32_t per_unit, int flags,
                             uint64_t n, double discount, Real *h_values, mc_result *out, Enq enqueue)
@@ -1842,14 +1863,7 @@ static int from_normals_run(mc_context *c, const Real *h_normals, size_t count, 
         return fail(MC_ERR_UNSUPPORTED, "from_normals: plain estimator with the context's default settings only");
     HIPCHK(hipSetDevice(c->device));
     const size_t bytes = padded * sizeof(Real);
-    if (c->d_ext_bytes < bytes) {
-        if (int rc = quiesce(c)) return rc;
-        if (c->d_ext) HIPCHK(hipFree(c->d_ext));
-        c->d_ext = nullptr, c->d_ext_bytes = 0;
-        HIPCHK(hipMalloc(&c->d_ext, bytes));
-        c->d_ext_bytes = bytes;
-    }
-    HIPCHK(hipStreamSynchronize(c->stream));   // a previous call's kernels may still read the buffer
+    if (int rc = ensure_ext(c, bytes)) return rc;
     if (padded > count)
         HIPCHK(hipMemsetAsync(c->d_ext, 0, bytes, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_ext, h_normals, count * sizeof(Real), hipMemcpyHostToDevice, c->stream));
@@ -1909,6 +1923,140 @@ static int from_normals_run(mc_context *c, const Real *h_normals, size_t count, 
                                       n, 1.0, h_values, out, [&](hipStream_t st, double *t, Real *d) {        \
                                           return cva_enqueue<Real>(c, o, 0, 0, n, t, st, d);                  \
                                       });                                                                     \
+    }
+
+// ---------------------------------------------------------------------------------------
+// Compatibility mode: the reference's launch geometry and per-thread XORWOW streams (include/mc_mi355x.h, "launch
+// geometry").  The normals of the whole call are drawn the reference's way -- one XORWOW state per (block, thread),
+// curand_init(blockIdx.x + gridDim.x, threadIdx.x, 0), curand_normal() one after the other, thread t of a block taking
+// paths t, t + T, ... (dp/MonteCarloKernel.cu:285-290,146-150,191-196,240-262) -- into HBM by grid_normals_kernel, and
+// the simulation kernels then price them through the external-normals policy: the payoff, accumulation and closing
+// code is the hot kernels' own.  Memory: one Real per draw (a 1e8-path vanilla call: 0.4 / 0.8 GB).
+// ---------------------------------------------------------------------------------------
+static int grid_check(mc_context *c, const void *opt, int num_blocks, int num_threads, uint64_t paths_per_block, const void *dst, uint64_t *n)
+{
+    if (!c) return fail(MC_ERR_INVALID, "NULL context");
+    if (!opt) return fail(MC_ERR_INVALID, "NULL option");
+    if (!dst) return fail(MC_ERR_INVALID, "NULL output pointer");
+    if (num_blocks < 1 || num_threads < 1 || num_threads > 1024 || (uint64_t)num_blocks * (uint64_t)num_threads > (1u << 24))
+        return fail(MC_ERR_INVALID, "launch geometry: need num_blocks >= 1, 1 <= num_threads <= 1024, at most 2^24 threads in all");
+    if (paths_per_block == 0 || paths_per_block > (1ull << 31) / (uint64_t)num_blocks)
+        return fail(MC_ERR_INVALID, "launch geometry: need 1 <= num_blocks * paths_per_block <= 2^31");
+    if (c->antithetic || c->control)
+        return fail(MC_ERR_UNSUPPORTED, "launch geometry: the reference's plain estimator only");
+    *n = (uint64_t)num_blocks * paths_per_block;
+    return MC_OK;
+}
+
+// the (num_blocks x num_threads) start states, cached in the context per geometry
+static int grid_states_ready(mc_context *c, int num_blocks, int num_threads)
+{
+    const uint32_t lanes = (uint32_t)num_blocks * (uint32_t)num_threads;
+    if (c->grid_blocks == num_blocks && c->grid_threads == num_threads && c->d_grid_states)
+        return MC_OK;
+    if (int rc = xorwow_jump_ready(c)) return rc;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_grid_states) HIPCHK(hipFree(c->d_grid_states));
+    c->d_grid_states = nullptr, c->grid_blocks = c->grid_threads = 0;
+    HIPCHK(hipMalloc(&c->d_grid_states, sizeof(uint32_t) * 6 * (size_t)lanes));
+    xorwow_grid_init_kernel<<<(lanes + 255) / 256, 256, 0, c->stream>>>(c->d_xorwow_jump, (uint32_t)num_blocks, (uint32_t)num_threads,
+                                                                         c->d_grid_states);
+    HIPCHK(hipGetLastError());
+    c->grid_blocks = num_blocks, c->grid_threads = num_threads;
+    return MC_OK;
+}
+
+// `draws` normals per path into rows of `row` Reals (the buffer zero-padded to `padded` Reals in all), then `enqueue` with
+// the external-normals policy reading `per_unit` Reals per unit
+template <class Real, class Enq>
+static int grid_run(mc_context *c, int num_blocks, int num_threads, uint64_t paths_per_block, uint32_t draws, uint32_t row,
+                    uint32_t per_unit, size_t padded, double discount, mc_result *out, Enq enqueue)
+{
+    const uint64_t n = (uint64_t)num_blocks * paths_per_block;
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = ensure_ext(c, padded * sizeof(Real))) return rc;
+    if (int rc = grid_states_ready(c, num_blocks, num_threads)) return rc;
+    if (padded > n * row)
+        HIPCHK(hipMemsetAsync((Real *)c->d_ext + n * row, 0, (padded - n * row) * sizeof(Real), c->stream));
+    const uint32_t lanes = (uint32_t)num_blocks * (uint32_t)num_threads;
+    grid_normals_kernel<Real><<<(lanes + 255) / 256, 256, 0, c->stream>>>(c->d_grid_states, (uint32_t)num_blocks, (uint32_t)num_threads,
+                                                                          paths_per_block, draws, row, (Real *)c->d_ext);
+    HIPCHK(hipGetLastError());
+    const int rng = c->rng, nf32 = c->normals_f32;
+    c->rng = MC_RNG_PHILOX, c->normals_f32 = 0;   // the external policy replaces the generator whatever the context selects
+    c->ext = c->d_ext, c->ext_per_unit = per_unit, c->ext_flags = 0;
+    const int rc = run_sync(c, n, discount, out, [&](hipStream_t st, double *t) { return enqueue(st, t); });
+    c->ext = nullptr, c->ext_per_unit = 0;
+    c->rng = rng, c->normals_f32 = nf32;
+    return rc;
+}
+
+// dates of a CVA path that draw a normal: `t -= dt >= 0` in Real arithmetic (dp/MonteCarloKernel.cu:249; the per-date
+// table of build_cva_table stops at the same date)
+template <class Real>
+static uint32_t cva_draws(Real t, int n_grid)
+{
+    const Real dt = t / n_grid;
+    uint32_t draws = 0;
+    for (int j = 1; j <= n_grid; ++j) {
+        t -= dt;
+        if (!(t >= 0)) break;
+        ++draws;
+    }
+    return draws;
+}
+
+extern "C" int mc_grid_normals(mc_context *c, int num_blocks, int num_threads, uint32_t count, float *h_out)
+{
+    uint64_t n;
+    if (int rc = grid_check(c, h_out, num_blocks, num_threads, 1, h_out, &n)) return rc;
+    const uint64_t lanes = (uint64_t)num_blocks * (uint64_t)num_threads;
+    if (count == 0 || lanes * count > (1ull << 28))
+        return fail(MC_ERR_INVALID, "mc_grid_normals: need 1 <= threads * count <= 2^28");
+    HIPCHK(hipSetDevice(c->device));
+    if (int rc = ensure_ext(c, lanes * count * sizeof(float))) return rc;
+    if (int rc = grid_states_ready(c, num_blocks, num_threads)) return rc;
+    // every thread as the only path of its own row: paths_per_block = num_threads, one path per thread, `count` draws
+    grid_normals_kernel<float><<<((uint32_t)lanes + 255) / 256, 256, 0, c->stream>>>(c->d_grid_states, (uint32_t)num_blocks, (uint32_t)num_threads,
+                                                                                    (uint64_t)num_threads, count, count, (float *)c->d_ext);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_out, c->d_ext, lanes * count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return MC_OK;
+}
+
+#define MC_DEFINE_GRID(X, Real)                                                                                                   \
+    extern "C" int mc_vanilla_run_grid_##X(mc_context *c, const mc_option_##X *o, int num_blocks, int num_threads,               \
+                                           uint64_t paths_per_block, mc_result *out)                                             \
+    {                                                                                                                             \
+        uint64_t n;                                                                                                               \
+        if (int rc = grid_check(c, o, num_blocks, num_threads, paths_per_block, out, &n)) return rc;                              \
+        const uint64_t NPB = GenPhilox::npb<Real>(), units = (n + NPB - 1) / NPB;                                                 \
+        /* a vanilla unit is NPB paths: rows of one normal, read NPB at a time */                                                 \
+        return grid_run<Real>(c, num_blocks, num_threads, paths_per_block, 1, 1, (uint32_t)NPB, units * NPB,                      \
+                              std::exp(-(double)o->r * (double)o->t), out,                                                        \
+                              [&](hipStream_t st, double *t) { return vanilla_enqueue<Real>(c, o, 0, 0, n, t, st, nullptr); });   \
+    }                                                                                                                             \
+    extern "C" int mc_basket_run_grid_##X(mc_context *c, const mc_basket_##X *o, int num_blocks, int num_threads,                \
+                                          uint64_t paths_per_block, mc_result *out)                                              \
+    {                                                                                                                             \
+        uint64_t n;                                                                                                               \
+        if (int rc = grid_check(c, o, num_blocks, num_threads, paths_per_block, out, &n)) return rc;                              \
+        if (o->n < 1 || o->n > MC_MAX_ASSETS_GENERIC) return fail(MC_ERR_INVALID, "basket: bad n");                               \
+        return grid_run<Real>(c, num_blocks, num_threads, paths_per_block, (uint32_t)o->n, (uint32_t)o->n, (uint32_t)o->n,        \
+                              ((size_t)n + 1) * (size_t)o->n, std::exp(-(double)o->r * (double)o->t), out,                        \
+                              [&](hipStream_t st, double *t) { return basket_enqueue<Real>(c, o, 0, 0, n, t, st, nullptr); });    \
+    }                                                                                                                             \
+    extern "C" int mc_cva_run_grid_##X(mc_context *c, const mc_cva_##X *o, int num_blocks, int num_threads,                      \
+                                       uint64_t paths_per_block, mc_result *out)                                                 \
+    {                                                                                                                             \
+        uint64_t n;                                                                                                               \
+        if (int rc = grid_check(c, o, num_blocks, num_threads, paths_per_block, out, &n)) return rc;                              \
+        if (o->n_grid < 1 || o->n_grid > (1 << 20) || !(o->option.t > 0))                                                         \
+            return fail(MC_ERR_INVALID, "cva: bad n_grid or maturity");                                                           \
+        return grid_run<Real>(c, num_blocks, num_threads, paths_per_block, cva_draws<Real>(o->option.t, o->n_grid),               \
+                              (uint32_t)o->n_grid, (uint32_t)o->n_grid, (size_t)n * (size_t)o->n_grid, 1.0, out,                                       \
+                              [&](hipStream_t st, double *t) { return cva_enqueue<Real>(c, o, 0, 0, n, t, st, nullptr); });       \
     }
 
 #define MC_DEFINE_PRODUCT(X, Real)                                                                           \
@@ -2014,4 +2162,6 @@ static int from_normals_run(mc_context *c, const Real *h_normals, size_t count, 
 MC_DEFINE_PRODUCT(f32, float)
 MC_DEFINE_PRODUCT(f64, double)
 MC_DEFINE_FROM_NORMALS(f32, float)
+MC_DEFINE_GRID(f32, float)
 MC_DEFINE_FROM_NORMALS(f64, double)
+MC_DEFINE_GRID(f64, double)

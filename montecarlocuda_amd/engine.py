@@ -306,6 +306,22 @@ class Engine:
                                                          out.ctypes.data_as(C.POINTER(_lib.CT[precision]))))
         return out.reshape(n_units, npb)
 
+    # ---- compatibility mode: the reference's launch geometry and per-thread XORWOW streams (mc_*_run_grid_*) ----
+    def run_grid(self, prod, inputs, num_blocks, num_threads, paths_per_block, precision="f64") -> Estimate:
+        """num_blocks * paths_per_block paths drawn the reference's way (dp/MonteCarloKernel.cu:285-290: one XORWOW state per
+        thread, seed blockIdx + gridDim, subsequence threadIdx; thread t prices paths t, t + T, ... of its block)."""
+        struct, keep = self.prepared(prod, precision, inputs)
+        r = _lib.Result()
+        check(getattr(lib(), f"mc_{prod}_run_grid_{precision}")(self._ctx, C.byref(struct), num_blocks, num_threads, paths_per_block,
+                                                                C.byref(r)))
+        return _estimate(r)
+
+    def grid_normals(self, num_blocks, num_threads, count):
+        """The first `count` normals of every thread's stream: (num_blocks, num_threads, count) float32."""
+        out = np.empty((num_blocks, num_threads, count), dtype=np.float32)
+        check(lib().mc_grid_normals(self._ctx, num_blocks, num_threads, count, out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     # ---- test hooks: the simulation kernels on a caller-supplied normal stream -----------------------
     def _from_normals(self, prod, X, struct, normals, n_paths, flags, want_values):
         z = np.ascontiguousarray(normals, dtype=NP[X]).reshape(-1)

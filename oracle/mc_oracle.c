@@ -128,6 +128,28 @@ uint32_t orc_xorwow_next(uint32_t state[6])
     return state[5] + state[4];
 }
 
+/* The reference's per-thread normal stream under its launch geometry (dp/MonteCarloKernel.cu:285-290: curand_init(seed =
+ * blockIdx.x + gridDim.x, subsequence = threadIdx.x, offset 0); :68,78,250 curand_normal): the first `count` normals of
+ * thread `thread` of block `block` of a launch of `num_blocks` blocks.  cuRAND is not in the image; this follows its AMD
+ * counterpart, which a HIP build of the reference calls: rocrand_normal(rocrand_state_xorwow *) -- two words per
+ * Box-Muller pair, sine member first, cosine member kept for the next call -- and box_muller(x, y) of
+ * rocrand_normal.h (host branch: sinf / cosf), expression for expression.  Pinned against rocRAND's own host-callable
+ * engine by tests/test_rocrand_xcheck.py. */
+void orc_grid_normals(uint32_t num_blocks, uint32_t block, uint32_t thread, uint32_t count, float *out)
+{
+    uint32_t st[6];
+    orc_xorwow_init((uint64_t)block + num_blocks, thread, st);
+    for (uint32_t k = 0; k < count; k += 2) {
+        const unsigned int x = orc_xorwow_next(st), y = orc_xorwow_next(st);
+        const float u = 2.3283064e-10f + (x * 2.3283064e-10f);
+        const float v = 1.46291807e-09f + (y * 1.46291807e-09f);
+        const float s = sqrtf(-2.0f * logf(u));
+        out[k] = sinf(v) * s;
+        if (k + 1 < count)
+            out[k + 1] = cosf(v) * s;
+    }
+}
+
 /* the jump matrices themselves, for the test that compares the product's (computed the same way, independently) */
 void orc_xorwow_jump_column(int i, int c, uint32_t out[5])
 {

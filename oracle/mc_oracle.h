@@ -56,6 +56,7 @@ void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t ou
 void orc_xorwow_init(uint64_t seed, uint64_t subsequence, uint32_t state[6]);
 uint32_t orc_xorwow_next(uint32_t state[6]);
 void orc_xorwow_jump_column(int i, int c, uint32_t out[5]);
+void orc_grid_normals(uint32_t num_blocks, uint32_t block, uint32_t thread, uint32_t count, float *out);
 void orc_xorwow_begin(uint64_t seed, uint64_t subsequence_base, uint32_t lanes, uint64_t unit0);
 void orc_xorwow_end(void);
 

@@ -143,6 +143,40 @@ def xorwow_words(seed, subsequence, count):
     return [int(L.orc_xorwow_next(st)) for _ in range(count)]
 
 
+def grid_normals(num_blocks, num_threads, count):
+    """The reference's launch geometry (dp/MonteCarloKernel.cu:285-290): the first `count` normals of every thread's own
+    XORWOW stream, shape (num_blocks, num_threads, count), float32 (orc_grid_normals)."""
+    L = lib()
+    L.orc_grid_normals.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_float)]
+    L.orc_grid_normals.restype = None
+    out = np.empty((num_blocks, num_threads, count), dtype=np.float32)
+    row = (C.c_float * count)()
+    for b in range(num_blocks):
+        for t in range(num_threads):
+            L.orc_grid_normals(num_blocks, b, t, count, row)
+            out[b, t] = np.frombuffer(row, dtype=np.float32)
+    return out
+
+
+def grid_path_normals(streams, paths_per_block, draws):
+    """Which normals each path of a grid-geometry call gets: thread t of a block prices paths t, t + T, ... < paths_per_block
+    (dp/MonteCarloKernel.cu:146,191,240) and draws `draws` normals for each, one after the other, from its stream
+    (`streams`: (num_blocks, num_threads, >= needed), from grid_normals or the device).  Returns
+    (num_blocks * paths_per_block, draws), path p = b * paths_per_block + i."""
+    G, T, have = streams.shape
+    out = np.empty((G, paths_per_block, draws), dtype=streams.dtype)
+    for t in range(min(T, paths_per_block)):
+        k = len(range(t, paths_per_block, T))
+        assert k * draws <= have
+        out[:, t::T, :] = streams[:, t, :k * draws].reshape(G, k, draws)
+    return out.reshape(G * paths_per_block, draws)
+
+
+def grid_draws_per_thread(num_threads, paths_per_block, draws):
+    """Normals the busiest thread (t = 0) of a block draws."""
+    return len(range(0, paths_per_block, num_threads)) * draws
+
+
 class xorwow_mode:
     """Context manager: inside it the dev_* functions draw their normals from one XORWOW sequence per lane
     (lane l = subsequence base + l prices units unit0 + l, unit0 + l + lanes, ...), like the product's XORWOW mode."""

@@ -63,3 +63,34 @@ def test_oracle_xorwow_equals_rocrand_engine(po, tmp_path):
     assert len(out) == len(cases)
     for (s, sub, c), line in zip(cases, out):
         assert po.xorwow_words(s, sub, c) == [int(x, 16) for x in line.split()], (s, sub)
+
+
+def test_oracle_grid_normals_equal_rocrand_normal(po, tmp_path):
+    """The reference's per-thread normal stream under its launch geometry (dp/MonteCarloKernel.cu:285-290,68: curand_init(
+    blockIdx.x + gridDim.x, threadIdx.x, 0) + curand_normal): the oracle's restatement (orc_grid_normals) against
+    rocRAND's own rocrand_init + rocrand_normal -- what a HIP build of the reference calls -- bit for bit, odd counts
+    (the kept second member of a Box-Muller pair) included."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc) or not os.path.exists("/opt/rocm/include/rocrand/rocrand_normal.h"):
+        pytest.skip("rocRAND headers / hipcc not available")
+    exe = tmp_path / "rocrand_normal_xcheck"
+    subprocess.check_call([hipcc, "-O1", "-w", "-ffp-contract=off", "--offload-arch=gfx950",
+                           os.path.join(ROOT, "tests", "cpp", "rocrand_normal_xcheck.cpp"), "-o", str(exe)])
+    count = 9
+    geoms = [(1, 1), (2, 3), (7, 64), (256, 5)]
+    cases = [(G, T, b, t) for G, T in geoms for b in sorted({0, G // 2, G - 1}) for t in sorted({0, T // 2, T - 1})]
+    text = "".join(f"{b + G} {t} {count}\n" for G, T, b, t in cases)
+    out = subprocess.run([str(exe)], input=text, capture_output=True, text=True, check=True).stdout.strip().split("\n")
+    assert len(out) == len(cases)
+    streams = {(G, T): po.grid_normals(G, T, count) for G, T in geoms}
+    for (G, T, b, t), line in zip(cases, out):
+        want = np.array([int(x, 16) for x in line.split()], dtype=np.uint32)
+        got = streams[(G, T)][b, t].view(np.uint32)
+        assert (got == want).all(), (G, T, b, t)
+    # the arrangement helper: thread t of a block takes paths t, t + T, ...; a path's draws are consecutive
+    s = streams[(2, 3)]
+    z = po.grid_path_normals(s, 4, 2)     # 4 paths per block, 2 draws each: thread 0 prices paths 0 and 3
+    assert z.shape == (8, 2)
+    assert (z[0] == s[0, 0, 0:2]).all() and (z[3] == s[0, 0, 2:4]).all() and (z[1] == s[0, 1, 0:2]).all()
+    assert (z[4 + 2] == s[1, 2, 0:2]).all()
+    assert po.grid_draws_per_thread(3, 4, 2) == 4
