@@ -9,6 +9,7 @@ The simulation itself always runs in libmc_mi355x.so on the GPU; nothing here co
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from dataclasses import dataclass, field
 from typing import Optional, Sequence
@@ -416,13 +417,20 @@ def _path_count(numBlocks, sims):
     return numBlocks * (sims // numBlocks)   # MonteCarloKernel.cu:491,508,524 with :413
 
 
+def _dev(prod, inputs, numBlocks, numThreads, sims, precision) -> OptionValue:
+    n = _path_count(numBlocks, sims)
+    if os.environ.get("MC_RNG") == "xorwow_grid":   # as the legacy symbols: the reference's launch geometry shapes the sample
+        return default_engine().run_grid(prod, inputs, numBlocks, numThreads, n // numBlocks, precision).value()
+    return getattr(default_engine(), prod)(inputs, n, precision=precision).value()
+
+
 def dev_vanillaOpt(opt, numBlocks, numThreads, sims, precision="f64") -> OptionValue:
-    return default_engine().vanilla(opt, _path_count(numBlocks, sims), precision=precision).value()
+    return _dev("vanilla", opt, numBlocks, numThreads, sims, precision)
 
 
 def dev_basketOpt(option, numBlocks, numThreads, sims, precision="f64") -> OptionValue:
-    return default_engine().basket(option, _path_count(numBlocks, sims), precision=precision).value()
+    return _dev("basket", option, numBlocks, numThreads, sims, precision)
 
 
 def dev_cvaEquityOption(cva, numBlocks, numThreads, sims, precision="f64") -> OptionValue:
-    return default_engine().cva(cva, _path_count(numBlocks, sims), precision=precision).value()
+    return _dev("cva", cva, numBlocks, numThreads, sims, precision)

@@ -230,3 +230,10 @@ def test_legacy_symbols_under_the_reference_geometry(mc, eng, po, X, monkeypatch
     v = L.dev_cvaEquityOption(C.byref(s), blocks, threads, sims)
     e = eng.run_grid("cva", c, blocks, threads, 1000, X)
     assert (v.Expected, v.Confidence) == (R(e.expected), R(e.confidence))
+
+
+def test_python_mirror_follows_the_same_switch(mc, eng, monkeypatch):
+    monkeypatch.setenv("MC_RNG", "xorwow_grid")
+    v = mc.dev_vanillaOpt(mc.OptionData(**VAN), 48, 128, 48 * 1000 + 17)
+    e = eng.run_grid("vanilla", VAN, 48, 128, 1000, "f64")
+    assert (v.Expected, v.Confidence) == (e.expected, e.confidence)
