@@ -20,6 +20,7 @@
 
 #include "../../include/mc_mi355x.h"
 #include "mc_hostmath.h"
+#include "mc_grid.hpp"
 #include "mc_kernels.hpp"
 
 using namespace mc;
