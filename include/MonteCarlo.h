@@ -20,6 +20,7 @@
 #define MONTECARLO_H_
 
 #include <math.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <time.h>
@@ -90,6 +91,12 @@ OptionValue dev_vanillaOpt(OptionData *opt, int numBlocks, int numThreads, int s
 OptionValue dev_basketOpt(MultiOptionData *option, int numBlocks, int numThreads, int sims);
 OptionValue dev_cvaEquityOption(CVA *cva, int numBlocks, int numThreads, int sims);
 
+/* Not in the reference (its API has no seed parameter; the GPU path uses fixed seeds, MonteCarloKernel.cu:289, the CPU path
+ * the wall clock, MonteCarloHost.c:189): the same calls with an explicit 64-bit seed instead of MC_SEED / the default. */
+OptionValue dev_vanillaOpt_ex(OptionData *opt, int numBlocks, int numThreads, int sims, uint64_t seed);
+OptionValue dev_basketOpt_ex(MultiOptionData *option, int numBlocks, int numThreads, int sims, uint64_t seed);
+OptionValue dev_cvaEquityOption_ex(CVA *cva, int numBlocks, int numThreads, int sims, uint64_t seed);
+
 /* Host entry points (reference MonteCarloHost.c:139,282,292,302,90,42,51; this repo:
  * libmchost_f64/_f32, montecarlocuda_amd/csrc/host_path.c -- a many-core CPU twin of the GPU
  * estimator on the same Philox stream, see that file's header). */
@@ -97,6 +104,9 @@ mc_real host_bsCall(OptionData option);
 OptionValue host_vanillaOpt(OptionData option, int path);
 OptionValue host_basketOpt(MultiOptionData *option, int path);
 OptionValue host_cvaEquityOption(CVA *cva, int path);
+OptionValue host_vanillaOpt_ex(OptionData option, int path, uint64_t seed);
+OptionValue host_basketOpt_ex(MultiOptionData *option, int path, uint64_t seed);
+OptionValue host_cvaEquityOption_ex(CVA *cva, int path, uint64_t seed);
 void Chol(mc_real c[N][N], mc_real a[N][N]);
 void printOption(OptionData o);
 void printMultiOpt(MultiOptionData *o);

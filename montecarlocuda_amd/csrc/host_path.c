@@ -216,8 +216,13 @@ static void block_normals(uint64_t seed, uint32_t domain, uint64_t unit, uint32_
 #endif
 }
 
+/* the seed of the next call: the *_ex entry points set it for their own call, everything else reads MC_SEED */
+static int g_seed_given;
+static uint64_t g_seed;
 static uint64_t seed_from_env(void)
 {
+    if (g_seed_given)
+        return g_seed;
     const char *s = getenv("MC_SEED");
     return s ? strtoull(s, NULL, 0) : MC_DEFAULT_SEED;
 }
@@ -517,4 +522,30 @@ OptionValue host_basketOpt(MultiOptionData *option, int path)
 OptionValue host_cvaEquityOption(CVA *cva, int path)
 {
     return simulate(cva_chunk, cva, path, 1.0);
+}
+
+/* ---- explicit-seed variants (not in the reference, whose API has no seed parameter: SURVEY 8b "RNG contract").
+ * Not re-entrant, like the rest of this file's entry points. ---- */
+OptionValue host_vanillaOpt_ex(OptionData option, int path, uint64_t seed)
+{
+    g_seed_given = 1, g_seed = seed;
+    const OptionValue v = host_vanillaOpt(option, path);
+    g_seed_given = 0;
+    return v;
+}
+
+OptionValue host_basketOpt_ex(MultiOptionData *option, int path, uint64_t seed)
+{
+    g_seed_given = 1, g_seed = seed;
+    const OptionValue v = host_basketOpt(option, path);
+    g_seed_given = 0;
+    return v;
+}
+
+OptionValue host_cvaEquityOption_ex(CVA *cva, int path, uint64_t seed)
+{
+    g_seed_given = 1, g_seed = seed;
+    const OptionValue v = host_cvaEquityOption(cva, path);
+    g_seed_given = 0;
+    return v;
 }

@@ -185,8 +185,13 @@ static int grid_mode(void)
     return 1;
 }
 
+/* the seed of the next call: the *_ex entry points set it for their own call, everything else reads MC_SEED */
+static int g_seed_given;
+static uint64_t g_seed;
 static uint64_t seed(void)
 {
+    if (g_seed_given)
+        return g_seed;
     const char *s = getenv("MC_SEED");
     return s ? strtoull(s, NULL, 0) : MC_DEFAULT_SEED;
 }
@@ -260,4 +265,31 @@ OptionValue dev_cvaEquityOption(CVA *cva, int numBlocks, int numThreads, int sim
     if ((multi() ? multi_cva(g_multi, &c, seed(), 0, n, &r) : API(mc_cva_run)(context(), &c, seed(), 0, n, &r)) != MC_OK)
         die("in dev_cvaEquityOption");
     return finish(&r, "dev_cvaEquityOption");
+}
+
+/* ---- explicit-seed variants (not in the reference, whose API has no seed parameter: SURVEY 8b "RNG contract").
+ * Same calls with `seed` in place of MC_SEED / the default; under MC_RNG=xorwow_grid the seed is the geometry's and
+ * `seed` is not used.  Not re-entrant, like the reference's entry points (process-global state). ---- */
+OptionValue dev_vanillaOpt_ex(OptionData *opt, int numBlocks, int numThreads, int sims, uint64_t seed_)
+{
+    g_seed_given = 1, g_seed = seed_;
+    const OptionValue v = dev_vanillaOpt(opt, numBlocks, numThreads, sims);
+    g_seed_given = 0;
+    return v;
+}
+
+OptionValue dev_basketOpt_ex(MultiOptionData *option, int numBlocks, int numThreads, int sims, uint64_t seed_)
+{
+    g_seed_given = 1, g_seed = seed_;
+    const OptionValue v = dev_basketOpt(option, numBlocks, numThreads, sims);
+    g_seed_given = 0;
+    return v;
+}
+
+OptionValue dev_cvaEquityOption_ex(CVA *cva, int numBlocks, int numThreads, int sims, uint64_t seed_)
+{
+    g_seed_given = 1, g_seed = seed_;
+    const OptionValue v = dev_cvaEquityOption(cva, numBlocks, numThreads, sims);
+    g_seed_given = 0;
+    return v;
 }

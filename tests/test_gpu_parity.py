@@ -324,6 +324,33 @@ def test_legacy_symbols_drop_in(mc, eng, po, X):
     assert (v.Expected, v.Confidence) == (R(e.expected), R(e.confidence))
 
 
+@pytest.mark.parametrize("X", ["f32", "f64"])
+def test_legacy_symbols_with_an_explicit_seed(mc, eng, po, X):
+    """dev_*_ex(..., seed): SURVEY 8b -- the reference's API has no seed parameter; these variants take one."""
+    L = C.CDLL(mc._lib.LEGACY[X])
+    OptionData, MultiOptionData, OptionValue, CVA = po.ref_types(X, 3)
+    L.dev_vanillaOpt_ex.argtypes = [C.POINTER(OptionData), C.c_int, C.c_int, C.c_int, C.c_uint64]
+    L.dev_vanillaOpt_ex.restype = OptionValue
+    L.dev_cvaEquityOption_ex.argtypes = [C.POINTER(CVA), C.c_int, C.c_int, C.c_int, C.c_uint64]
+    L.dev_cvaEquityOption_ex.restype = OptionValue
+    L.dev_vanillaOpt.argtypes = [C.POINTER(OptionData), C.c_int, C.c_int, C.c_int]
+    L.dev_vanillaOpt.restype = OptionValue
+    R = np.dtype(po.NP[X]).type
+    o = OptionData(*[VAN[k] for k in "skrvt"])
+    for seed in (1, 777, 2 ** 64 - 1):
+        v = L.dev_vanillaOpt_ex(C.byref(o), 512, 128, 131072, seed)
+        e = eng.vanilla(VAN, 131072, seed, 0, X)
+        assert (v.Expected, v.Confidence) == (R(e.expected), R(e.confidence))
+    d = L.dev_vanillaOpt(C.byref(o), 512, 128, 131072)     # the default seed again afterwards
+    e = eng.vanilla(VAN, 131072, SEED, 0, X)
+    assert (d.Expected, d.Confidence) == (R(e.expected), R(e.confidence))
+    c = dict(CVA0, n_grid=50)
+    s = CVA(c["defint"], c["lgd"], 0, OptionData(*[c[k] for k in "skrvt"]), c["n_grid"])
+    v = L.dev_cvaEquityOption_ex(C.byref(s), 64, 256, 8192, 99)
+    e = eng.cva(c, 8192, 99, 0, X)
+    assert (v.Expected, v.Confidence) == (R(e.expected), R(e.confidence))
+
+
 def test_python_mirror_of_reference_interface(mc, eng):
     v = mc.dev_vanillaOpt(mc.OptionData(**VAN), 512, 128, 131072 * 8)
     e = eng.vanilla(VAN, 131072 * 8, SEED, 0, "f64")

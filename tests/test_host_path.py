@@ -270,3 +270,39 @@ def test_small_host_helpers(po, X):
     L.randMinMax.restype = R
     draws = [L.randMinMax(-2.0, 3.0) for _ in range(200)]
     assert all(-2.0 <= d <= 3.0 for d in draws) and len(set(draws)) > 150
+
+
+@pytest.mark.parametrize("X", ["f64", "f32"])
+def test_explicit_seed_variants(po, X, monkeypatch):
+    """host_*_ex(..., seed): the reference's API has no seed parameter; the added variants take one and equal the
+    plain calls under MC_SEED."""
+    L, OptionData, MultiOptionData, OptionValue, CVA = load(po, X)
+    L.host_vanillaOpt_ex.argtypes = [OptionData, C.c_int, C.c_uint64]
+    L.host_vanillaOpt_ex.restype = OptionValue
+    L.host_cvaEquityOption_ex.argtypes = [C.POINTER(CVA), C.c_int, C.c_uint64]
+    L.host_cvaEquityOption_ex.restype = OptionValue
+    L.host_basketOpt_ex.argtypes = [C.POINTER(MultiOptionData), C.c_int, C.c_uint64]
+    L.host_basketOpt_ex.restype = OptionValue
+    o = OptionData(*[VAN[k] for k in "skrvt"])
+    a = L.host_vanillaOpt_ex(o, 50001, 777)
+    _, want = po.dev_vanilla(X, VAN, 777, 0, 50001, want_paths=False)
+    assert float(a.Expected) == pytest.approx(want["expected"], rel=1e-12 if X == "f64" else 2e-6)
+    monkeypatch.setenv("MC_SEED", "777")
+    b = L.host_vanillaOpt(o, 50001)
+    assert (a.Expected, a.Confidence) == (b.Expected, b.Confidence)
+    monkeypatch.setenv("MC_SEED", "778")
+    assert L.host_vanillaOpt(o, 50001).Expected != a.Expected
+    a2 = L.host_vanillaOpt_ex(o, 50001, 777)          # the explicit seed wins over the environment, for its own call only
+    assert (a2.Expected, a2.Confidence) == (a.Expected, a.Confidence)
+    assert L.host_vanillaOpt(o, 50001).Expected != a.Expected
+    c = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6, n_grid=25)
+    s = CVA(c["defint"], c["lgd"], 0, OptionData(*[c[k] for k in "skrvt"]), 25)
+    v = L.host_cvaEquityOption_ex(C.byref(s), 3001, 5)
+    _, want = po.dev_cva(X, c, 5, 0, 3001, want_paths=False)
+    assert float(v.Expected) == pytest.approx(want["expected"], rel=1e-12 if X == "f64" else 2e-6)
+    m = MultiOptionData()
+    for i in range(3):
+        m.s[i], m.v[i], m.d[i], m.w[i] = 100.0, 0.2, 0.0, 1 / 3
+        m.p[i][i] = 1.0
+    m.k, m.t, m.r = 100.0, 1.0, 0.05
+    assert L.host_basketOpt_ex(C.byref(m), 20001, 9).Expected != L.host_basketOpt_ex(C.byref(m), 20001, 10).Expected
