@@ -89,7 +89,7 @@ struct mc_context {
     uint32_t *d_grid_states = nullptr;   // launch-geometry mode: one start state per (block, thread) of the cached geometry
     int grid_blocks = 0, grid_threads = 0;
     bool normals_f32 = false;     // fp64 kernels draw fp32 normals, widened (the reference's dp arithmetic): GenPhiloxF32N
-    // external normals (tests only, mc_*_from_normals_*): set around one enqueue
+    // external normals (mc_*_from_normals_*, mc_*_run_grid_*): set around one enqueue
     const void *ext = nullptr;    // device array, ext_per_unit Reals per unit
     uint32_t ext_per_unit = 0;
     int ext_flags = 0;
@@ -414,7 +414,7 @@ static int with_gen(GenSel g, F f)
         if (g == GEN_EXTERNAL) { f(gen_tag<GenExternal>{}); return MC_OK; }
     return fail(MC_ERR_UNSUPPORTED, "this kernel is not compiled for the selected generator / estimator combination");
 }
-// plain / antithetic x generator; the external-normals policy (tests) exists for the plain estimator only
+// plain / antithetic x generator; the external-normals policy exists for the plain estimator only
 template <unsigned ALLOW, class F>
 static int with_anti_gen(bool anti, GenSel g, F f)
 {

@@ -96,7 +96,7 @@ __device__ __forceinline__ void box_muller_pk(uint32_t xa, uint32_t ya, uint32_t
 // mirrored path -z; the sample is the mean of the two payoffs (here their sum: the 1/2 rides on the
 // finishing step's scale).  Costs one more fma + exponential + clamp-subtract per path.
 //
-// GenExternal (tests): the four normals come from memory and the exponent is fma(z, b2, a2k); everything after the
+// GenExternal (from-normals hooks, launch-geometry mode): the four normals come from memory and the exponent is fma(z, b2, a2k); everything after the
 // exponent -- exponential, clamp-subtract, sums, flushes, final reduction -- is the code of the hot path.
 template <bool ANTI, class Gen>
 __device__ __forceinline__ void vanilla_unit_pk(Gen &gen, const VanillaF32 &o, const Work &w, uint32_t c0, f2 &pc, f2 &ps)

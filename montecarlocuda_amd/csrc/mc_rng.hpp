@@ -14,7 +14,7 @@
 //
 // WHERE a kernel's normals come from is a policy class (the `Gen` template parameter of every simulation kernel,
 // "generator policies" below): Philox (default), XORWOW (the reference's generator), Philox with fp32 normals widened
-// to double (the reference's own dp arithmetic, opt-in), or a caller-supplied array in HBM (tests only).
+// to double (the reference's own dp arithmetic, opt-in), or an array in HBM (the from-normals test hooks; the launch-geometry compatibility mode, mc_grid.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -170,7 +170,7 @@ struct Work {
     // first_path <= p < end_path.  Ignored by the unmasked kernels.
     uint64_t first_path, end_path;
     const uint32_t *xorwow;     // GenXorwow only: start states of the launch's lanes, 6 words each
-    const void *ext;            // GenExternal only (tests): normals of the segment's units, `ext_per_unit` Reals per unit
+    const void *ext;            // GenExternal only: normals of the segment's units, `ext_per_unit` Reals per unit
     uint32_t ext_per_unit;
 };
 
@@ -204,10 +204,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));  // one VGPR pair: v_pk_{f
 // through mc_math_f64.hpp; everything downstream of the normal stays fp64.  Its own stream layout (4 normals per
 // block in fp64), mirrored by the oracle (orc_set_normals_f32).
 //
-// GenExternal (tests only: mc_*_from_normals_*): the normals are read from a caller-supplied array, `ext_per_unit`
+// GenExternal (mc_*_from_normals_*, mc_*_run_grid_*): the normals are read from an array in HBM, `ext_per_unit`
 // Reals per unit, so that the reference's own normal stream (glibc rand() + Box-Muller, MonteCarloHost.c:117-121) can be
 // pushed through the very payoff / accumulation / final-reduction code of the hot kernels and compared with the
-// compiled reference's outputs (tests/test_gpu_from_normals.py).  Indices beyond a unit's count read as 0.
+// compiled reference's outputs (tests/test_gpu_from_normals.py) -- and so that the launch-geometry compatibility mode can
+// price the sample a (numBlocks x numThreads) launch of the reference draws (mc_grid.hpp writes it in path order).
+// Indices beyond a unit's count read as 0.
 struct GenPhilox {
     static constexpr bool external = false;
     template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }
