@@ -39,6 +39,22 @@ def test_vanilla_driver(X, tol):
     assert abs(cpu[1] - ci_gpu) <= 2e-6
 
 
+def test_vanilla_driver_under_the_reference_launch_geometry():
+    """MC_RNG=xorwow_grid: the unchanged C driver, through dev_vanillaOpt(&option, 512, 128, sims), prices the sample the
+    reference's 512 x 128 launch draws (mc_vanilla_run_grid_f64 from Python gives the same number)."""
+    import montecarlocuda_amd as mc
+    exe = os.path.join(ROOT, "drivers", "vanillaOpt_f64")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "drivers")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe, "8", "--no-cpu"], capture_output=True, text=True, timeout=600, env=dict(os.environ, MC_RNG="xorwow_grid"))
+    assert out.returncode == 0, out.stderr
+    gpu = floats_after(out.stdout, "Speedup :\n", 4)
+    with mc.Engine(0) as eng:
+        e = eng.run_grid("vanilla", dict(s=100.0, k=100.0, r=0.048790, v=0.2, t=1.0), 512, 128, 8 * 131072 // 512, "f64")
+    assert abs(gpu[0] - e.expected) < 1e-6 and abs(gpu[1] - e.confidence) < 1e-6
+    assert abs(gpu[0] - BS) < 3.5 / 1.96 * gpu[1]
+
+
 def test_basket_driver_reference_data():
     out = run("basketOpt_f64", "16")
     assert "zero pivot" in out                   # the reference's N=3 correlation matrix is singular
