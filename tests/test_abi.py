@@ -39,6 +39,12 @@ def test_legacy_library_exports_reference_entry_points(mc, X):
     L = C.CDLL(path)
     for name in ("dev_vanillaOpt", "dev_basketOpt", "dev_cvaEquityOption"):
         assert hasattr(L, name)
+        assert hasattr(L, name + "_ex")     # explicit-seed variants (SURVEY 8b "RNG contract"; include/MonteCarlo.h)
+    # the host entry points the reference's drivers link (MonteCarloHost.c:139,282,292,302,90,42,51) + their _ex variants
+    H = C.CDLL(os.path.join(os.path.dirname(path), f"libmchost_{X}.so"))
+    for name in ("host_bsCall", "host_vanillaOpt", "host_basketOpt", "host_cvaEquityOption", "Chol", "printOption", "printMultiOpt",
+                 "printVect", "printMat", "prodMat", "randMinMax", "host_vanillaOpt_ex", "host_basketOpt_ex", "host_cvaEquityOption_ex"):
+        assert hasattr(H, name), name
 
 
 LAYOUT_C = r"""
