@@ -348,7 +348,8 @@ int mc_cva_from_normals_f64(mc_context *ctx, const mc_cva_f64 *cva, const double
  *   n = num_blocks * paths_per_block paths are priced (the reference's numBlocks * (sims / numBlocks)).
  * The normals of the call are first written to HBM (one Real per draw) and then priced by the same simulation kernels as
  * mc_*_run_* through the external-normals policy; a compatibility path, not a fast one.  Plain estimator only; the
- * context's generator / normals settings are ignored.  num_threads <= 1024, at most 2^24 threads and 2^31 paths. */
+ * context's generator / normals settings are ignored.  num_threads <= 1024, at most 2^24 threads and 2^31 paths.
+ * mc_result.kernel_ms covers the pricing kernel only; wall_ms the whole call from the moment the normals are enqueued. */
 int mc_vanilla_run_grid_f32(mc_context *ctx, const mc_option_f32 *opt, int num_blocks, int num_threads,
                             uint64_t paths_per_block, mc_result *out);
 int mc_vanilla_run_grid_f64(mc_context *ctx, const mc_option_f64 *opt, int num_blocks, int num_threads,
