@@ -517,6 +517,47 @@ def test_async_launches_are_graph_capturable(mc):
     eng.close()
 
 
+def test_one_context_per_host_thread_is_safe(mc):
+    """one context per host thread.  Four threads, each with its own context, price a mix of calls
+    concurrently (ctypes releases the GIL inside a call); every result equals the serial one bit for bit, and an error raised
+    in one thread carries that thread's own message (mc_last_error is thread-local)."""
+    import threading
+    jobs = []
+    for i in range(24):
+        prod = ("vanilla", "basket", "cva")[i % 3]
+        X = ("f32", "f64")[(i // 3) % 2]
+        inp = {"vanilla": VAN, "basket": basket_inputs(mc, (3, 4, 16, 20)[i % 4], X), "cva": dict(CVA0, n_grid=(12, 50)[i % 2])}[prod]
+        jobs.append((prod, X, inp, 20000 + 997 * i, SEED + i, 1000003 * i))
+    with mc.Engine(0) as e:
+        serial = [getattr(e, p)(inp, n, seed, first, X) for p, X, inp, n, seed, first in jobs]
+    results, errors = {}, {}
+
+    def worker(t):
+        try:
+            with mc.Engine(0) as e:
+                for rep in range(6):
+                    for j in range(t, len(jobs), 4):
+                        p, X, inp, n, seed, first = jobs[j]
+                        r = getattr(e, p)(inp, n, seed, first, X)
+                        results[(t, rep, j)] = (r.sum, r.sum2, r.n)
+                try:
+                    e.vanilla(dict(VAN, s=-1.0 - t), 10)
+                except mc.McError as ex:
+                    errors[t] = str(ex)
+        except Exception as ex:      # noqa: BLE001
+            errors[t] = "thread failed: " + repr(ex)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert len(results) == 6 * len(jobs)
+    for (t, rep, j), got in results.items():
+        assert got == (serial[j].sum, serial[j].sum2, serial[j].n), (t, rep, j)
+    assert sorted(errors) == [0, 1, 2, 3] and all("s>0" in m or "need" in m for m in errors.values()), errors
+
+
 def test_armed_launch_and_publish_deliver_into_pinned_slots(mc):
     """mc_context_arm_direct / mc_context_publish (what libmc_multi and bench.py's strong rows read results back with):
     the next asynchronous launch's last workgroup stores the triple into pinned host memory, a one-lane kernel does the
