@@ -15,6 +15,10 @@
  *     the 24-byte payload of the multi-GPU all-reduce.  No host synchronisation;
  *   - *_run_* are the synchronous forms: launch, wait, close the estimator on the host;
  *   - *_paths_* return per-path values for a (small) path range: used by the parity tests.
+ * Sizes: first_path and n_paths are 64-bit; ONE call covers at most 8 segments of 2^31 units (a unit = 4 / 8 vanilla paths in
+ * f32 / f64, one basket or CVA path), none crossing a multiple of 2^32 units: up to 6.9e10 / 1.4e11 vanilla paths and
+ * 1.7e10 basket or CVA paths per call (MC_ERR_INVALID beyond: "split it").  Larger jobs are several calls on consecutive
+ * ranges; their triples add (mc_closing takes the sums).
  * One launch per call: the last workgroup to arrive adds the per-workgroup (sum, sum2) pairs and writes the triple.
  * Contract of a context: it owns one pair buffer, one ticket block and one constant table, so its calls execute one
  * after the other; calls on one stream are ordered by the stream, a call on a DIFFERENT stream than the context's
