@@ -517,6 +517,23 @@ def test_async_launches_are_graph_capturable(mc):
     eng.close()
 
 
+def test_largest_single_call_and_the_refusal_beyond(mc, eng):
+    """One call covers at most 8 segments of 2^31 units (include/mc_mi355x.h "Sizes"): 2^36 fp32 vanilla paths in one call
+    (6.9e10, ~35 ms) price to Black-Scholes within the confidence interval and add up from two halves; one unit more is
+    refused with a message that says what to do."""
+    n = 1 << 36
+    e = eng.vanilla(VAN, n, SEED, 0, "f32")
+    assert e.n == n
+    assert abs(e.expected - BS_EXACT) < 3.5 / 1.96 * e.confidence + 2e-5      # + the fp32 constants' bias (DESIGN 5)
+    lo = eng.vanilla(VAN, n // 2, SEED, 0, "f32")
+    hi = eng.vanilla(VAN, n // 2, SEED, n // 2, "f32")
+    assert lo.sum + hi.sum == pytest.approx(e.sum, rel=1e-13) and lo.n + hi.n == n
+    with pytest.raises(mc.McError, match="split it"):
+        eng.vanilla(VAN, n + 4, SEED, 0, "f32")
+    with pytest.raises(mc.McError, match="split it"):
+        eng.cva(dict(CVA0, n_grid=4), (1 << 34) + 1, SEED, 0, "f64")
+
+
 def test_one_context_per_host_thread_is_safe(mc):
     """one context per host thread.  Four threads, each with its own context, price a mix of calls
     concurrently (ctypes releases the GIL inside a call); every result equals the serial one bit for bit, and an error raised
