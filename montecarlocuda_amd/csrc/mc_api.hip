@@ -2010,6 +2010,7 @@ static uint32_t cva_draws(Real t, int n_grid)
 extern "C" int mc_grid_normals(mc_context *c, int num_blocks, int num_threads, uint32_t count, float *h_out)
 {
     uint64_t n;
+    if (!h_out) return fail(MC_ERR_INVALID, "mc_grid_normals: NULL output pointer");
     if (int rc = grid_check(c, h_out, num_blocks, num_threads, 1, h_out, &n)) return rc;
     const uint64_t lanes = (uint64_t)num_blocks * (uint64_t)num_threads;
     if (count == 0 || lanes * count > (1ull << 28))
