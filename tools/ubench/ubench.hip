@@ -117,6 +117,72 @@ K64_2(k_rcp_f64, "v_rcp_f64 %0, %0")
 K64_2(k_sqrt_f64, "v_sqrt_f64 %0, %0")
 K64_2(k_lshl_b64, "v_lshlrev_b64 %0, 1, %0")
 KMAD64(k_mad_u64_u32)
+// the non-arithmetic fp64 helpers of mc_math_f64.hpp's table forms (round 3): scaling, exponent / mantissa extraction,
+// conversions, the 1/sqrt seed, max, 64-bit move, and the lane <-> scalar moves of an SGPR spill
+K64_2(k_ldexp_f64, "v_ldexp_f64 %0, %0, 1")
+K64_2(k_frexp_mant_f64, "v_frexp_mant_f64 %0, %0")
+K64_2(k_rsq_f64, "v_rsq_f64 %0, %0")
+K64_2(k_max_f64, "v_max_f64 %0, %0, %1")
+K64_2(k_mov_b64, "v_mov_b64 %0, %1")
+K64_2(k_fmac_f64, "v_fmac_f64 %0, %1, %1")
+#define K64_FROM32(NAME, ASM)                                                              \
+    __global__ __launch_bounds__(256) void NAME(float *out, unsigned long long *clk)       \
+    {                                                                                      \
+        double r[8];                                                                       \
+        int a[8];                                                                          \
+        for (int i = 0; i < 8; i++) { r[i] = 0; a[i] = threadIdx.x + i; }                  \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime(); \
+        for (int it = 0; it < ITERS; ++it) {                                               \
+            _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                           \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(ASM : "=v"(r[i]) : "v"(a[i])); \
+            }                                                                              \
+        }                                                                                  \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime(); \
+        double s = 0;                                                                      \
+        for (int i = 0; i < 8; i++) s += r[i];                                             \
+        if (s == 123.456) out[0] = (float)s;                                               \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }   \
+    }
+K64_FROM32(k_cvt_f64_i32, "v_cvt_f64_i32 %0, %1")
+#define K32_FROM64(NAME, ASM)                                                              \
+    __global__ __launch_bounds__(256) void NAME(float *out, unsigned long long *clk)       \
+    {                                                                                      \
+        double r[8];                                                                       \
+        int a[8];                                                                          \
+        for (int i = 0; i < 8; i++) { r[i] = 1.0 + threadIdx.x * 1e-3 + i; a[i] = 0; }     \
+        unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime(); \
+        for (int it = 0; it < ITERS; ++it) {                                               \
+            _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {                           \
+                _Pragma("unroll") for (int i = 0; i < 8; i++) asm volatile(ASM : "=v"(a[i]) : "v"(r[i])); \
+            }                                                                              \
+        }                                                                                  \
+        unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime(); \
+        int s = 0;                                                                         \
+        for (int i = 0; i < 8; i++) s += a[i];                                             \
+        if (s == 123456) out[0] = 1.0f;                                                    \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }   \
+    }
+K32_FROM64(k_frexp_exp_f64, "v_frexp_exp_i32_f64 %0, %1")
+K32_FROM64(k_cmp_f64, "v_cmp_lt_f64 vcc, %1, %1\n v_mov_b32 %0, 0")
+__global__ __launch_bounds__(256) void k_readlane(float *out, unsigned long long *clk)
+{
+    int r[8];
+    for (int i = 0; i < 8; i++) r[i] = threadIdx.x + i;
+    int sacc = 0;
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < ITERS; ++it) {
+        _Pragma("unroll") for (int u = 0; u < UNROLL; ++u) {
+            _Pragma("unroll") for (int i = 0; i < 8; i++) {
+                int s;
+                asm volatile("v_readlane_b32 %0, %1, 3" : "=s"(s) : "v"(r[i]));
+                sacc ^= s;
+            }
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
+    if (sacc == 123456) out[0] = 1.0f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
 
 // ---- context probes: operand kinds, dependent chains, Philox-like mixes ---------------------
 #define K32_S(NAME, ASM)                                                                   \
@@ -322,6 +388,9 @@ int main(int argc, char **argv)
         {"v_pk_fma_f32", k_pk_fma_f32}, {"v_pk_mul_f32", k_pk_mul_f32}, {"v_pk_add_f32", k_pk_add_f32},
         {"v_fma_f64", k_fma_f64}, {"v_add_f64", k_add_f64}, {"v_mul_f64", k_mul_f64},
         {"v_rcp_f64", k_rcp_f64}, {"v_sqrt_f64", k_sqrt_f64}, {"v_lshlrev_b64", k_lshl_b64},
+        {"v_ldexp_f64", k_ldexp_f64}, {"v_frexp_mant_f64", k_frexp_mant_f64}, {"v_frexp_exp_i32_f64", k_frexp_exp_f64},
+        {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_rsq_f64", k_rsq_f64}, {"v_max_f64", k_max_f64}, {"v_mov_b64", k_mov_b64},
+        {"v_fmac_f64", k_fmac_f64}, {"v_cmp_lt_f64 + v_mov /2", k_cmp_f64}, {"v_readlane_b32 (+s_xor)", k_readlane},
         {"v_xor_b32(sgpr)", k_xor_sgpr}, {"v_add_f32(sgpr)", k_add_f32_sgpr}, {"v_sub_f32 clamp", k_sub_clamp},
         {"v_sub_f32", k_sub_f32}, {"v_and_b32", k_and_b32}, {"v_or_b32", k_or_b32}, {"v_lshlrev_b32", k_lshl_b32},
         {"v_lshrrev_b32", k_lshr_b32}, {"v_mov_b32", k_mov_b32}, {"v_fmac_f32", k_fmac_f32}, {"v_min_f32", k_min_f32},
