@@ -92,7 +92,7 @@ for it in range(cases):
     else:
         h, vals = eng.cva_from_normals(inp, z, X)
         want, _ = po.dev_cva_on_normals(X, inp, z.astype(np.float64), 0)
-        tol = TOL[X]["cva"] * spot / 100.0 * 3
+        tol = TOL[X]["cva"] * spot * float(np.exp(r * t + 4 * inp["v"] * np.sqrt(t))) / 100.0 * 3   # as tools/fuzz_parity.py: the reachable spot
     if (e.sum, e.sum2, e.n) != (h.sum, h.sum2, G * per_block):
         bad += 1
         print("VIOLATION sums differ from the arrangement's", what, (e.sum, e.sum2, e.n), (h.sum, h.sum2, h.n))
