@@ -11,8 +11,11 @@
  * How a call runs (mc_multi.cpp):
  *   device g of G owns the contiguous global paths [first + floor(g n / G), first + floor((g+1) n / G))
  *   (mc_shard_range), same seed: a path's normals depend only on (seed, global path index), so the union of the
- *   shards IS the single-GPU sample; every device's launch (mc_*_launch_*, include/mc_mi355x.h) is enqueued from
- *   the calling thread on that device's own stream and leaves its triple in that device's HBM; then ONE grouped
+ *   shards IS the single-GPU sample; every device's launch (mc_*_launch_*, include/mc_mi355x.h) is enqueued on that
+ *   device's own stream -- with more than one device by that device's own LAUNCHER THREAD, which the handle creates and
+ *   the calling thread starts through one flag word, so that all devices start together (serially from the calling
+ *   thread an asynchronous launch costs ~4 us: device 7 of 8 would start ~30 us late) -- and leaves its triple in that
+ *   device's HBM; then ONE grouped
  *   ncclAllReduce(count = 3, ncclDouble, ncclSum) on the same streams (communicators from ncclCommInitAll, created
  *   once with the handle, never per call), 24 bytes read back from the first device, closing formulas on the host.
  *   The pre-reduction triples are read back as well and added on the host in device order: the cross-check of the
@@ -62,6 +65,13 @@ int mc_multi_set_generator(mc_multi *m, int generator, uint64_t subsequence_base
 int mc_multi_set_timing(mc_multi *m, int on);
 /* MC_REDUCE_RCCL (default; MC_MULTI_REDUCE=host in the environment selects the other) or MC_REDUCE_HOST */
 int mc_multi_set_reduce(mc_multi *m, int mode);
+/* Launcher threads (created with the handle when it has more than one device; MC_MULTI_THREADS=0 in the environment keeps
+ * the serial fan-out from the calling thread).  A launcher thread spins on its flag word for MC_MULTI_LINGER_US (default
+ * 2000) after its last job and then sleeps, so back-to-back calls pay no wake-up and an idle handle uses no core.
+ * mc_multi_launcher_threads: how many the handle runs (0 = serial).  mc_multi_last_fanout_us: host time from the entry of
+ * the last mc_multi_*_run_* call until the LAST device's launch had been enqueued.  One calling thread per handle. */
+int mc_multi_launcher_threads(const mc_multi *m);
+double mc_multi_last_fanout_us(const mc_multi *m);
 /* Text of the last failure of an mc_multi_* call on this thread ("" if none). */
 const char *mc_multi_last_error(void);
 /* |RCCL sum - host sum| / |host sum| of the last call's `sum` (0 when the host did the reduction) */

@@ -7,8 +7,10 @@
 //
 // Host-only translation unit: no device code.  Everything a call enqueues -- G launches, one grouped all-reduce, one
 // one-lane publish kernel -- is asynchronous; the results come back through pinned host memory that the devices write
-// themselves and the calling thread polls (run_sharded).  NOTE: the grouped all-reduce has only ever run with a
-// communicator of ONE rank (one-GPU test boxes; RCCL refuses a repeated device): the G > 1 collective is unexercised.
+// themselves and the calling thread polls (run_sharded).  With G > 1 every device's launch is issued by that device's
+// own launcher thread (mc_multi_host.hpp: LaunchCrew), so the devices start together; the collective stays ONE grouped
+// call on the calling thread.  NOTE: the grouped all-reduce has only ever run with a communicator of ONE rank (one-GPU
+// test boxes; RCCL refuses a repeated device): the G > 1 collective is unexercised.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -18,10 +20,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
 #include "../../include/mc_multi.h"
+#include "mc_multi_host.hpp"
 
 static thread_local std::string g_multi_error;
 
@@ -72,12 +76,17 @@ struct mc_multi {
     bool timing = true;                        // two HIP events per device and call (mc_result.kernel_ms)
     bool readback_copy = false;                // MC_MULTI_READBACK=copy: round 2's copy + synchronize read-back also with timing off (A/B)
     double last_reduce_error = 0.0;
+    // one launcher thread per device (G > 1; MC_MULTI_THREADS=0 keeps the serial fan-out of rounds 2-3 for A/B)
+    std::unique_ptr<mc_host::LaunchCrew> crew;
+    std::vector<std::string> worker_error;     // text of a worker's failed launch (mc_last_error is per thread)
+    double last_fanout_us = 0.0;               // call entry -> the last device's launch enqueued, of the last call
 };
 
 extern "C" void mc_multi_destroy(mc_multi *m)
 {
     if (!m)
         return;
+    m->crew.reset();   // joins the launcher threads: none of them is inside a launch after this
     for (size_t g = 0; g < m->ctx.size(); ++g) {
         (void)hipSetDevice(m->devices[g]);
         if (g < m->stream.size() && m->stream[g]) (void)hipStreamSynchronize(m->stream[g]);
@@ -147,6 +156,19 @@ extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc
         mc_multi_destroy(m);
         return rc;
     }
+    // Launcher threads: device g's launches are issued by thread g (its own hipSetDevice, arm and launch), started through
+    // one flag word each, so that device G-1 starts with device 0 instead of (G-1) x ~4 us later.  A worker spins for
+    // MC_MULTI_LINGER_US (default 2000) after its last job and then sleeps: back-to-back calls never pay a wake-up, an
+    // idle handle burns no core.
+    const char *th = getenv("MC_MULTI_THREADS");
+    if (n_devices > 1 && !(th && atoi(th) == 0)) {
+        const char *lg = getenv("MC_MULTI_LINGER_US");
+        const long linger_us = lg ? atol(lg) : 2000;
+        m->worker_error.resize((size_t)n_devices);
+        m->crew.reset(new mc_host::LaunchCrew(
+            n_devices, std::chrono::microseconds(linger_us < 0 ? 0 : linger_us),
+            [](void *h, int g) { (void)hipSetDevice(static_cast<mc_multi *>(h)->devices[(size_t)g]); }, m));
+    }
     *out = m;
     return MC_OK;
 }
@@ -157,6 +179,8 @@ extern "C" mc_context *mc_multi_context(mc_multi *m, int i)
     return (m && i >= 0 && i < (int)m->ctx.size()) ? m->ctx[i] : nullptr;
 }
 extern "C" double mc_multi_last_reduce_error(const mc_multi *m) { return m ? m->last_reduce_error : 0.0; }
+extern "C" double mc_multi_last_fanout_us(const mc_multi *m) { return m ? m->last_fanout_us : 0.0; }
+extern "C" int mc_multi_launcher_threads(const mc_multi *m) { return (m && m->crew) ? m->crew->size() : 0; }
 
 extern "C" int mc_multi_set_antithetic(mc_multi *m, int on)
 {
@@ -253,22 +277,21 @@ struct InFlight {
     ~InFlight() { settle(); }
 };
 
-static inline bool slot_ready(const volatile double *slot)
-{
-    return __atomic_load_n((const uint64_t *)(slot + 2), __ATOMIC_ACQUIRE) != 0xBFF0000000000000ull;   // bits of -1.0
-}
-
 // launch(g, ctx, first, count, d_triple, stream) enqueues device g's shard.
+//
+// Fan-out.  G == 1 (or MC_MULTI_THREADS=0): the calling thread enqueues every device's launch itself, one after the
+// other -- an asynchronous launch costs it ~4.2 us (profiles/r02_launch_cost.log), so device 7 of 8 started ~30 us after
+// device 0: 3 % of C5's 1 ms shard.  G > 1: every device has its own launcher thread (LaunchCrew), the calling thread
+// bumps G flag words and the launches are issued concurrently; `last_fanout_us` = call entry -> the last device's launch
+// enqueued (tools/c/multi_cost.c prints it).
 //
 // Read-back.  With timing off (what the legacy symbols and the benchmarks use) nothing is copied and nothing sleeps:
 // every device's last workgroup stores its triple into a pinned host slot of its context (mc_context_arm_direct), the
 // all-reduced triple follows through a one-lane kernel behind the collective on device 0's stream
-// (mc_context_publish), and this thread polls the G (+ 1) flag words in ONE loop from user space.  Round 2 issued G + 1
-// hipMemcpyAsync and G serial hipStreamSynchronize calls instead.  Measured on one device, C5's shard of 8 (a 1.04 ms
-// kernel), wall minus the kernel's own duration per call (profiles/r03_multi_fixed_cost.log, tools/c/multi_cost.c; the
-// dispatch-bound events of the measurement itself cost ~10 us of it): host sum 13.8 us = the single-device floor (13.7),
-// RCCL over one rank + publish 21.8 us; round 2's form 23.7 / 28.6 us.  With timing on the event/copy/synchronize path
-// is kept: it is the one that can report kernel_ms.
+// (mc_context_publish), and this thread polls the G (+ 1) flag words in ONE loop from user space
+// (mc_multi_host.hpp: poll_slots).  Round 2 issued G + 1 hipMemcpyAsync and G serial hipStreamSynchronize calls
+// instead (kept as MC_MULTI_READBACK=copy, the conservative fallback, and whenever timing is on: it is the form that
+// can report kernel_ms).
 template <class Launch>
 static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount, double add_back, mc_result *out, Launch launch)
 {
@@ -281,23 +304,74 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     const auto wall0 = std::chrono::steady_clock::now();
     InFlight fl(m);
     bool direct = !m->timing && !m->readback_copy;
-    std::vector<const volatile double *> slot((size_t)G, nullptr);
-    const volatile double *rslot = nullptr;
-    for (int g = 0; g < G; ++g) {
+    std::vector<const volatile double *> slot((size_t)G + 1, nullptr);   // [G] = the all-reduced triple's slot
+    // device g's part of the call; runs on the calling thread or on launcher thread g.  Returns an MC_* status; the text
+    // of a failure goes to `err` (mc_last_error is thread-local: a worker's text would be lost otherwise).
+    struct Job {
+        mc_multi *m;
+        uint64_t first, n;
+        bool want_direct;
+        const volatile double **slot;
+        Launch *launch;
+        std::vector<char> armed;
+    } job{m, first, n, direct, slot.data(), &launch, std::vector<char>((size_t)G, 0)};
+    const auto device_part = [](void *jp, int g) -> int {
+        Job &j = *static_cast<Job *>(jp);
+        mc_multi *m = j.m;
+        const int G = (int)m->devices.size();
+        std::string *err = m->worker_error.empty() ? nullptr : &m->worker_error[(size_t)g];
+        const auto hip_fail = [&](const char *what, hipError_t e) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "%s failed: %s", what, hipGetErrorString(e));
+            if (err) *err = buf; else g_multi_error = buf;
+            return MC_ERR_HIP;
+        };
         uint64_t lo = 0, cnt = 0;
-        mc_shard_range(n, g, G, &lo, &cnt);
-        HIPCHK(hipSetDevice(m->devices[g]));
-        fl.touched = g + 1;
-        if (m->timing) HIPCHK(hipEventRecord(m->ev0[g], m->stream[g]));
+        mc_shard_range(j.n, g, G, &lo, &cnt);
+        hipError_t e = hipSetDevice(m->devices[(size_t)g]);
+        if (e != hipSuccess) return hip_fail("hipSetDevice", e);
+        if (m->timing && (e = hipEventRecord(m->ev0[(size_t)g], m->stream[(size_t)g])) != hipSuccess) return hip_fail("hipEventRecord", e);
         if (cnt) {
-            if (direct && mc_context_arm_direct(m->ctx[g], &slot[g]) != MC_OK)
-                direct = false;   // e.g. MC_FINISH=kernel: fall back to copies for the whole call (g == 0: nothing armed yet)
-            MCCHK(launch(g, m->ctx[g], first + lo, cnt, m->d_send[g], (void *)m->stream[g]));
+            if (j.want_direct && mc_context_arm_direct(m->ctx[(size_t)g], &j.slot[g]) == MC_OK)
+                j.armed[(size_t)g] = 1;   // not armed (e.g. MC_FINISH=kernel): the whole call falls back to copies
+            const int rc = (*j.launch)(g, m->ctx[(size_t)g], j.first + lo, cnt, m->d_send[(size_t)g], (void *)m->stream[(size_t)g]);
+            if (rc != MC_OK) {
+                if (err) *err = mc_last_error(); else g_multi_error = mc_last_error();
+                return rc;
+            }
         } else {  // fewer paths than devices: this one contributes {0, 0, 0}
-            HIPCHK(hipMemsetAsync(m->d_send[g], 0, 3 * sizeof(double), m->stream[g]));
+            j.armed[(size_t)g] = 1;
+            if ((e = hipMemsetAsync(m->d_send[(size_t)g], 0, 3 * sizeof(double), m->stream[(size_t)g])) != hipSuccess) return hip_fail("hipMemsetAsync", e);
         }
-        if (m->timing) HIPCHK(hipEventRecord(m->ev1[g], m->stream[g]));
+        if (m->timing && (e = hipEventRecord(m->ev1[(size_t)g], m->stream[(size_t)g])) != hipSuccess) return hip_fail("hipEventRecord", e);
+        return MC_OK;
+    };
+    fl.touched = G;   // from here on any device may have work of this call
+    std::vector<int> rcs((size_t)G, MC_OK);
+    std::vector<int64_t> at_ns((size_t)G, 0);
+    if (m->crew) {
+        m->crew->run_all(device_part, &job, rcs.data(), wall0, at_ns.data());
+    } else {
+        for (int g = 0; g < G; ++g) {
+            rcs[(size_t)g] = device_part(&job, g);
+            at_ns[(size_t)g] = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - wall0).count();
+            if (rcs[(size_t)g] != MC_OK)
+                break;
+        }
     }
+    int64_t last_ns = 0;
+    for (int g = 0; g < G; ++g) {
+        last_ns = at_ns[(size_t)g] > last_ns ? at_ns[(size_t)g] : last_ns;
+        if (rcs[(size_t)g] != MC_OK)
+            return fail(rcs[(size_t)g], "device %d: %s", m->devices[(size_t)g],
+                        m->worker_error.empty() ? g_multi_error.c_str() : m->worker_error[(size_t)g].c_str());
+        if (direct && !job.armed[(size_t)g])
+            direct = false;
+    }
+    m->last_fanout_us = last_ns * 1e-3;
+    if (!direct)
+        for (int g = 0; g < G; ++g)
+            slot[(size_t)g] = nullptr;
     if (m->reduce == MC_REDUCE_RCCL) {
         NCCLCHK(ncclGroupStart());
         fl.group_open = true;
@@ -307,32 +381,17 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
         NCCLCHK(ncclGroupEnd());
         if (direct) {
             const int g = 0;
-            MCCHK(mc_context_publish(m->ctx[0], m->d_recv[0], (void *)m->stream[0], &rslot));
+            MCCHK(mc_context_publish(m->ctx[0], m->d_recv[0], (void *)m->stream[0], &slot[(size_t)G]));
         }
     }
+    const volatile double *rslot = slot[(size_t)G];
     float kernel_ms = 0;
     double host[3] = {0, 0, 0}, reduced[3] = {0, 0, 0};
     if (direct) {
         // one polling loop over every flag word; after 50 ms (BASELINE's C4 and C5 shards take 1-40 ms) hand the core
         // back and wait in the runtime, which is also the way out if a device faulted and will never write
-        bool all = false;
-        for (uint32_t spin = 0; !all; ++spin) {
-            all = !rslot || slot_ready(rslot);
-            for (int g = 0; g < G && all; ++g)
-                all = !slot[g] || slot_ready(slot[g]);
-            if (all)
-                break;
-            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - wall0 > std::chrono::milliseconds(50)) {
-                fl.settle();
-                all = !rslot || slot_ready(rslot);
-                for (int g = 0; g < G && all; ++g)
-                    all = !slot[g] || slot_ready(slot[g]);
-                if (!all)
-                    return fail(MC_ERR_HIP, "a device never delivered its result");
-                break;
-            }
-            __builtin_ia32_pause();
-        }
+        if (!mc_host::poll_slots(slot.data(), G + 1, wall0, std::chrono::milliseconds(50), [&] { fl.settle(); }))
+            return fail(MC_ERR_HIP, "a device never delivered its result");
         for (int g = 0; g < G; ++g)
             for (int k = 0; k < 3; ++k)
                 host[k] += slot[g] ? slot[g][k] : 0.0;

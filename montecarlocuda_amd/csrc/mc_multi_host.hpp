@@ -1,0 +1,201 @@
+// mc_multi_host.hpp -- the two pieces of libmc_multi.so's control flow that touch no GPU API, kept apart so that a plain
+// g++ program can drive them on a box without one (tests/cpp/multi_host_check.cpp, tests/test_host_logic.py):
+//
+//   poll_slots    the read-back loop of run_sharded: G (+ 1) pinned flag words polled from user space, a deadline after
+//                 which the caller's `settle` (drain every stream the call touched) runs once and the words are looked
+//                 at one last time -- the way out when a device faulted and will never write
+//   LaunchCrew    one launcher thread per device: the calling thread hands every device's launch to that device's own
+//                 thread through one flag word each, so that all devices start together instead of ~4 us apart
+//
+// Nothing here exists in the reference (single device, default stream, synchronous: dp/MonteCarloKernel.cu:296-532).
+#pragma once
+#include <sched.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#if defined(__x86_64__) || defined(__i386__)
+#define MC_CPU_RELAX() __builtin_ia32_pause()
+#else
+#define MC_CPU_RELAX() ((void)0)
+#endif
+
+namespace mc_host {
+
+constexpr uint64_t SLOT_SENTINEL_BITS = 0xBFF0000000000000ull;   // the bits of -1.0: what an armed slot's n word holds
+
+// word 2 of a slot ({sum, sum2, n}) no longer holds the sentinel: the device's release store has landed
+static inline bool slot_ready(const volatile double *slot)
+{
+    return __atomic_load_n((const uint64_t *)(slot + 2), __ATOMIC_ACQUIRE) != SLOT_SENTINEL_BITS;
+}
+
+static inline bool all_ready(const volatile double *const *slots, int n)
+{
+    for (int i = 0; i < n; ++i)
+        if (slots[i] && !slot_ready(slots[i]))
+            return false;
+    return true;
+}
+
+// Polls until every non-NULL slot is ready.  After `spin_for` the core is handed back: settle() -- which waits in the
+// runtime for everything the call enqueued -- runs ONCE, then the slots are checked a last time.
+// Returns true when all slots delivered, false when some never did (the caller reports MC_ERR_HIP).
+template <class Settle>
+static bool poll_slots(const volatile double *const *slots, int n, std::chrono::steady_clock::time_point t0,
+                       std::chrono::nanoseconds spin_for, Settle settle)
+{
+    for (uint32_t spin = 0;; ++spin) {
+        if (all_ready(slots, n))
+            return true;
+        if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > spin_for) {
+            settle();
+            return all_ready(slots, n);
+        }
+        MC_CPU_RELAX();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One launcher thread per device.  A call publishes its job (a callable taking the device index) and bumps every
+// worker's `go` word; worker g runs job(g) on its own thread -- its own hipSetDevice, arm and launch -- stores the
+// job's status and bumps `done`.  The caller spins on the `done` words.  Hand-off is one cache line each way, no
+// system call: a worker SPINS on its word while calls keep coming (for `linger` after its last job) and parks on a
+// condition variable only when the handle has been idle for longer than that, so a sequence of calls never pays a
+// wake-up and an idle handle burns no core.  When the process may run on fewer CPUs than the crew has threads (+ the
+// caller), every spin iteration yields the CPU instead (sched_yield): a spinning thread that sits on the core the
+// thread it waits for needs would otherwise cost a whole scheduler quantum (measured: 2 ms per hand-off with 9 threads
+// on 8 CPUs, 3 us with the yield).
+// ---------------------------------------------------------------------------------------------------------------
+static inline int cpus_allowed()
+{
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) != 0)
+        return 1;
+    const int n = CPU_COUNT(&set);
+    return n > 0 ? n : 1;
+}
+
+class LaunchCrew {
+public:
+    typedef int (*JobFn)(void *ctx, int g);
+
+    LaunchCrew(int n, std::chrono::nanoseconds linger, void (*thread_init)(void *, int) = nullptr, void *init_ctx = nullptr)
+        : linger_(linger), yield_(cpus_allowed() < n + 1), workers_((size_t)n)
+    {
+        for (int g = 0; g < n; ++g) {
+            workers_[(size_t)g].reset(new Worker);
+            Worker *w = workers_[(size_t)g].get();
+            w->th = std::thread([this, w, g, thread_init, init_ctx] {
+                if (thread_init)
+                    thread_init(init_ctx, g);
+                run(*w, g);
+            });
+        }
+    }
+    ~LaunchCrew()
+    {
+        quit_.store(true, std::memory_order_seq_cst);
+        for (auto &w : workers_) {
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->cv.notify_all();
+            }
+            w->th.join();
+        }
+    }
+    LaunchCrew(const LaunchCrew &) = delete;
+    LaunchCrew &operator=(const LaunchCrew &) = delete;
+
+    int size() const { return (int)workers_.size(); }
+    bool yields() const { return yield_; }
+
+    // Runs fn(ctx, g) on worker g for every g, waits for all of them; rc[g] = fn's return value.
+    // enqueued_ns[g] (optional) = steady_clock time at which worker g's job returned, in ns since `t0`.
+    void run_all(JobFn fn, void *ctx, int *rc, std::chrono::steady_clock::time_point t0 = {}, int64_t *enqueued_ns = nullptr)
+    {
+        fn_ = fn, ctx_ = ctx, t0_ = t0;
+        const uint32_t seq = ++seq_;
+        for (auto &w : workers_) {
+            w->go.store(seq, std::memory_order_seq_cst);
+            if (w->parked.load(std::memory_order_seq_cst)) {   // Dekker with the worker's (parked = true; read go)
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->cv.notify_one();
+            }
+        }
+        for (size_t g = 0; g < workers_.size(); ++g) {
+            Worker &w = *workers_[g];
+            while (w.done.load(std::memory_order_acquire) != seq)
+                relax();
+            rc[g] = w.rc;
+            if (enqueued_ns)
+                enqueued_ns[g] = w.at_ns;
+        }
+    }
+
+private:
+    struct alignas(128) Worker {
+        std::atomic<uint32_t> go{0};
+        alignas(128) std::atomic<uint32_t> done{0};
+        int rc = 0;
+        int64_t at_ns = 0;
+        alignas(128) std::atomic<bool> parked{false};
+        std::mutex mu;
+        std::condition_variable cv;
+        std::thread th;
+    };
+
+    void run(Worker &w, int g)
+    {
+        uint32_t seen = 0;
+        auto idle_since = std::chrono::steady_clock::now();
+        for (;;) {
+            uint32_t cur;
+            uint32_t spin = 0;
+            while ((cur = w.go.load(std::memory_order_acquire)) == seen) {
+                if (quit_.load(std::memory_order_relaxed))
+                    return;
+                if ((++spin & 1023u) == 0 && std::chrono::steady_clock::now() - idle_since > linger_) {
+                    std::unique_lock<std::mutex> lk(w.mu);
+                    w.parked.store(true, std::memory_order_seq_cst);
+                    while (w.go.load(std::memory_order_seq_cst) == seen && !quit_.load(std::memory_order_seq_cst))
+                        w.cv.wait(lk);
+                    w.parked.store(false, std::memory_order_seq_cst);
+                    idle_since = std::chrono::steady_clock::now();
+                } else {
+                    relax();
+                }
+            }
+            seen = cur;
+            w.rc = fn_(ctx_, g);
+            w.at_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+            w.done.store(cur, std::memory_order_release);
+            idle_since = std::chrono::steady_clock::now();
+        }
+    }
+
+    void relax() const
+    {
+        if (yield_)
+            sched_yield();
+        else
+            MC_CPU_RELAX();
+    }
+
+    std::chrono::nanoseconds linger_;
+    bool yield_;
+    std::vector<std::unique_ptr<Worker>> workers_;
+    std::atomic<bool> quit_{false};
+    JobFn fn_ = nullptr;
+    void *ctx_ = nullptr;
+    std::chrono::steady_clock::time_point t0_{};
+    uint32_t seq_ = 0;
+};
+
+}  // namespace mc_host
