@@ -188,19 +188,31 @@ def cpu_all_cores(seconds=2.0):
             "note": "threads = OpenMP's default capped by the container's cgroup CPU quota (MC_HOST_THREADS overrides)"}
 
 
-def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, backend, barrier, reps):
+def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, backend, barrier, reps, preheat_ms=300.0):
     """BASELINE.json's strong-scaling target, measured on this N: ONE pricing call of configs[3] (C4: basket, 16 assets,
-    1e9 paths, fp64) and of configs[4] (C5: CVA, 256 dates x 1e7 paths, fp64) -- and of 10x those sizes --
+    1e9 paths, fp64) and of configs[4] (C5: CVA, 256 dates x 1e7 paths, fp64) -- and of 10x those sizes, and of
+    all four once more on fp32 normals (the reference's own dp arithmetic: shorter kernels, fixed costs weigh more) --
     sharded over the N ranks (mc_shard_range), timed wall-clock from the first launch to the all-reduced triple on the
-    host, max over ranks, 2 warm-ups then `reps` repeats.  The driver's lines for N = 1, 2, 4, 8 give
-    the efficiency T1 / (N TN) of each row."""
+    host, max over ranks, median of `reps` (>= 10) calls.  The driver's lines for N = 1, 2, 4, 8 give the
+    efficiency T1 / (N TN) of each row.
+
+    Clock conditioning (profiles/r04_shard_clock_quantisation_vs_dvfs.log): an idle MI355X runs its first ~30 ms of work at
+    1.9-2.2 GHz; C5's 1 ms shard measured after two warm-up calls took 1.15-1.19 ms, after 300 ms of load 0.97-0.98 ms.  So
+    every row -- T(1) and T(shard) alike -- is measured HOT: this rank's own shard launched back to back for `preheat_ms`
+    (no collective), two warm-up calls, then the timed calls.  The base-size rows are also measured COLD (0.5 s of idle, two
+    warm-up calls, 5 calls: what a one-off call sees) and reported beside it ("cold")."""
     import numpy as np
     rows = []
-    specs = [("C4", "basket", basket_inputs(mc, 16, "f64"), 10 ** 9, "Basket call, 16 correlated assets, 1e9 paths, fp64 (BASELINE configs[3])"),
-             ("C4x10", "basket", basket_inputs(mc, 16, "f64"), 10 ** 10, "the same, 1e10 paths"),
-             ("C5", "cva", CVA, 10 ** 7, "CVA on vanilla call, 256 dates x 1e7 paths, fp64 (BASELINE configs[4])"),
-             ("C5x10", "cva", CVA, 10 ** 8, "the same, 1e8 paths")]
+    c4, c4d = basket_inputs(mc, 16, "f64"), "Basket call, 16 correlated assets, 1e9 paths, fp64 (BASELINE configs[3])"
+    c5d = "CVA on vanilla call, 256 dates x 1e7 paths, fp64 (BASELINE configs[4])"
+    n32 = " on fp32 normals (the reference's dp arithmetic)"
+    # name, product, inputs, total paths, description, normals mode, base size (measured cold as well)
+    specs = [("C4", "basket", c4, 10 ** 9, c4d, "native", True), ("C4x10", "basket", c4, 10 ** 10, "the same, 1e10 paths", "native", False),
+             ("C5", "cva", CVA, 10 ** 7, c5d, "native", True), ("C5x10", "cva", CVA, 10 ** 8, "the same, 1e8 paths", "native", False),
+             ("C4_n32", "basket", c4, 10 ** 9, c4d + n32, "f32", True), ("C4x10_n32", "basket", c4, 10 ** 10, "the same, 1e10 paths", "f32", False),
+             ("C5_n32", "cva", CVA, 10 ** 7, c5d + n32, "f32", True), ("C5x10_n32", "cva", CVA, 10 ** 8, "the same, 1e8 paths", "f32", False)]
     out = torch.zeros(3, dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(3, dtype=torch.float64, device="cuda")
     pinned = torch.zeros(3, dtype=torch.float64).pin_memory()
     # N = 1 also times what ONE rank does at N = 2, 4, 8: shard 0 of S of every row through the same code path
     # ("shard_of" rows) -- the device side of the scaling curve, which a one-GPU box can measure; the all-reduce
@@ -209,60 +221,91 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
     runs = [(spec, 1) for spec in specs]
     if world == 1:
         runs += [(spec, S) for S in (2, 4, 8) for spec in specs]
-    t_full = {}
-    for (name, prod, inputs, total, desc), shard_of in runs:
-        struct, keep = eng.prepared(prod, "f64", inputs)
-        first, count = mc.shard_range(total, rank, world) if shard_of == 1 else mc.shard_range(total, 0, shard_of)
-        times = []
+    t_full, t_full_cold = {}, {}
+
+    def one_call(prod, struct, first, count):
+        """first launch -> the all-reduced triple on this host: returns the triple as a 3-element float64 tensor"""
+        # launch, RCCL and the read-back all on torch's current stream (a handle torch owns): no hop between streams.
+        # The result comes back the way libmc_multi reads its devices: the last workgroup (N = 1) or a one-lane kernel
+        # behind the all-reduce (RCCL) stores the triple into pinned host memory and this thread polls it from user
+        # space -- no copy command, no sleeping synchronize (mc_context_arm_direct / mc_context_publish).
+        direct = count > 0 and (not grouped or backend == "nccl")
+        slot = eng.arm_direct() if (direct and not grouped) else None
+        if count:
+            eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), stream.cuda_stream)
+        else:
+            out.zero_()
+        if grouped and backend == "nccl":
+            dist.all_reduce(out, op=dist.ReduceOp.SUM)      # RCCL, ordered behind the launch (current stream)
+            if direct:
+                slot = eng.publish(out.data_ptr(), stream.cuda_stream)
+        if slot is not None:
+            host = torch.tensor(eng.wait_slot(slot), dtype=torch.float64)
+        else:
+            pinned.copy_(out, non_blocking=True)            # 24 bytes into pinned host memory
+            stream.synchronize()
+            host = pinned.clone()
+        if grouped and backend != "nccl":
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        return host
+
+    def timed(prod, struct, first, count, n_reps, hot):
         host = None
-        for r_ in range(-2, reps):
+        if hot and preheat_ms > 0 and count:
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < preheat_ms:     # this rank's own shard, back to back, no collective
+                for _ in range(2):
+                    eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, (1 << 50) + first, count, scratch.data_ptr(), stream.cuda_stream)
+                stream.synchronize()
+        elif not hot:
+            barrier()
+            time.sleep(0.5)
+        times = []
+        for r_ in range(-2, n_reps):
             barrier()
             t0 = time.perf_counter()
-            # launch, RCCL and the read-back all on torch's current stream (a handle torch owns): no hop between streams.
-            # The result comes back the way libmc_multi reads its devices: the last workgroup (N = 1) or a one-lane kernel
-            # behind the all-reduce (RCCL) stores the triple into pinned host memory and this thread polls it from user
-            # space -- no copy command, no sleeping synchronize (mc_context_arm_direct / mc_context_publish).
-            direct = count > 0 and (not grouped or backend == "nccl")
-            slot = eng.arm_direct() if (direct and not grouped) else None
-            if count:
-                eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, out.data_ptr(), stream.cuda_stream)
-            else:
-                out.zero_()
-            if grouped and backend == "nccl":
-                dist.all_reduce(out, op=dist.ReduceOp.SUM)      # RCCL, ordered behind the launch (current stream)
-                if direct:
-                    slot = eng.publish(out.data_ptr(), stream.cuda_stream)
-            if slot is not None:
-                host = torch.tensor(eng.wait_slot(slot), dtype=torch.float64)
-            else:
-                pinned.copy_(out, non_blocking=True)            # 24 bytes into pinned host memory
-                stream.synchronize()
-                host = pinned.clone()
-            if grouped and backend != "nccl":
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            dt = time.perf_counter() - t0
+            host = one_call(prod, struct, first, count)
             if r_ >= 0:
-                times.append(dt)
+                times.append(time.perf_counter() - t0)
         t = torch.tensor(times, dtype=torch.float64, device="cuda" if (grouped and backend == "nccl") else "cpu")
         if grouped:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)            # a repeat ends when its slowest rank has the result
-        times = sorted(t.tolist())
+        return sorted(t.tolist()), host
+
+    for (name, prod, inputs, total, desc, normals, base), shard_of in runs:
+        eng.set_normals(normals)
+        struct, keep = eng.prepared(prod, "f64", inputs)
+        first, count = mc.shard_range(total, rank, world) if shard_of == 1 else mc.shard_range(total, 0, shard_of)
+        times, host = timed(prod, struct, first, count, reps, True)
+        cold = None
+        if base:
+            cold_times, _ = timed(prod, struct, first, count, min(reps, 5), False)
+            cold = float(np.median(cold_times))
         s_, s2_, n_ = (float(x) for x in host.tolist())
         disc = 1.0 if prod == "cva" else math.exp(-float(inputs["r"]) * float(inputs["t"]))
         price, ci = mc.closing(s_, s2_, int(n_), disc)
         med = float(np.median(times))
         if shard_of == 1:
-            t_full[name] = med
-            rows.append({"config": name, "workload": desc, "paths_total": total, "paths_per_gpu": count, "reps": reps,
-                         "wall_ms_median": med * 1e3, "wall_ms_min": times[0] * 1e3, "paths_per_s": total / med,
-                         "value": price, "confidence_95": ci, "paths_priced": int(n_)})
+            t_full[name], t_full_cold[name] = med, cold
+            row = {"config": name, "workload": desc, "normals": normals, "paths_total": total, "paths_per_gpu": count, "reps": reps,
+                   "preheat_ms": preheat_ms, "wall_ms_median": med * 1e3, "wall_ms_min": times[0] * 1e3, "paths_per_s": total / med,
+                   "value": price, "confidence_95": ci, "paths_priced": int(n_)}
+            if cold is not None:
+                row["cold"] = {"wall_ms_median": cold * 1e3, "what": "0.5 s idle, 2 warm-up calls, median of 5"}
+            rows.append(row)
         else:
-            shard_rows.append({"config": name, "shard_of": shard_of, "paths": count, "reps": reps, "wall_ms_median": med * 1e3,
-                         "wall_ms_min": times[0] * 1e3, "device_side_efficiency": t_full[name] / (shard_of * med),
-                         "what": f"shard 0 of {shard_of} on this one GPU: T(1) / ({shard_of} T(shard)); the all-reduce between "
-                                 "ranks is not in it"})
+            row = {"config": name, "normals": normals, "shard_of": shard_of, "paths": count, "reps": reps, "preheat_ms": preheat_ms,
+                   "wall_ms_median": med * 1e3, "wall_ms_min": times[0] * 1e3, "device_side_efficiency": t_full[name] / (shard_of * med),
+                   "what": f"shard 0 of {shard_of} on this one GPU: T(1) / ({shard_of} T(shard)), hot / hot; the all-reduce between "
+                           "ranks is not in it"}
+            if cold is not None and t_full_cold.get(name):
+                row["cold"] = {"wall_ms_median": cold * 1e3, "device_side_efficiency": t_full_cold[name] / (shard_of * cold)}
+            shard_rows.append(row)
+    eng.set_normals("native")
     return {"scaling": "strong", "n_gpus": world, "rows": rows, "shard_rows": shard_rows,
-            "timing": "wall-clock, first launch -> all-reduced {sum, sum2, n} on the host, max over ranks; 2 warm-ups",
+            "timing": "wall-clock, first launch -> all-reduced {sum, sum2, n} on the host, max over ranks; every row HOT: "
+                      f"{preheat_ms:.0f} ms of this rank's own shard back to back, 2 warm-up calls, median of `reps`; base sizes also "
+                      "COLD (0.5 s idle first)",
             "note": "strong-scaling efficiency of a row = wall_ms_median(N=1) / (N * wall_ms_median(N)), from the driver's "
                     "own N = 1, 2, 4, 8 lines"}
 
@@ -276,7 +319,7 @@ def c_multi_block(max_seconds):
     if not os.path.exists(exe):
         return {"error": "drivers/multiBench not built (make -C drivers)"}
     try:
-        out = subprocess.run([exe, "--reps", "5"], capture_output=True, text=True, timeout=max_seconds)
+        out = subprocess.run([exe, "--reps", "10"], capture_output=True, text=True, timeout=max_seconds)
     except subprocess.TimeoutExpired:
         return {"error": f"drivers/multiBench exceeded {max_seconds} s"}
     rows = []
@@ -285,7 +328,7 @@ def c_multi_block(max_seconds):
             rows.append(json.loads(line))
         except ValueError:
             pass
-    res = {"command": "drivers/multiBench --reps 5", "rc": out.returncode, "rows": rows,
+    res = {"command": "drivers/multiBench --reps 10", "rc": out.returncode, "rows": rows,
            "what": "one C process, libmc_multi.so: mc_shard_range + mc_*_launch_* per device + ONE ncclAllReduce(3, ncclDouble); "
                    "wall-clock first launch -> closed estimate"}
     if out.returncode != 0:
@@ -332,8 +375,12 @@ def main():
                     help="untimed device work before the warm-up steps, so that the W warm-up steps and the K timed steps "
                          "run at the GPU's sustained clock (a cold MI355X needs tens of ms of load to ramp; with --warmup 5 "
                          "the timed region would otherwise measure the ramp).  Reported as config.preheat_ms; 0 = off")
-    ap.add_argument("--strong-reps", type=int, default=5,
-                    help="repeats of each strong-scaling row (C4, C5 and 10x sizes sharded over the N ranks; 0 = skip the block)")
+    ap.add_argument("--strong-reps", type=int, default=10,
+                    help="timed calls of each strong-scaling row (C4, C5, 10x sizes, and the same on fp32 normals, sharded over the N "
+                         "ranks; SURVEY 8d: median of >= 10; 0 = skip the block)")
+    ap.add_argument("--strong-preheat-ms", type=float, default=300.0,
+                    help="device load before every strong-scaling row (this rank's own shard, back to back), so that T(1) and "
+                         "T(shard) are both measured at the sustained clock; 0 = off")
     ap.add_argument("--c-multi-seconds", type=int, default=240,
                     help="N=1 only: time limit of the child process drivers/multiBench (the C library's own multi-GPU path over "
                          "1, 2, 4, 8 ... of the visible GPUs); 0 = skip")
@@ -576,7 +623,7 @@ def main():
     strong = None
     if args.strong_reps > 0 and args.workload == "vanilla_f32":
         strong = strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, args.backend, barrier,
-                                      args.strong_reps)
+                                      args.strong_reps, args.strong_preheat_ms)
 
     if rank == 0:
         tot = triples[W:].sum(dim=0).cpu().tolist()           # every step's triple is already all-reduced

@@ -115,6 +115,8 @@ class Engine:
         self.device = device
         self.blocks = lib().mc_context_blocks(self._ctx)
         self.stream = lib().mc_context_stream(self._ctx) or 0
+        # the C context also enters the fp32-normals mode from the environment at creation (mc_api.hip: context_allocate)
+        self._normals_f32 = os.environ.get("MC_F64_NORMALS") == "f32"
 
     def close(self):
         if self._ctx:
@@ -301,7 +303,7 @@ class Engine:
         return self._paths("cva", precision, _as_cva(precision, c), seed, first_path, n_paths)
 
     def normals(self, seed, domain, first_unit, n_units, block=0, precision="f64"):
-        npb = 4 if (precision == "f32" or getattr(self, "_normals_f32", False)) else 8
+        npb = 4 if (precision == "f32" or self._normals_f32) else 8
         out = np.empty(n_units * npb, dtype=NP[precision])
         check(getattr(lib(), f"mc_normals_{precision}")(self._ctx, seed, domain, first_unit, n_units, block,
                                                          out.ctypes.data_as(C.POINTER(_lib.CT[precision]))))

@@ -9,10 +9,12 @@
  * result must equal the host sum of the device triples.  Also: fewer paths than devices, error paths.
  * Prints one line per comparison; exit status 0 iff everything held.  Run by tests/test_gpu_multi.py.
  */
+#define _GNU_SOURCE
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "mc_multi.h"
 
@@ -154,6 +156,51 @@ int main(void)
         snprintf(label, sizeof label, "vanilla f64 %s, 2 paths", names[h]);
         compare(label, &got, &ref, 1e-12);
         printf("  last RCCL-vs-host relative difference on this handle: %.3g\n", mc_multi_last_reduce_error(m));
+    }
+    /* launcher threads (round 4): {0,0,0} runs one thread per device; the serial fan-out from the calling thread
+     * (MC_MULTI_THREADS=0, rounds 2-3) must give the same bits -- same shards, same kernels, same host sum in device order.
+     * 500 short calls back to back and calls after pauses longer than the linger time (parked workers). */
+    {
+        setenv("MC_MULTI_THREADS", "0", 1);
+        mc_multi *serial;
+        CHECK(mc_multi_create(d000, 3, 0, &serial));
+        unsetenv("MC_MULTI_THREADS");
+        CHECK(mc_multi_set_reduce(serial, MC_REDUCE_HOST));
+        printf("launcher threads: {0,0,0} default %d, MC_MULTI_THREADS=0 %d, {0} %d\n", mc_multi_launcher_threads(m_three),
+               mc_multi_launcher_threads(serial), mc_multi_launcher_threads(m_one));
+        failures += !(mc_multi_launcher_threads(m_three) == 3 && mc_multi_launcher_threads(serial) == 0 && mc_multi_launcher_threads(m_one) == 0);
+        mc_result a, b;
+        int same = 1;
+        for (int timing = 0; timing < 2; ++timing) {
+            CHECK(mc_multi_set_timing(m_three, timing));
+            CHECK(mc_multi_set_timing(serial, timing));
+            for (int rep = 0; rep < (timing ? 20 : 500); ++rep) {
+                const uint64_t cnt = 1000 + 977 * (uint64_t)rep;
+                CHECK(mc_multi_cva_run_f64(m_three, &c64, seed, first + rep, cnt, &a));
+                CHECK(mc_multi_cva_run_f64(serial, &c64, seed, first + rep, cnt, &b));
+                same = same && a.sum == b.sum && a.sum2 == b.sum2 && a.n == b.n;
+                if (rep % 100 == 99) {   /* let the workers park (linger 2 ms), then call again */
+                    struct timespec ts = {0, 5000000};
+                    nanosleep(&ts, NULL);
+                }
+            }
+        }
+        CHECK(mc_multi_basket_run_f32(m_three, &b32, seed, first, n / 4, &a));
+        CHECK(mc_multi_basket_run_f32(serial, &b32, seed, first, n / 4, &b));
+        same = same && a.sum == b.sum && a.sum2 == b.sum2 && a.n == b.n;
+        printf("%s threaded fan-out == serial fan-out bit for bit (520 CVA calls of growing size + a basket call); last fan-out %.1f us threaded, %.1f us serial\n",
+               same ? "ok   " : "MISMATCH", mc_multi_last_fanout_us(m_three), mc_multi_last_fanout_us(serial));
+        failures += !same;
+        /* a launch that fails on a worker thread: the status and the worker's own error text reach the caller */
+        mc_option_f64 badopt = v64;
+        badopt.s = -1;
+        const int rc = mc_multi_vanilla_run_f64(m_three, &badopt, seed, 0, 1000, &a);
+        printf("error text from a launcher thread: %s\n", mc_multi_last_error());
+        failures += !(rc == MC_ERR_INVALID && strstr(mc_multi_last_error(), "need s>0") != NULL);
+        CHECK(mc_multi_vanilla_run_f64(m_three, &v64, seed, 7, 1000, &a));   /* and the handle stays usable */
+        CHECK(mc_multi_vanilla_run_f64(serial, &v64, seed, 7, 1000, &b));
+        failures += !(a.sum == b.sum);
+        mc_multi_destroy(serial);
     }
     /* a 1e9-path fp64 basket call through the multi path (BASELINE configs[3] is n = 16; shape check only here) */
     CHECK(mc_multi_vanilla_run_f32(m_all ? m_all : m_one, &v32, seed, 0, 1000000000ull, &got));

@@ -60,13 +60,21 @@ def test_bench_contract_single_gpu():
     assert abs(d["fp64"]["price"] - BS) < 0.05
     # strong-scaling rows (C4, C5 and 10x) and the C library's own multi-GPU path are part of the N=1 line
     rows = {x["config"]: x for x in d["strong"]["rows"]}
-    assert set(rows) == {"C4", "C4x10", "C5", "C5x10"} and rows["C4"]["paths_priced"] == 10 ** 9 and rows["C5x10"]["paths_priced"] == 10 ** 8
+    base = {"C4", "C4x10", "C5", "C5x10"}
+    assert set(rows) == base | {c + "_n32" for c in base} and rows["C4"]["paths_priced"] == 10 ** 9 and rows["C5x10"]["paths_priced"] == 10 ** 8
     assert 9.70 < rows["C4"]["value"] < 9.74 and 0.1895 < rows["C5"]["value"] < 0.1905
+    assert 9.70 < rows["C4_n32"]["value"] < 9.74 and 0.1895 < rows["C5_n32"]["value"] < 0.1905      # the reference's dp arithmetic: same prices
+    assert rows["C4_n32"]["wall_ms_median"] < 0.8 * rows["C4"]["wall_ms_median"] and rows["C4_n32"]["normals"] == "f32"
     assert rows["C4x10"]["wall_ms_median"] == pytest.approx(10 * rows["C4"]["wall_ms_median"], rel=0.1)
+    # every row is measured hot (pre-heat) with >= 10 timed calls; the base sizes cold as well, and cold is never faster by much
+    assert all(x["reps"] >= 10 and x["preheat_ms"] == 300.0 for x in rows.values())
+    assert all(("cold" in rows[c]) == (not c.startswith(("C4x10", "C5x10"))) for c in rows)
+    assert rows["C5"]["cold"]["wall_ms_median"] > 0.95 * rows["C5"]["wall_ms_median"]
     # ... and, at N = 1, what one rank does at N = 2, 4, 8 (shard 0 of S): the device side of the scaling curve
     sh = {(x["config"], x["shard_of"]): x for x in d["strong"]["shard_rows"]}
     assert set(sh) == {(c, S) for c in rows for S in (2, 4, 8)} and sh[("C4", 8)]["paths"] == 125000000
     assert all(0.5 < x["device_side_efficiency"] < 1.1 for x in sh.values()) and sh[("C4x10", 8)]["device_side_efficiency"] > 0.9
+    assert sh[("C5", 8)]["device_side_efficiency"] > 0.9 and "cold" in sh[("C5", 8)]      # hot / hot: 0.96-0.99 measured
     cm = d["c_multi"]
     assert any("shard_of" in x for x in cm["rows"])
     assert cm["rc"] == 0 and any(x.get("workload", "").startswith("C4 basket") and x["devices"] == 1 for x in cm["rows"])

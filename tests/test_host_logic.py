@@ -97,3 +97,20 @@ def test_factor_from_cov_matches_reference_golden(mc, po):
     for badcov in ([[0.0, 0.0], [0.0, 1.0]], [[-1.0, 0.0], [0.0, 1.0]], [[float("nan"), 0.0], [0.0, 1.0]], [[1.0, 0.0], [float("inf"), 1.0]]):
         with pytest.raises(ValueError):
             mc.factor_from_cov(badcov)
+
+
+def test_multi_gpu_host_control_flow_without_a_gpu(tmp_path):
+    """libmc_multi.so's GPU-free control flow (csrc/mc_multi_host.hpp), driven by a plain g++ program on fake slots in
+    ordinary memory: the read-back polling loop of run_sharded (G = 3 with one slot never written must fail after ONE settle
+    of the streams; a slot delivered during the settle still counts), and the launcher-thread crew (every device's job on
+    its own thread, no hand-off lost while the workers spin nor after they parked).  One-GPU boxes never run G > 1 on real
+    devices, so this is where that logic is covered."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "multi_host_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-I", os.path.join(root, "montecarlocuda_amd", "csrc"),
+                           os.path.join(root, "tests", "cpp", "multi_host_check.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    print(out.stdout)
+    assert out.returncode == 0 and "all checks passed" in out.stdout and "FAILED" not in out.stdout, out.stdout + out.stderr

@@ -5,6 +5,10 @@
  *   multi host  libmc_multi, host reduction, pinned slots (no RCCL call, no publish kernel)
  *   multi rccl  libmc_multi, RCCL all-reduce over a communicator of ONE + publish kernel, pinned slots
  *   ... copy    the two multi forms with round 2's read-back (MC_MULTI_READBACK=copy is read at handle creation)
+ *   fan-out     EIGHT contexts on device 0 (the one-GPU stand-in for 8 devices; host reduction, RCCL refuses a repeated device),
+ *               1.25e6 paths sharded over them: host time from call entry until the LAST device's launch had been enqueued
+ *               (mc_multi_last_fanout_us), serial from the calling thread (MC_MULTI_THREADS=0: rounds 2-3) against one
+ *               launcher thread per device (round 4) -- VERDICT r03 "next" #1c asks for <= 6 us
  * Build on the GPU box:
  *   gcc -O2 -std=gnu11 -Iinclude tools/c/multi_cost.c -Lmontecarlocuda_amd/csrc -lmc_multi -lmc_mi355x -lm \
  *       -Wl,-rpath,$PWD/montecarlocuda_amd/csrc -Wl,-rpath-link,montecarlocuda_amd/csrc:/opt/rocm/lib -o /tmp/multi_cost */
@@ -80,6 +84,25 @@ int main(int argc, char **argv)
             report(name, wall, kern);
             mc_multi_destroy(m);
         }
+    }
+    /* fan-out over 8 "devices" */
+    for (int threads = 0; threads < 2; ++threads) {
+        if (threads) unsetenv("MC_MULTI_THREADS"); else setenv("MC_MULTI_THREADS", "0", 1);
+        const int dev8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        mc_multi *m;
+        if (mc_multi_create(dev8, 8, 0, &m) != MC_OK) { fprintf(stderr, "%s\n", mc_multi_last_error()); return 1; }
+        mc_multi_set_reduce(m, MC_REDUCE_HOST);
+        mc_multi_set_timing(m, 0);
+        double fan[REPS];
+        for (int i = -3; i < REPS; ++i) {
+            const double t0 = now_us();
+            if (mc_multi_cva_run_f64(m, &cva, MC_DEFAULT_SEED, 0, paths, &r) != MC_OK) { fprintf(stderr, "%s | %s\n", mc_multi_last_error(), mc_last_error()); return 1; }
+            if (i >= 0) wall[i] = now_us() - t0, fan[i] = mc_multi_last_fanout_us(m);
+        }
+        qsort(fan, REPS, sizeof *fan, cmp);
+        printf("fan-out over 8 contexts, %-28s call entry -> last launch enqueued: median %6.2f us  (min %5.2f, max %6.2f)   call wall median %8.1f us   [%d launcher threads]\n",
+               threads ? "one launcher thread each:" : "serial (MC_MULTI_THREADS=0):", fan[REPS / 2], fan[0], fan[REPS - 1], median(wall), mc_multi_launcher_threads(m));
+        mc_multi_destroy(m);
     }
     return 0;
 }
