@@ -150,17 +150,18 @@ int main(int argc, char **argv)
             if (time_row(m, &work[k], 0, work[k].paths, reps, events, 1, preheat_ms, &hot, &r)) return 1;
             const mc_result res = r;
             const double rel = mc_multi_last_reduce_error(m);
+            CHECK(mc_multi_set_timing(m, 1));   /* one more call with the per-device events, for kernel_ms (still hot) */
+            CHECK(one_call(m, &work[k], 0, work[k].paths, &r));
+            const float kernel_ms = r.kernel_ms;
             const int do_cold = cold && work[k].base;
             if (do_cold && time_row(m, &work[k], 0, work[k].paths, reps < 5 ? reps : 5, events, 0, 0, &cd, &r)) return 1;
-            CHECK(mc_multi_set_timing(m, 1));   /* one more call with the per-device events, for kernel_ms */
-            CHECK(one_call(m, &work[k], 0, work[k].paths, &r));
             if (G == 1)
                 t1[k] = hot.med, t1_cold[k] = cd.med;
             printf("{\"devices\": %d, \"workload\": \"%s\", \"normals\": \"%s\", \"paths\": %llu, \"reps\": %d, \"preheat_ms\": %.0f, \"wall_ms_median\": %.4f, "
                    "\"wall_ms_min\": %.4f, \"paths_per_s\": %.6g, \"strong_efficiency_vs_1\": %.4f, \"kernel_ms_slowest_device\": %.4f, "
                    "\"fanout_us\": %.2f, \"value\": %.9g, \"confidence_95\": %.3g, \"rccl_vs_host_rel\": %.3g",
                    G, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)work[k].paths, reps, hot.preheat_ms, hot.med * 1e3, hot.min * 1e3,
-                   (double)work[k].paths / hot.med, t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0, r.kernel_ms, hot.fanout_us, res.expected, res.confidence, rel);
+                   (double)work[k].paths / hot.med, t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0, kernel_ms, hot.fanout_us, res.expected, res.confidence, rel);
             if (do_cold)
                 printf(", \"cold\": {\"wall_ms_median\": %.4f, \"wall_ms_min\": %.4f, \"strong_efficiency_vs_1\": %.4f, \"what\": \"0.5 s idle, 2 warm-up calls, 5 calls\"}",
                        cd.med * 1e3, cd.min * 1e3, t1_cold[k] > 0 ? t1_cold[k] / (G * cd.med) : 0.0);
@@ -184,13 +185,14 @@ int main(int argc, char **argv)
                 mc_shard_range(work[k].paths, 0, G, &lo, &cnt);
                 Timing hot, cd = {0, 0, 0, 0, 0};
                 if (time_row(m, &work[k], lo, cnt, reps, events, 1, preheat_ms, &hot, &r)) return 1;
-                const int do_cold = cold && work[k].base;
-                if (do_cold && time_row(m, &work[k], lo, cnt, reps < 5 ? reps : 5, events, 0, 0, &cd, &r)) return 1;
                 CHECK(mc_multi_set_timing(m, 1));
                 CHECK(one_call(m, &work[k], lo, cnt, &r));
+                const float kernel_ms = r.kernel_ms;
+                const int do_cold = cold && work[k].base;
+                if (do_cold && time_row(m, &work[k], lo, cnt, reps < 5 ? reps : 5, events, 0, 0, &cd, &r)) return 1;
                 printf("{\"shard_of\": %d, \"devices\": 1, \"workload\": \"%s\", \"normals\": \"%s\", \"paths\": %llu, \"reps\": %d, \"preheat_ms\": %.0f, "
                        "\"wall_ms_median\": %.4f, \"wall_ms_min\": %.4f, \"kernel_ms\": %.4f, \"device_side_efficiency\": %.4f",
-                       G, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)cnt, reps, hot.preheat_ms, hot.med * 1e3, hot.min * 1e3, r.kernel_ms,
+                       G, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)cnt, reps, hot.preheat_ms, hot.med * 1e3, hot.min * 1e3, kernel_ms,
                        t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0);
                 if (do_cold)
                     printf(", \"cold\": {\"wall_ms_median\": %.4f, \"device_side_efficiency\": %.4f}", cd.med * 1e3,

@@ -166,7 +166,7 @@ int mc_xorwow_words(mc_context *ctx, uint64_t seed, uint64_t first_subsequence, 
  * widened to double (dp/MonteCarloKernel.cu:68,78,250): four normals per Philox block through the hardware
  * fp32 transcendentals, everything downstream of the normal in fp64.  A different (coarser: 24-bit normals, |z| < 6.77)
  * stream than the default, same path indexing; about 1.4-1.7x the paths/s on the 16-asset basket and the 256-date CVA
- * (DESIGN.md).  Philox only; no effect on the _f32 entry points; the Greeks entry points refuse it.  Also selected at
+ * (DESIGN.md).  Philox only; no effect on the _f32 entry points (their Greeks included); the fp64 Greeks entry points refuse it.  Also selected at
  * context creation by the environment variable MC_F64_NORMALS=f32 (how the legacy symbols get it). */
 enum { MC_NORMALS_NATIVE = 0, MC_NORMALS_F32 = 1 };
 int mc_context_set_normals(mc_context *ctx, int mode);
@@ -220,7 +220,8 @@ int mc_context_order(mc_context *ctx, void *stream);
  * flight per context; a synchronous mc_*_run_* call before the launch cancels the arming; needs the fused final
  * reduction (the default).
  * mc_context_publish: enqueues on `stream` a one-lane kernel that copies the three doubles at d_src (device memory: e.g.
- * the output of an all-reduce enqueued on that stream before it) into a second slot of the context, same protocol. */
+ * the output of an all-reduce enqueued on that stream before it) into a second slot of the context, same protocol.
+ * ONE publish in flight per context as well: a second publish before the first slot has been read re-arms the same slot. */
 int mc_context_arm_direct(mc_context *ctx, const volatile double **slot);
 int mc_context_publish(mc_context *ctx, const double *d_src, void *stream, const volatile double **slot);
 

@@ -577,7 +577,9 @@ extern "C" int mc_context_publish(mc_context *c, const double *d_src, void *stre
 {
     if (!c || !d_src || !slot)
         return fail(MC_ERR_INVALID, "mc_context_publish: bad argument");
-    HIPCHK(hipSetDevice(c->device));
+    // a call of the context like any other: ordered behind its previous call, and recorded as its last stream, so that
+    // quiesce() -- before the pinned slots are freed -- waits for this kernel too whatever stream it runs on
+    if (int rc = begin_call(c, (hipStream_t)stream)) return rc;
     volatile double *s = c->h_direct + 8;
     s[2] = DIRECT_SENTINEL;
     __atomic_thread_fence(__ATOMIC_SEQ_CST);
@@ -1027,13 +1029,15 @@ static int ensure_planes(mc_context *c, int planes)
 }
 
 // launch(tail, segment index, segment, grid) enqueues one segment; grid_y = workgroups per x position (arrivals)
+// real_bytes = sizeof the simulation type: the fp32-normals mode concerns the fp64 kernels only (mc_mi355x.h: "no effect on
+// the _f32 entry points"), so only the fp64 Greeks refuse it
 template <class Launch>
-static int planes_run(mc_context *c, int planes, int grid_y, uint64_t unit0, uint64_t n_units, uint64_t n, double discount,
+static int planes_run(mc_context *c, size_t real_bytes, int planes, int grid_y, uint64_t unit0, uint64_t n_units, uint64_t n, double discount,
                       mc_result **out, Launch launch)
 {
     const auto wall0 = std::chrono::steady_clock::now();
     hipStream_t st = c->stream;
-    if (c->rng != MC_RNG_PHILOX || c->normals_f32)
+    if (c->rng != MC_RNG_PHILOX || (real_bytes == 8 && c->normals_f32))
         return fail(MC_ERR_UNSUPPORTED, "greeks: implemented for the Philox generator with native normals only");
     if (int rc = begin_call(c, st)) return rc;
     if (int rc = ensure_planes(c, planes)) return rc;
@@ -1104,7 +1108,7 @@ static int greeks_run(mc_context *c, const In *o, uint64_t seed, uint64_t first,
     greeks_prepare(*o, k);
     const uint64_t end = first + n, u0 = first / NPB, u1 = (end + NPB - 1) / NPB;
     mc_result *r[3] = {&out->price, &out->delta, &out->vega};
-    return planes_run(c, 3, 1, u0, u1 - u0, n, std::exp(-(double)o->r * (double)o->t), r,
+    return planes_run(c, sizeof(Real), 3, 1, u0, u1 - u0, n, std::exp(-(double)o->r * (double)o->t), r,
                       [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
                           vanilla_greeks_kernel<Opt, Real, LR><<<g, GROUP, 0, st>>>(t, k, make_work(seed, s, first, end));
                       });
@@ -1704,7 +1708,7 @@ static int basket_greeks_run(mc_context *c, const typename BasketIn<Real>::type 
     out[0] = price;
     for (int a = 0; a < na; ++a)
         out[1 + a] = delta + a, out[1 + na + a] = vega + a;
-    return planes_run(c, 1 + 2 * na, na, first, n, n, std::exp(-(double)o->r * (double)o->t), out.data(),
+    return planes_run(c, sizeof(Real), 1 + 2 * na, na, first, n, n, std::exp(-(double)o->r * (double)o->t), out.data(),
                       [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
                           hipLaunchKernelGGL(basket_greeks_kernel<Real>, dim3(g, na), dim3(GROUP), lds, st, t, k, make_work(seed, s, 0, 0));
                       });
@@ -1733,7 +1737,7 @@ static int cva_greeks_run(mc_context *c, const typename CvaIn<Real>::type *v, ui
     const Real inv_spot = (Real)(1.0 / (double)v->option.s);
     const Real dt = v->option.t / v->n_grid;   // the table's own dt (build_cva_table)
     const Real sqrt_dt = (Real)std::sqrt((double)dt);
-    return planes_run(c, 3, 1, first, n, n, 1.0, r, [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
+    return planes_run(c, sizeof(Real), 3, 1, first, n, n, 1.0, r, [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
         cva_greeks_kernel<Real><<<g, GROUP, 0, st>>>(t, args, make_work(seed, s, 0, 0), inv_spot, sqrt_dt);
     });
 }

@@ -69,7 +69,7 @@ def test_bench_contract_single_gpu():
     # every row is measured hot (pre-heat) with >= 10 timed calls; the base sizes cold as well, and cold is never faster by much
     assert all(x["reps"] >= 10 and x["preheat_ms"] == 300.0 for x in rows.values())
     assert all(("cold" in rows[c]) == (not c.startswith(("C4x10", "C5x10"))) for c in rows)
-    assert rows["C5"]["cold"]["wall_ms_median"] > 0.95 * rows["C5"]["wall_ms_median"]
+    assert rows["C5"]["cold"]["wall_ms_median"] > 0.9 * rows["C5"]["wall_ms_median"]
     # ... and, at N = 1, what one rank does at N = 2, 4, 8 (shard 0 of S): the device side of the scaling curve
     sh = {(x["config"], x["shard_of"]): x for x in d["strong"]["shard_rows"]}
     assert set(sh) == {(c, S) for c in rows for S in (2, 4, 8)} and sh[("C4", 8)]["paths"] == 125000000

@@ -167,10 +167,23 @@ def test_mode_is_refused_where_it_is_not_implemented(mc, eng):
             eng.vanilla(VAN, 4096, SEED, 0, "f64")
     finally:
         eng.set_generator("philox", 0)
-    # the fp32 entry points are unaffected by the mode
+    # the fp32 entry points are unaffected by the mode -- their Greeks included (planes_run refused them all)
     native = mc.Engine(0)
     try:
         assert eng.vanilla(VAN, 10 ** 6, SEED, 0, "f32").sum == native.vanilla(VAN, 10 ** 6, SEED, 0, "f32").sum
+        for a, b in zip(eng.vanilla_greeks(VAN, 10 ** 5, SEED, 3, "f32"), native.vanilla_greeks(VAN, 10 ** 5, SEED, 3, "f32")):
+            assert a.sum == b.sum and a.sum2 == b.sum2 and a.n == b.n
+        for a, b in zip(eng.vanilla_greeks_lr(VAN, 10 ** 5, SEED, 3, "f32"), native.vanilla_greeks_lr(VAN, 10 ** 5, SEED, 3, "f32")):
+            assert a.sum == b.sum and a.sum2 == b.sum2
+        bk = basket_inputs(mc, 4)
+        pa, da, va = eng.basket_greeks(bk, 20000, SEED, 0, "f32")
+        pb, db, vb = native.basket_greeks(bk, 20000, SEED, 0, "f32")
+        assert pa.sum == pb.sum and [x.sum for x in da] == [x.sum for x in db] and [x.sum for x in va] == [x.sum for x in vb]
+        c = dict(CVA0, n_grid=16)
+        for a, b in zip(eng.cva_greeks(c, 20000, SEED, 0, "f32"), native.cva_greeks(c, 20000, SEED, 0, "f32")):
+            assert a.sum == b.sum and a.sum2 == b.sum2
+        with pytest.raises(mc.McError, match="native normals"):      # the fp64 ones still refuse it
+            eng.cva_greeks(c, 1000, SEED, 0, "f64")
     finally:
         native.close()
 
@@ -179,7 +192,17 @@ def test_environment_variable_selects_the_mode_for_the_legacy_symbols(mc, monkey
     monkeypatch.setenv("MC_F64_NORMALS", "f32")
     e = mc.Engine(0)
     try:
-        e._normals_f32 = True
-        assert e.normals(SEED, 1, 0, 8, 0, "f64").shape == (8, 4)
+        # the Python mirror follows the C context, which reads the variable at creation (normals() used to allocate
+        # 8 per unit and hand back a half-written array)
+        assert e._normals_f32 is True
+        z = e.normals(SEED, 1, 0, 8, 0, "f64")
+        assert z.shape == (8, 4) and np.isfinite(z).all() and np.abs(z).max() < 6.77
+        assert np.array_equal(z, e.normals(SEED, 1, 0, 8, 0, "f32").astype(np.float64))
+    finally:
+        e.close()
+    monkeypatch.delenv("MC_F64_NORMALS")
+    e = mc.Engine(0)
+    try:
+        assert e._normals_f32 is False and e.normals(SEED, 1, 0, 8, 0, "f64").shape == (8, 8)
     finally:
         e.close()
