@@ -156,11 +156,6 @@ int mc_context_set_timing(mc_context *ctx, int on);
  * calls run at Philox speed, baskets on the generic kernel; Greeks are Philox-only.  Subsequence numbers stay below 2^48. */
 enum { MC_RNG_PHILOX = 0, MC_RNG_XORWOW = 1 };
 int mc_context_set_generator(mc_context *ctx, int generator, uint64_t subsequence_base);
-/* The generator alone (tests): words_each consecutive 32-bit outputs of each of the XORWOW subsequences
- * first_subsequence .. first_subsequence + n_subsequences - 1 for `seed`, subsequence-major, to the HOST array h_out. */
-int mc_xorwow_words(mc_context *ctx, uint64_t seed, uint64_t first_subsequence, uint32_t n_subsequences,
-                    uint32_t words_each, uint32_t *h_out);
-
 /* Normals of the fp64 kernels.  MC_NORMALS_NATIVE (default): true fp64 normals, two per Philox block (52-bit uniforms,
  * mc_math_f64.hpp).  MC_NORMALS_F32: the reference's own dp arithmetic -- `double z = curand_normal(...)`, a FLOAT normal
  * widened to double (dp/MonteCarloKernel.cu:68,78,250): four normals per Philox block through the hardware
@@ -299,46 +294,6 @@ int mc_cva_paths_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
                      uint64_t first_path, uint64_t n_paths, float *h_out);
 int mc_cva_paths_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed,
                      uint64_t first_path, uint64_t n_paths, double *h_out);
-/* The normals of Philox blocks (unit = first_unit .. first_unit+n_units-1, block, domain):
- * 4 per unit in f32, 8 per unit in f64 (4 under MC_NORMALS_F32), written unit-major to the HOST array h_out.  In f64 block b
- * of the stream is Philox blocks 3b .. 3b + 2 (MC_STREAM_VERSION 2). */
-int mc_normals_f32(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,
-                   uint64_t n_units, uint32_t block, float *h_out);
-int mc_normals_f64(mc_context *ctx, uint64_t seed, uint32_t domain, uint64_t first_unit,
-                   uint64_t n_units, uint32_t block, double *h_out);
-
-/* ---- test hooks: the simulation kernels on a caller-supplied normal stream -------------------------------------
- * NOT part of the drop-in surface; speed irrelevant.  They run the pricing call's own simulation kernel for that size --
- * payoff, per-lane sums and fp32 flushes, DPP/LDS reduction, last-arriver final reduction -- instantiated with a
- * generator policy that READS the normals from HBM instead of drawing them, so that the reference's normal stream
- * (glibc rand() + Box-Muller, MonteCarloHost.c:111-121) can be pushed through the HIP path and the result compared with
- * numbers the compiled reference printed (tests/test_gpu_from_normals.py, tests/golden/ref_mc.json).
- *   h_normals  HOST array.  vanilla: n_paths values, path i uses h_normals[i].  basket: n_paths * opt->n, path i's
- *              normals in drawing order (MonteCarloHost.c:150-161).  CVA: n_paths * n_grid, date j of path i at
- *              [i * n_grid + j - 1].
- *   h_values   HOST array of n_paths per-path values (undiscounted), or NULL.
- *   flags      MC_FROM_NORMALS_NO_VOL (basket): the diffusion without the volatility -- the model the reference's dp
- *              CPU path computes (dp/MonteCarloHost.c:180); only its goldens need it.
- *              MC_FROM_NORMALS_HOST_ORDER (CVA): the reference CPU loop's ordering, exposure of date j at the spot of
- *              date j - 1 (dp/MonteCarloHost.c:254-261).
- * Kernels: vanilla -- the hot kernels (whole units) + the masked kernel (a partial last unit, per-path values);
- * basket -- 3 and 4 assets: the kernel-argument kernels, 16: the tiled kernels, otherwise the generic kernel;
- * CVA -- cva_kernel.  Plain estimator, at most 2^26 paths. */
-#define MC_FROM_NORMALS_NO_VOL 1
-#define MC_FROM_NORMALS_HOST_ORDER 2
-int mc_vanilla_from_normals_f32(mc_context *ctx, const mc_option_f32 *opt, const float *h_normals, uint64_t n_paths,
-                                float *h_values, mc_result *out);
-int mc_vanilla_from_normals_f64(mc_context *ctx, const mc_option_f64 *opt, const double *h_normals, uint64_t n_paths,
-                                double *h_values, mc_result *out);
-int mc_basket_from_normals_f32(mc_context *ctx, const mc_basket_f32 *opt, const float *h_normals, uint64_t n_paths,
-                               int flags, float *h_values, mc_result *out);
-int mc_basket_from_normals_f64(mc_context *ctx, const mc_basket_f64 *opt, const double *h_normals, uint64_t n_paths,
-                               int flags, double *h_values, mc_result *out);
-int mc_cva_from_normals_f32(mc_context *ctx, const mc_cva_f32 *cva, const float *h_normals, uint64_t n_paths,
-                            int flags, float *h_values, mc_result *out);
-int mc_cva_from_normals_f64(mc_context *ctx, const mc_cva_f64 *cva, const double *h_normals, uint64_t n_paths,
-                            int flags, double *h_values, mc_result *out);
-
 /* ---- compatibility mode: the reference's launch geometry and per-thread XORWOW streams ---------------------------
  * The reference's result depends on (numBlocks, numThreads): dp/MonteCarloKernel.cu:285-290 gives every thread of the
  * launch its own cuRAND XORWOW state, curand_init(seed = blockIdx.x + gridDim.x, subsequence = threadIdx.x, offset 0);
@@ -351,10 +306,15 @@ int mc_cva_from_normals_f64(mc_context *ctx, const mc_cva_f64 *cva, const double
  * cuRAND itself seeds XORWOW with other constants and is not in this image: equality with an NVIDIA run of the reference
  * is NOT claimed ("parity unpinned").
  *   n = num_blocks * paths_per_block paths are priced (the reference's numBlocks * (sims / numBlocks)).
- * The normals of the call are first written to HBM (one Real per draw) and then priced by the same simulation kernels as
- * mc_*_run_* through the external-normals policy; a compatibility path, not a fast one.  Plain estimator only; the
- * context's generator / normals settings are ignored.  num_threads <= 1024, at most 2^24 threads and 2^31 paths.
- * mc_result.kernel_ms covers the pricing kernel only; wall_ms the whole call from the moment the normals are enqueued. */
+ * How it runs (round 4): the call IS the reference's launch -- num_blocks workgroups of num_threads threads, every thread
+ * with its XORWOW state and Box-Muller pair in registers, pricing its own paths through the per-path code of the hot kernels;
+ * no normal touches HBM (1e8 vanilla paths at 512 x 128: 0.40 ms in round 3's staged form, see DESIGN.md for this one).
+ * Shapes without a fused kernel (baskets beyond 16 assets, more blocks than the context's pair buffer holds) take round
+ * 3's staged form: the normals of the call are written to HBM (one Real per draw) and priced by the simulation kernels
+ * of mc_*_run_* through the external-normals policy -- same sample, same per-path values.  MC_GRID_FORM=staged / fused in
+ * the environment forces a form.  The start states of a geometry are set up on first use and kept (the last 4 geometries).
+ * Plain estimator only; the context's generator / normals settings are ignored.  num_threads <= 1024, at most 2^24 threads
+ * and 2^31 paths.  mc_result.kernel_ms covers the pricing kernel only; wall_ms the whole call. */
 int mc_vanilla_run_grid_f32(mc_context *ctx, const mc_option_f32 *opt, int num_blocks, int num_threads,
                             uint64_t paths_per_block, mc_result *out);
 int mc_vanilla_run_grid_f64(mc_context *ctx, const mc_option_f64 *opt, int num_blocks, int num_threads,
@@ -367,9 +327,6 @@ int mc_cva_run_grid_f32(mc_context *ctx, const mc_cva_f32 *cva, int num_blocks, 
                         uint64_t paths_per_block, mc_result *out);
 int mc_cva_run_grid_f64(mc_context *ctx, const mc_cva_f64 *cva, int num_blocks, int num_threads,
                         uint64_t paths_per_block, mc_result *out);
-/* The first `count` normals of every thread's stream: h_out[(b * num_threads + t) * count + k] (tests). */
-int mc_grid_normals(mc_context *ctx, int num_blocks, int num_threads, uint32_t count, float *h_out);
-
 /* ---- host-side helpers -------------------------------------------------------------- */
 /* Closing formulas of dp/MonteCarloKernel.cu:420-423 (discount = exp(-rT)) and :466-468
  * (discount = 1), in fp64, from an (all-reduced) triple. */

@@ -1,4 +1,4 @@
-"""ctypes declarations for libmc_mi355x.so (include/mc_mi355x.h).
+"""ctypes declarations for libmc_mi355x.so (include/mc_mi355x.h, and the test hooks of include/mc_mi355x_test.h).
 
 Loading is strict: if the shared library is missing the import of this module raises -- there
 is no Python or CPU fallback for the simulation path.
@@ -73,16 +73,24 @@ OPTION = {"f32": OptionF32, "f64": OptionF64}
 BASKET = {"f32": BasketF32, "f64": BasketF64}
 CVA = {"f32": CvaF32, "f64": CvaF64}
 
-# every symbol include/mc_mi355x.h declares (tests/test_abi.py checks the .so exports them all)
+# every symbol include/mc_mi355x.h declares (the drop-in surface), then the test hooks of include/mc_mi355x_test.h;
+# tests/test_abi.py checks that the .so exports each of them and that each is declared in exactly one of the two headers
 EXPORTS = ["mc_last_error", "mc_device_count", "mc_context_create", "mc_context_destroy", "mc_context_device",
-           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read", "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing", "mc_context_order", "mc_context_idle", "mc_context_arm_direct", "mc_context_publish", "mc_context_set_generator", "mc_context_set_normals", "mc_xorwow_words", "mc_grid_normals", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range", "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
+           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_profile", "mc_context_profile_read",
+           "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing",
+           "mc_context_order", "mc_context_idle", "mc_context_arm_direct", "mc_context_publish", "mc_context_set_generator",
+           "mc_context_set_normals", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range",
+           "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
+TEST_EXPORTS = ["mc_xorwow_words", "mc_grid_normals", "mc_context_set_grid_form"]
 for _x in ("f32", "f64"):
     for _p in ("vanilla", "basket", "cva"):
         EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]
-    EXPORTS.append(f"mc_normals_{_x}")
-    EXPORTS += [f"mc_{_p}_from_normals_{_x}" for _p in ("vanilla", "basket", "cva")]   # test hooks
     EXPORTS += [f"mc_{_p}_run_grid_{_x}" for _p in ("vanilla", "basket", "cva")]       # the reference's launch geometry
     EXPORTS += [f"mc_vanilla_greeks_run_{_x}", f"mc_vanilla_greeks_lr_run_{_x}", f"mc_basket_greeks_run_{_x}", f"mc_cva_greeks_run_{_x}"]
+    TEST_EXPORTS.append(f"mc_normals_{_x}")
+    TEST_EXPORTS += [f"mc_{_p}_from_normals_{_x}" for _p in ("vanilla", "basket", "cva")]
+    TEST_EXPORTS += [f"mc_{_p}_paths_grid_{_x}" for _p in ("vanilla", "basket", "cva")]
+GRID_FORM = {"auto": 0, "staged": 1, "fused": 2}
 
 
 def _declare(L: C.CDLL) -> C.CDLL:
@@ -110,6 +118,7 @@ def _declare(L: C.CDLL) -> C.CDLL:
     L.mc_context_set_generator.argtypes = [ctx, C.c_int, C.c_uint64]
     L.mc_context_set_normals.argtypes = [ctx, C.c_int]
     L.mc_grid_normals.argtypes = [ctx, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float)]
+    L.mc_context_set_grid_form.argtypes = [ctx, C.c_int]
     L.mc_xorwow_words.argtypes = [ctx, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     for X in ("f32", "f64"):
         getattr(L, f"mc_basket_control_mean_{X}").argtypes = [C.POINTER(BASKET[X]), C.POINTER(C.c_double)]
@@ -129,6 +138,7 @@ def _declare(L: C.CDLL) -> C.CDLL:
             getattr(L, f"mc_{prod}_run_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, C.POINTER(Result)]
             getattr(L, f"mc_{prod}_paths_{X}").argtypes = [ctx, C.POINTER(S), u64, u64, u64, RP]
             getattr(L, f"mc_{prod}_run_grid_{X}").argtypes = [ctx, C.POINTER(S), C.c_int, C.c_int, u64, C.POINTER(Result)]
+            getattr(L, f"mc_{prod}_paths_grid_{X}").argtypes = [ctx, C.POINTER(S), C.c_int, C.c_int, u64, RP]
         getattr(L, f"mc_normals_{X}").argtypes = [ctx, u64, C.c_uint32, u64, u64, C.c_uint32, RP]
         getattr(L, f"mc_vanilla_from_normals_{X}").argtypes = [ctx, C.POINTER(OPTION[X]), RP, u64, RP, C.POINTER(Result)]
         getattr(L, f"mc_basket_from_normals_{X}").argtypes = [ctx, C.POINTER(BASKET[X]), RP, u64, C.c_int, RP, C.POINTER(Result)]

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/mc_mi355x.h"
+#include "../../include/mc_mi355x_test.h"
 #include "mc_hostmath.h"
 #include "mc_grid.hpp"
 #include "mc_kernels.hpp"
@@ -86,8 +87,11 @@ struct mc_context {
     uint32_t *d_xorwow_jump = nullptr;   // jump matrices A^(2^67 2^i), i < XORWOW_JUMP_BITS
     bool xorwow_valid = false;           // d_xorwow holds the states of (xorwow_seed, xorwow_state_base)
     uint64_t xorwow_seed = 0, xorwow_state_base = 0;
-    uint32_t *d_grid_states = nullptr;   // launch-geometry mode: one start state per (block, thread) of the cached geometry
-    int grid_blocks = 0, grid_threads = 0;
+    // launch-geometry mode: one start state per (block, thread), cached for the last GRID_CACHE geometries used
+    struct GridStates { int blocks, threads; uint32_t *d; uint64_t last_used; };
+    std::vector<GridStates> grid_cache;
+    uint64_t grid_clock = 0;
+    int grid_form = MC_GRID_FORM_AUTO;   // fused kernels where they exist, otherwise staged through HBM (MC_GRID_FORM, mc_context_set_grid_form)
     bool normals_f32 = false;     // fp64 kernels draw fp32 normals, widened (the reference's dp arithmetic): GenPhiloxF32N
     // external normals (mc_*_from_normals_*, mc_*_run_grid_*): set around one enqueue
     const void *ext = nullptr;    // device array, ext_per_unit Reals per unit
@@ -182,6 +186,8 @@ static int context_allocate(mc_context *c)
         c->fused = strcmp(e, "kernel") != 0;
     if (const char *e = getenv("MC_F64_NORMALS"))   // "f32": the reference's dp arithmetic (mc_context_set_normals)
         c->normals_f32 = strcmp(e, "f32") == 0;
+    if (const char *e = getenv("MC_GRID_FORM"))     // launch-geometry mode: "staged" / "fused" force a form (default: fused where compiled)
+        c->grid_form = strcmp(e, "staged") == 0 ? MC_GRID_FORM_STAGED : (strcmp(e, "fused") == 0 ? MC_GRID_FORM_FUSED : MC_GRID_FORM_AUTO);
     return MC_OK;
 }
 
@@ -230,7 +236,7 @@ extern "C" void mc_context_destroy(mc_context *c)
     (void)hipFree(c->tickets);
     (void)hipFree(c->d_xorwow);
     (void)hipFree(c->d_xorwow_jump);
-    (void)hipFree(c->d_grid_states);
+    for (const mc_context::GridStates &g : c->grid_cache) (void)hipFree(g.d);
     if (c->last_use) (void)hipEventDestroy(c->last_use);
     (void)hipFree(c->d_triple);
     (void)hipFree(c->g_pairs);
@@ -1171,21 +1177,29 @@ static int basket_launch_kernel(mc_context *c, ProfileScope &prof, bool anti, co
 // only be met on that model.  The drift keeps the true volatility, as it does there.
 static double diffusion_vol(const mc_context *c, double v) { return (c->ext && (c->ext_flags & MC_FROM_NORMALS_NO_VOL)) ? 1.0 : v; }
 
+// Folds a basket of o.n <= NA assets into the kernel-argument constants of size NA (rows beyond o.n: zero factor, base and
+// weight -- they add exactly 0 to the basket).  out_scale = what the kernel's per-path values are multiplied by to give
+// currency units (fp32: the exact power of two of the [0,1] rescale; 1/2 of it under antithetic variates, whose fp32
+// kernels return the SUM of the two mirrored payoffs).
 template <class Real, int NA>
-static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
-                           const std::vector<Segment> &segs, hipStream_t st, Real *out, uint64_t n_paths, double *d_triple)
+static int basket_fold(mc_context *c, const typename BasketIn<Real>::type &o, BasketArgs<Real, NA> &k, double &out_scale)
 {
+    const int n = o.n;
     double scale = 1.0;
-    BasketArgs<Real, NA> k;
     constexpr bool is_f32 = sizeof(Real) == 4;
     const double sc = exp_scale<Real>();
     const double sqrt_t = std::sqrt((double)o.t);
     double m[NA][NA], base[NA], coef[NA];
     for (int a = 0; a < NA; ++a) {
+        base[a] = coef[a] = 0;
+        for (int b = 0; b < NA; ++b)
+            m[a][b] = 0;
+    }
+    for (int a = 0; a < n; ++a) {
         const double va = (double)o.v[a];
         const double vd = diffusion_vol(c, va);   // va, except under the bridge tests' reference-CPU-bug switch
         for (int b = 0; b <= a; ++b)
-            m[a][b] = vd * sqrt_t * (double)o.p[a * NA + b] * sc;
+            m[a][b] = vd * sqrt_t * (double)o.p[a * n + b] * sc;
         base[a] = (((double)o.r - 0.5 * va * va) * (double)o.t + vd * sqrt_t * (double)o.d[a]) * sc;
         coef[a] = (double)o.w[a] * (double)o.s[a];
         double bound = std::fabs(base[a]);
@@ -1200,7 +1214,7 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
         // an exact power of two so that the device's [0,1] clamp is the payoff's max(.,0)
         const double zmax = 6.77;
         double bound = 0;
-        for (int a = 0; a < NA; ++a) {
+        for (int a = 0; a < n; ++a) {
             double x = base[a];
             for (int b = 0; b <= a; ++b)
                 x += std::fabs(m[a][b]) * zmax;
@@ -1214,7 +1228,7 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
             return fail(MC_ERR_INVALID, "basket f32: inputs out of the float range (scale 2^%g)", kk);
         scale = std::ldexp(1.0, (int)kk);
     }
-    const double out_scale = (is_f32 && c->antithetic) ? 0.5 * scale : scale;  // f32 anti: kernel returns the SUM
+    out_scale = (is_f32 && c->antithetic) ? 0.5 * scale : scale;  // f32 anti: kernel returns the SUM
     for (int a = 0; a < NA; ++a) {
         for (int b = 0; b <= a; ++b)
             k.m[a * (a + 1) / 2 + b] = (Real)m[a][b];
@@ -1229,9 +1243,9 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
         double cv_mean;
         if (int rc = control_mean(o, &cv_mean)) return rc;  // validates w > 0, s > 0, k > 0
         double W = 0, cg = 0;
-        for (int a = 0; a < NA; ++a)
+        for (int a = 0; a < n; ++a)
             W += (double)o.w[a];
-        for (int a = 0; a < NA; ++a) {
+        for (int a = 0; a < n; ++a) {
             k.wg[a] = (Real)((double)o.w[a] / W);
             cg += (double)o.w[a] / W * std::log((double)o.s[a]);
         }
@@ -1239,6 +1253,17 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
         k.cg = (Real)((cg + std::log(W)) * sc - (is_f32 ? std::log2(scale) : 0.0));
         k.cv = 1;
     }
+    return MC_OK;
+}
+
+template <class Real, int NA>
+static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename BasketIn<Real>::type &o, uint64_t seed,
+                           const std::vector<Segment> &segs, hipStream_t st, Real *out, uint64_t n_paths, double *d_triple)
+{
+    constexpr bool is_f32 = sizeof(Real) == 4;
+    BasketArgs<Real, NA> k;
+    double out_scale = 1.0;
+    if (int rc = basket_fold<Real, NA>(c, o, k, out_scale)) return rc;
     int total = 0, slot = 0;
     for (const Segment &s : segs)
         total += grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
@@ -1953,47 +1978,120 @@ static int grid_check(mc_context *c, const void *opt, int num_blocks, int num_th
     return MC_OK;
 }
 
-// the (num_blocks x num_threads) start states, cached in the context per geometry
-static int grid_states_ready(mc_context *c, int num_blocks, int num_threads)
+// the (num_blocks x num_threads) start states: cached in the context for the last GRID_CACHE geometries used (the set-up is
+// a 48-step GF(2) jump per thread, < 1 ms for the reference's 512 x 128; the jump matrices themselves are computed once per
+// process, ~20 ms on the host).  All launch-geometry work runs on the context's own stream, so a cached array is never read
+// by a kernel that started before it was filled.
+static constexpr size_t GRID_CACHE = 4;
+static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, const uint32_t **states)
 {
     const uint32_t lanes = (uint32_t)num_blocks * (uint32_t)num_threads;
-    if (c->grid_blocks == num_blocks && c->grid_threads == num_threads && c->d_grid_states)
-        return MC_OK;
+    for (mc_context::GridStates &g : c->grid_cache)
+        if (g.blocks == num_blocks && g.threads == num_threads) {
+            g.last_used = ++c->grid_clock;
+            *states = g.d;
+            return MC_OK;
+        }
     if (int rc = xorwow_jump_ready(c)) return rc;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->d_grid_states) HIPCHK(hipFree(c->d_grid_states));
-    c->d_grid_states = nullptr, c->grid_blocks = c->grid_threads = 0;
-    HIPCHK(hipMalloc(&c->d_grid_states, sizeof(uint32_t) * 6 * (size_t)lanes));
-    xorwow_grid_init_kernel<<<(lanes + 255) / 256, 256, 0, c->stream>>>(c->d_xorwow_jump, (uint32_t)num_blocks, (uint32_t)num_threads,
-                                                                         c->d_grid_states);
-    HIPCHK(hipGetLastError());
-    c->grid_blocks = num_blocks, c->grid_threads = num_threads;
+    if (c->grid_cache.size() >= GRID_CACHE) {   // evict the least recently used geometry (no kernel may still read it)
+        HIPCHK(hipStreamSynchronize(c->stream));
+        size_t lru = 0;
+        for (size_t i = 1; i < c->grid_cache.size(); ++i)
+            if (c->grid_cache[i].last_used < c->grid_cache[lru].last_used)
+                lru = i;
+        HIPCHK(hipFree(c->grid_cache[lru].d));
+        c->grid_cache.erase(c->grid_cache.begin() + (long)lru);
+    }
+    uint32_t *d = nullptr;
+    HIPCHK(hipMalloc(&d, sizeof(uint32_t) * 6 * (size_t)lanes));
+    xorwow_grid_init_kernel<<<(lanes + 255) / 256, 256, 0, c->stream>>>(c->d_xorwow_jump, (uint32_t)num_blocks, (uint32_t)num_threads, d);
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFree(d);
+        return fail(MC_ERR_HIP, "launch geometry: the state set-up kernel failed to launch");
+    }
+    c->grid_cache.push_back({num_blocks, num_threads, d, ++c->grid_clock});
+    *states = d;
     return MC_OK;
 }
 
+extern "C" int mc_context_set_grid_form(mc_context *c, int form)
+{
+    if (!c || (form != MC_GRID_FORM_AUTO && form != MC_GRID_FORM_STAGED && form != MC_GRID_FORM_FUSED))
+        return fail(MC_ERR_INVALID, "mc_context_set_grid_form: bad argument");
+    c->grid_form = form;
+    return MC_OK;
+}
+
+// ---- staged form (round 3): normals into HBM, then the engine's kernels through the external-normals policy -------------
 // `draws` normals per path into rows of `row` Reals (the buffer zero-padded to `padded` Reals in all), then `enqueue` with
-// the external-normals policy reading `per_unit` Reals per unit
+// the external-normals policy reading `per_unit` Reals per unit.  h_values: per-path dump (tests) instead of the estimate.
 template <class Real, class Enq>
-static int grid_run(mc_context *c, int num_blocks, int num_threads, uint64_t paths_per_block, uint32_t draws, uint32_t row,
-                    uint32_t per_unit, size_t padded, double discount, mc_result *out, Enq enqueue)
+static int grid_run_staged(mc_context *c, int num_blocks, int num_threads, uint64_t paths_per_block, uint32_t draws, uint32_t row,
+                           uint32_t per_unit, size_t padded, double discount, Real *h_values, mc_result *out, Enq enqueue)
 {
     const uint64_t n = (uint64_t)num_blocks * paths_per_block;
     HIPCHK(hipSetDevice(c->device));
     if (int rc = ensure_ext(c, padded * sizeof(Real))) return rc;
-    if (int rc = grid_states_ready(c, num_blocks, num_threads)) return rc;
+    const uint32_t *states = nullptr;
+    if (int rc = grid_states_ready(c, num_blocks, num_threads, &states)) return rc;
     if (padded > n * row)
         HIPCHK(hipMemsetAsync((Real *)c->d_ext + n * row, 0, (padded - n * row) * sizeof(Real), c->stream));
     const uint32_t lanes = (uint32_t)num_blocks * (uint32_t)num_threads;
-    grid_normals_kernel<Real><<<(lanes + 255) / 256, 256, 0, c->stream>>>(c->d_grid_states, (uint32_t)num_blocks, (uint32_t)num_threads,
+    grid_normals_kernel<Real><<<(lanes + 255) / 256, 256, 0, c->stream>>>(states, (uint32_t)num_blocks, (uint32_t)num_threads,
                                                                           paths_per_block, draws, row, (Real *)c->d_ext);
     HIPCHK(hipGetLastError());
     const int rng = c->rng, nf32 = c->normals_f32;
     c->rng = MC_RNG_PHILOX, c->normals_f32 = 0;   // the external policy replaces the generator whatever the context selects
     c->ext = c->d_ext, c->ext_per_unit = per_unit, c->ext_flags = 0;
-    const int rc = run_sync(c, n, discount, out, [&](hipStream_t st, double *t) { return enqueue(st, t); });
+    int rc;
+    if (h_values)
+        rc = dump_sync<Real>(c, n, h_values, [&](hipStream_t st, double *t, Real *d) { return enqueue(st, t, d); });
+    else
+        rc = run_sync(c, n, discount, out, [&](hipStream_t st, double *t) { return enqueue(st, t, (Real *)nullptr); });
     c->ext = nullptr, c->ext_per_unit = 0;
     c->rng = rng, c->normals_f32 = nf32;
     return rc;
+}
+
+// ---- fused form (round 4): the reference's launch itself, every thread's XORWOW stream in registers (mc_grid.hpp) -------
+// launch(tail, work, geo, workgroup size, stream, d_out) starts the product's grid kernel.  One (sum, sum2) pair per
+// reference block, closed by the last arriver like every other call.
+static bool grid_fused_fits(const mc_context *c, int num_blocks)
+{
+    return (uint64_t)num_blocks <= (uint64_t)MAX_SEGMENTS * (uint64_t)c->blocks * MAX_GRID_SCALE;   // the context's pair buffer
+}
+template <class Real, class Launch>
+static int grid_run_fused(mc_context *c, int num_blocks, int num_threads, uint64_t paths_per_block, uint32_t draws, double scale1,
+                          double scale2, double discount, Real *h_values, mc_result *out, Launch launch)
+{
+    const uint64_t n = (uint64_t)num_blocks * paths_per_block;
+    HIPCHK(hipSetDevice(c->device));
+    const auto enqueue = [&](hipStream_t st, double *d_triple, Real *d_out) -> int {
+        if (int rc = begin_call(c, st)) return rc;
+        GridGeom geo;
+        if (int rc = grid_states_ready(c, num_blocks, num_threads, &geo.states)) return rc;
+        geo.num_threads = (uint32_t)num_threads;
+        geo.paths_per_block = (uint32_t)paths_per_block;
+        Work w = make_work(0, Segment{0, 1u}, 0, 0);
+        w.ext_per_unit = draws;
+        const Tail t = make_tail(c, num_blocks, scale1, scale2, n, d_triple);
+        const int group = (num_threads + 63) / 64 * 64;   // whole waves; the lanes beyond num_threads idle
+        if (int rc = launch(t, w, geo, group, st, d_out)) return rc;
+        return finish_call(c, t, num_blocks, st);
+    };
+    if (h_values)
+        return dump_sync<Real>(c, n, h_values, enqueue);
+    return run_sync(c, n, discount, out, [&](hipStream_t st, double *t) { return enqueue(st, t, (Real *)nullptr); });
+}
+
+// which form a call takes: the context's choice, else fused where a fused kernel exists for the shape
+static int grid_pick(mc_context *c, bool fused_possible, bool *fused)
+{
+    if (c->grid_form == MC_GRID_FORM_FUSED && !fused_possible)
+        return fail(MC_ERR_UNSUPPORTED, "launch geometry: no fused kernel for this shape (baskets beyond 16 assets, more blocks than the pair "
+                                        "buffer holds); the staged form covers it");
+    *fused = c->grid_form == MC_GRID_FORM_STAGED ? false : fused_possible;
+    return MC_OK;
 }
 
 // dates of a CVA path that draw a normal: `t -= dt >= 0` in Real arithmetic (dp/MonteCarloKernel.cu:249; the per-date
@@ -2021,9 +2119,10 @@ extern "C" int mc_grid_normals(mc_context *c, int num_blocks, int num_threads, u
         return fail(MC_ERR_INVALID, "mc_grid_normals: need 1 <= threads * count <= 2^28");
     HIPCHK(hipSetDevice(c->device));
     if (int rc = ensure_ext(c, lanes * count * sizeof(float))) return rc;
-    if (int rc = grid_states_ready(c, num_blocks, num_threads)) return rc;
+    const uint32_t *states = nullptr;
+    if (int rc = grid_states_ready(c, num_blocks, num_threads, &states)) return rc;
     // every thread as the only path of its own row: paths_per_block = num_threads, one path per thread, `count` draws
-    grid_normals_kernel<float><<<((uint32_t)lanes + 255) / 256, 256, 0, c->stream>>>(c->d_grid_states, (uint32_t)num_blocks, (uint32_t)num_threads,
+    grid_normals_kernel<float><<<((uint32_t)lanes + 255) / 256, 256, 0, c->stream>>>(states, (uint32_t)num_blocks, (uint32_t)num_threads,
                                                                                     (uint64_t)num_threads, count, count, (float *)c->d_ext);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h_out, c->d_ext, lanes * count * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -2031,38 +2130,129 @@ extern "C" int mc_grid_normals(mc_context *c, int num_blocks, int num_threads, u
     return MC_OK;
 }
 
+// the fused basket kernels are compiled for 4, 8 and 16 assets; a smaller basket runs the next size zero-padded
+template <class Real, int NA>
+static int grid_basket_fused(mc_context *c, const typename BasketIn<Real>::type *o, int nb, int nt, uint64_t ppb, Real *h_values, mc_result *out)
+{
+    BasketArgs<Real, NA> k;
+    double out_scale = 1.0;
+    if (int rc = basket_fold<Real, NA>(c, *o, k, out_scale)) return rc;
+    return grid_run_fused<Real>(c, nb, nt, ppb, (uint32_t)o->n, out_scale, out_scale * out_scale, std::exp(-(double)o->r * (double)o->t), h_values, out,
+                                [&](const Tail &t, const Work &w, const GridGeom &geo, int group, hipStream_t st, Real *d_out) -> int {
+                                    grid_basket_kernel<Real, NA><<<nb, group, 0, st>>>(t, k, w, geo, d_out, (Real)out_scale);
+                                    return MC_OK;
+                                });
+}
+
+template <class Real>
+static int grid_vanilla(mc_context *c, const typename VanillaTraits<Real>::In *o, int nb, int nt, uint64_t ppb, Real *h_values, mc_result *out)
+{
+    uint64_t n;
+    if (int rc = grid_check(c, o, nb, nt, ppb, h_values ? (const void *)h_values : (const void *)out, &n)) return rc;
+    bool fused;
+    if (int rc = grid_pick(c, grid_fused_fits(c, nb), &fused)) return rc;
+    const double disc = std::exp(-(double)o->r * (double)o->t);
+    if (!fused) {
+        const uint64_t NPB = GenPhilox::npb<Real>(), units = (n + NPB - 1) / NPB;
+        /* a vanilla unit is NPB paths: rows of one normal, read NPB at a time */
+        return grid_run_staged<Real>(c, nb, nt, ppb, 1, 1, (uint32_t)NPB, units * NPB, disc, h_values, out,
+                                     [&](hipStream_t st, double *t, Real *d) { return vanilla_enqueue<Real>(c, o, 0, 0, n, t, st, d); });
+    }
+    typename VanillaTraits<Real>::Opt k;
+    double scale1, scale2;
+    if (int rc = VanillaTraits<Real>::prepare(*o, k, scale1, scale2)) return rc;
+    return grid_run_fused<Real>(c, nb, nt, ppb, 1u, scale1, scale2, disc, h_values, out,
+                                [&](const Tail &t, const Work &w, const GridGeom &geo, int group, hipStream_t st, Real *d_out) -> int {
+                                    if constexpr (sizeof(Real) == 4)
+                                        grid_vanilla_f32_kernel<<<nb, group, 0, st>>>(t, k, w, geo, d_out, (float)scale1);
+                                    else
+                                        grid_vanilla_f64_kernel<<<nb, group, 0, st>>>(t, k, w, geo, d_out, 1.0);
+                                    return MC_OK;
+                                });
+}
+
+template <class Real>
+static int grid_basket(mc_context *c, const typename BasketIn<Real>::type *o, int nb, int nt, uint64_t ppb, Real *h_values, mc_result *out)
+{
+    uint64_t n;
+    if (int rc = grid_check(c, o, nb, nt, ppb, h_values ? (const void *)h_values : (const void *)out, &n)) return rc;
+    if (o->n < 1 || o->n > MC_MAX_ASSETS_GENERIC) return fail(MC_ERR_INVALID, "basket: bad n");
+    if (!o->s || !o->v || !o->p || !o->d || !o->w) return fail(MC_ERR_INVALID, "basket: NULL array");
+    if (!(o->t >= 0) || !std::isfinite((double)o->r) || !std::isfinite((double)o->k)) return fail(MC_ERR_INVALID, "basket: need t>=0 and finite r, k");
+    bool fused;
+    if (int rc = grid_pick(c, grid_fused_fits(c, nb) && o->n <= 16, &fused)) return rc;
+    if (!fused)
+        return grid_run_staged<Real>(c, nb, nt, ppb, (uint32_t)o->n, (uint32_t)o->n, (uint32_t)o->n, ((size_t)n + 1) * (size_t)o->n,
+                                     std::exp(-(double)o->r * (double)o->t), h_values, out,
+                                     [&](hipStream_t st, double *t, Real *d) { return basket_enqueue<Real>(c, o, 0, 0, n, t, st, d); });
+    if (o->n <= 4) return grid_basket_fused<Real, 4>(c, o, nb, nt, ppb, h_values, out);
+    if (o->n <= 8) return grid_basket_fused<Real, 8>(c, o, nb, nt, ppb, h_values, out);
+    return grid_basket_fused<Real, 16>(c, o, nb, nt, ppb, h_values, out);
+}
+
+template <class Real>
+static int grid_cva(mc_context *c, const typename CvaIn<Real>::type *o, int nb, int nt, uint64_t ppb, Real *h_values, mc_result *out)
+{
+    uint64_t n;
+    if (int rc = grid_check(c, o, nb, nt, ppb, h_values ? (const void *)h_values : (const void *)out, &n)) return rc;
+    if (o->n_grid < 1 || o->n_grid > (1 << 20) || !(o->option.t > 0))
+        return fail(MC_ERR_INVALID, "cva: bad n_grid or maturity");
+    bool fused;
+    if (int rc = grid_pick(c, grid_fused_fits(c, nb), &fused)) return rc;
+    const uint32_t draws = cva_draws<Real>(o->option.t, o->n_grid);
+    if (!fused)
+        return grid_run_staged<Real>(c, nb, nt, ppb, draws, (uint32_t)o->n_grid, (uint32_t)o->n_grid, (size_t)n * (size_t)o->n_grid, 1.0, h_values, out,
+                                     [&](hipStream_t st, double *t, Real *d) { return cva_enqueue<Real>(c, o, 0, 0, n, t, st, d); });
+    return grid_run_fused<Real>(c, nb, nt, ppb, draws, 1.0, 1.0, 1.0, h_values, out,
+                                [&](const Tail &t, const Work &w, const GridGeom &geo, int group, hipStream_t st, Real *d_out) -> int {
+                                    CvaArgs<Real> args;
+                                    if (int rc = cva_table_ready<Real>(c, o, st, args)) return rc;
+                                    grid_cva_kernel<Real><<<nb, group, 0, st>>>(t, args, w, geo, d_out);
+                                    return MC_OK;
+                                });
+}
+
 #define MC_DEFINE_GRID(X, Real)                                                                                                   \
     extern "C" int mc_vanilla_run_grid_##X(mc_context *c, const mc_option_##X *o, int num_blocks, int num_threads,               \
                                            uint64_t paths_per_block, mc_result *out)                                             \
     {                                                                                                                             \
-        uint64_t n;                                                                                                               \
-        if (int rc = grid_check(c, o, num_blocks, num_threads, paths_per_block, out, &n)) return rc;                              \
-        const uint64_t NPB = GenPhilox::npb<Real>(), units = (n + NPB - 1) / NPB;                                                 \
-        /* a vanilla unit is NPB paths: rows of one normal, read NPB at a time */                                                 \
-        return grid_run<Real>(c, num_blocks, num_threads, paths_per_block, 1, 1, (uint32_t)NPB, units * NPB,                      \
-                              std::exp(-(double)o->r * (double)o->t), out,                                                        \
-                              [&](hipStream_t st, double *t) { return vanilla_enqueue<Real>(c, o, 0, 0, n, t, st, nullptr); });   \
+        if (!out) return fail(MC_ERR_INVALID, "NULL output pointer");                                                             \
+        return grid_vanilla<Real>(c, o, num_blocks, num_threads, paths_per_block, (Real *)nullptr, out);                         \
     }                                                                                                                             \
     extern "C" int mc_basket_run_grid_##X(mc_context *c, const mc_basket_##X *o, int num_blocks, int num_threads,                \
                                           uint64_t paths_per_block, mc_result *out)                                              \
     {                                                                                                                             \
-        uint64_t n;                                                                                                               \
-        if (int rc = grid_check(c, o, num_blocks, num_threads, paths_per_block, out, &n)) return rc;                              \
-        if (o->n < 1 || o->n > MC_MAX_ASSETS_GENERIC) return fail(MC_ERR_INVALID, "basket: bad n");                               \
-        return grid_run<Real>(c, num_blocks, num_threads, paths_per_block, (uint32_t)o->n, (uint32_t)o->n, (uint32_t)o->n,        \
-                              ((size_t)n + 1) * (size_t)o->n, std::exp(-(double)o->r * (double)o->t), out,                        \
-                              [&](hipStream_t st, double *t) { return basket_enqueue<Real>(c, o, 0, 0, n, t, st, nullptr); });    \
+        if (!out) return fail(MC_ERR_INVALID, "NULL output pointer");                                                             \
+        if (!o) return fail(MC_ERR_INVALID, "NULL option");                                                                       \
+        return grid_basket<Real>(c, o, num_blocks, num_threads, paths_per_block, (Real *)nullptr, out);                          \
     }                                                                                                                             \
     extern "C" int mc_cva_run_grid_##X(mc_context *c, const mc_cva_##X *o, int num_blocks, int num_threads,                      \
                                        uint64_t paths_per_block, mc_result *out)                                                 \
     {                                                                                                                             \
-        uint64_t n;                                                                                                               \
-        if (int rc = grid_check(c, o, num_blocks, num_threads, paths_per_block, out, &n)) return rc;                              \
-        if (o->n_grid < 1 || o->n_grid > (1 << 20) || !(o->option.t > 0))                                                         \
-            return fail(MC_ERR_INVALID, "cva: bad n_grid or maturity");                                                           \
-        return grid_run<Real>(c, num_blocks, num_threads, paths_per_block, cva_draws<Real>(o->option.t, o->n_grid),               \
-                              (uint32_t)o->n_grid, (uint32_t)o->n_grid, (size_t)n * (size_t)o->n_grid, 1.0, out,                                       \
-                              [&](hipStream_t st, double *t) { return cva_enqueue<Real>(c, o, 0, 0, n, t, st, nullptr); });       \
+        if (!out) return fail(MC_ERR_INVALID, "NULL output pointer");                                                             \
+        if (!o) return fail(MC_ERR_INVALID, "NULL option");                                                                       \
+        return grid_cva<Real>(c, o, num_blocks, num_threads, paths_per_block, (Real *)nullptr, out);                             \
+    }                                                                                                                             \
+    /* per-path values of a launch-geometry call, in the call's path order (block-major): test hooks, mc_mi355x_test.h */         \
+    extern "C" int mc_vanilla_paths_grid_##X(mc_context *c, const mc_option_##X *o, int num_blocks, int num_threads,             \
+                                             uint64_t paths_per_block, Real *h_out)                                              \
+    {                                                                                                                             \
+        if (!h_out) return fail(MC_ERR_INVALID, "NULL output pointer");                                                           \
+        return grid_vanilla<Real>(c, o, num_blocks, num_threads, paths_per_block, h_out, (mc_result *)nullptr);                  \
+    }                                                                                                                             \
+    extern "C" int mc_basket_paths_grid_##X(mc_context *c, const mc_basket_##X *o, int num_blocks, int num_threads,              \
+                                            uint64_t paths_per_block, Real *h_out)                                               \
+    {                                                                                                                             \
+        if (!h_out) return fail(MC_ERR_INVALID, "NULL output pointer");                                                           \
+        if (!o) return fail(MC_ERR_INVALID, "NULL option");                                                                       \
+        return grid_basket<Real>(c, o, num_blocks, num_threads, paths_per_block, h_out, (mc_result *)nullptr);                   \
+    }                                                                                                                             \
+    extern "C" int mc_cva_paths_grid_##X(mc_context *c, const mc_cva_##X *o, int num_blocks, int num_threads,                    \
+                                         uint64_t paths_per_block, Real *h_out)                                                  \
+    {                                                                                                                             \
+        if (!h_out) return fail(MC_ERR_INVALID, "NULL output pointer");                                                           \
+        if (!o) return fail(MC_ERR_INVALID, "NULL option");                                                                       \
+        return grid_cva<Real>(c, o, num_blocks, num_threads, paths_per_block, h_out, (mc_result *)nullptr);                      \
     }
 
 #define MC_DEFINE_PRODUCT(X, Real)                                                                           \

@@ -1,9 +1,17 @@
 // mc_grid.hpp -- compatibility mode: the reference's launch geometry and per-thread XORWOW normal streams
 // (mc_*_run_grid_*, include/mc_mi355x.h "launch geometry"; host side: mc_api.hip grid_run).
 //
-// Not on the hot path: these kernels only WRITE the normals a (num_blocks x num_threads) launch of the reference draws
-// into HBM, in path order; the simulation kernels of mc_kernels.hpp then price them through the external-normals policy.
+// Two forms of the same sample:
+//   fused (round 4, the default)  grid_*_kernel below: launched with the REFERENCE's geometry, every thread owns its XORWOW
+//           normal stream in registers and walks the reference's own thread-to-path map -- thread t of block b prices paths
+//           t, t + T, ... of its block (dp/MonteCarloKernel.cu:146,191,240) -- through the per-path device functions of the
+//           hot kernels (vanilla_unit_pk, basket_path, cva_path with a stream policy): no normal touches HBM;
+//   staged (round 3, the checker and the fallback for shapes the fused kernels do not cover)  grid_normals_kernel WRITES the
+//           normals of the whole call into HBM in path order, the simulation kernels of mc_kernels.hpp then price them
+//           through the external-normals policy.
+// Per-path values of the two forms are the same bits (tests/test_gpu_grid.py): same normals, same per-path functions.
 #pragma once
+#include "mc_kernels.hpp"
 #include "mc_rng.hpp"
 
 namespace mc {
@@ -36,20 +44,28 @@ struct XorwowNormalStream {
     float kept;
     bool have = false;
     __device__ __forceinline__ explicit XorwowNormalStream(const uint32_t *states) : rng(states) {}
-    __device__ __forceinline__ float next()
+    __device__ __forceinline__ XorwowNormalStream(const uint32_t *row, GenXorwow::Row tag) : rng(row, tag) {}
+    // the next Box-Muller pair: first = the member curand_normal returns first (sine), second = the one it keeps (cosine)
+    __device__ __forceinline__ void pair(float &first, float &second)
     {
-        if (have) {
-            have = false;
-            return kept;
-        }
         const uint32_t x = rng.next(), y = rng.next();
         const float u = 2.3283064e-10f + (x * 2.3283064e-10f);
         const float v = 1.46291807e-09f + (y * 1.46291807e-09f);
         const float s = sqrtf(-2.0f * logf(u));
         float sn, cs;
         __sincosf(v, &sn, &cs);
-        kept = cs * s, have = true;
-        return sn * s;
+        first = sn * s, second = cs * s;
+    }
+    __device__ __forceinline__ float next()
+    {
+        if (have) {
+            have = false;
+            return kept;
+        }
+        float first;
+        pair(first, kept);
+        have = true;
+        return first;
     }
 };
 
@@ -74,6 +90,177 @@ __global__ __launch_bounds__(256) void grid_normals_kernel(const uint32_t *__res
         for (uint32_t j = draws; j < per_unit; ++j)
             row[j] = (Real)0;
     }
+}
+
+// ---- fused form: the reference's launch, thread for thread --------------------------------------------------------------
+// Generator policy of the fused kernels: the normals of a "block" are the thread's next draws, widened to Real as
+// `double z = curand_normal(...)` does.  WHOLE = every draw of every block is used and blocks are pair-aligned (vanilla: 4 or
+// 8 paths per trip, one draw each): whole Box-Muller pairs, no bookkeeping.  Otherwise draw `idx < w.ext_per_unit` of a unit
+// is drawn and the rest of the block is zero WITHOUT drawing (a basket path draws n, a CVA path one per date that draws) --
+// exactly the rows the staged form writes.  The counter arguments are ignored: the stream is sequential.
+template <bool WHOLE>
+struct GenGridStream {
+    static constexpr bool external = true;   // values, not words: the kernels take their fma(z, b, a) paths
+    template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }
+    XorwowNormalStream z;
+    __device__ __forceinline__ explicit GenGridStream(const uint32_t *row) : z(row, GenXorwow::Row{}) {}
+    template <class Real, int N>
+    __device__ __forceinline__ void normals(const Work &w, uint32_t, uint32_t block, uint32_t, Real (&out)[N])
+    {
+        if constexpr (WHOLE) {
+            static_assert(N % 2 == 0, "whole pairs");
+#pragma unroll
+            for (int j = 0; j < N; j += 2) {
+                float a, b;
+                z.pair(a, b);
+                out[j] = (Real)a, out[j + 1] = (Real)b;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                out[j] = block * (uint32_t)N + (uint32_t)j < w.ext_per_unit ? (Real)z.next() : (Real)0;
+        }
+    }
+    struct Carry {};
+    __device__ __forceinline__ void pair(const Work &w, uint32_t, uint32_t, uint32_t P, Carry &, double &z0, double &z1)
+    {
+        z0 = 2u * P < w.ext_per_unit ? (double)z.next() : 0.0;
+        z1 = 2u * P + 1u < w.ext_per_unit ? (double)z.next() : 0.0;
+    }
+    __device__ __forceinline__ void pairs_done(uint32_t) {}
+};
+
+// The reference's launch: num_blocks blocks of num_threads threads, paths_per_block paths per block; `states` = one start
+// state per (block, thread) (xorwow_grid_init_kernel).  The fused kernels are launched with num_blocks workgroups of
+// num_threads rounded up to whole waves (the extra lanes idle): blockIdx.x = the reference's block, threadIdx.x its thread.
+struct GridGeom {
+    const uint32_t *states;
+    uint32_t num_threads;
+    uint32_t paths_per_block;
+};
+constexpr int GRID_MAX_THREADS = 1024;   // the reference's blockDim limit
+
+// paths of this thread: t, t + T, ... < paths_per_block
+__device__ __forceinline__ uint32_t grid_thread_paths(const GridGeom &geo)
+{
+    return threadIdx.x < geo.paths_per_block ? (geo.paths_per_block - threadIdx.x + geo.num_threads - 1) / geo.num_threads : 0u;
+}
+// index (in the call's path order, block-major) of this thread's k-th path: what `out` is indexed by
+__device__ __forceinline__ uint64_t grid_path_index(const GridGeom &geo, uint32_t k)
+{
+    return (uint64_t)blockIdx.x * geo.paths_per_block + threadIdx.x + (uint64_t)k * geo.num_threads;
+}
+
+// Vanilla: one draw per path, so a trip of NPB draws = NPB consecutive paths of the thread = NPB / 2 whole Box-Muller pairs.
+// vanilla_unit_pk / vanilla_unit are the hot kernels' per-unit functions (mc_kernels.hpp) on their external-normals path.
+__global__ __launch_bounds__(GRID_MAX_THREADS) void grid_vanilla_f32_kernel(const Tail /* first argument, read late */, const VanillaF32 o, const Work w,
+                                                                            const GridGeom geo, float *__restrict__ out, float out_scale)
+{
+    double acc_s = 0.0, acc_q = 0.0;
+    if (threadIdx.x < geo.num_threads) {
+        const uint32_t n_t = grid_thread_paths(geo);
+        GenGridStream<true> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
+        for (uint32_t k = 0; k < n_t; k += 4) {
+            float p[4];
+            vanilla_unit<false>(gen, o, w, 0u, p);
+            float s = 0.0f, q = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k + j >= n_t)
+                    p[j] = 0.0f;
+                else if (out)
+                    out[grid_path_index(geo, k + j)] = p[j] * out_scale;
+                s += p[j];
+                q = __builtin_fmaf(p[j], p[j], q);
+            }
+            acc_s += (double)s;
+            acc_q += (double)q;
+        }
+    }
+    group_sum2(acc_s, acc_q);
+    finish_group(acc_s, acc_q);
+}
+__global__ __launch_bounds__(GRID_MAX_THREADS) void grid_vanilla_f64_kernel(const Tail /* first argument, read late */, const VanillaF64 o, const Work w,
+                                                                            const GridGeom geo, double *__restrict__ out, double out_scale)
+{
+    stage_tables<double>();
+    double acc_s = 0.0, acc_q = 0.0;
+    if (threadIdx.x < geo.num_threads) {
+        const uint32_t n_t = grid_thread_paths(geo);
+        GenGridStream<true> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
+        for (uint32_t k = 0; k < n_t; k += 8) {
+            double p[8];
+            vanilla_unit<false>(gen, o, w, 0u, p);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (k + j >= n_t)
+                    p[j] = 0.0;
+                else if (out)
+                    out[grid_path_index(geo, k + j)] = p[j] * out_scale;
+                acc_s += p[j];
+                acc_q = __builtin_fma(p[j], p[j], acc_q);
+            }
+        }
+    }
+    group_sum2(acc_s, acc_q);
+    finish_group(acc_s, acc_q);
+}
+
+// Basket: a path draws its n normals one after the other (an odd n makes a Box-Muller pair straddle two paths, as in the
+// reference).  basket_path is the kernel-argument family's per-path function; NA is the compiled size, a smaller basket
+// runs it zero-padded (rows beyond n: zero factor, base and weight -- they add exactly 0; w.ext_per_unit = n draws).
+template <class Real, int NA>
+__global__ __launch_bounds__(GRID_MAX_THREADS) void grid_basket_kernel(const Tail /* first argument, read late */, const BasketArgs<Real, NA> o, const Work w,
+                                                                       const GridGeom geo, Real *__restrict__ out, Real out_scale)
+{
+    stage_tables<Real>();
+    // constants from LDS where the hot kernels stage them -- except fp64 at 8 assets, where hipcc keeps the staged values in
+    // more registers than a 1024-thread workgroup may have (128: it spilled 332 bytes of scratch per lane)
+    constexpr bool IN_LDS = basket_consts_in_lds<Real, NA>() && !(sizeof(Real) == 8 && NA == 8);
+    __shared__ Real lds_consts[IN_LDS ? ConstsLds<Real, NA>::COUNT : 1];
+    if (IN_LDS)
+        ConstsLds<Real, NA>::stage(lds_consts, o);
+    double acc_s = 0.0, acc_q = 0.0;
+    if (threadIdx.x < geo.num_threads) {
+        const uint32_t n_t = grid_thread_paths(geo);
+        GenGridStream<false> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
+        for (uint32_t k = 0; k < n_t; ++k) {
+            Real p;
+            if constexpr (IN_LDS)
+                p = basket_path<Real, NA, false>(gen, o, ConstsLds<Real, NA>{lds_consts}, w, 0u);
+            else
+                p = basket_path<Real, NA, false>(gen, o, ConstsArg<Real, NA>{o}, w, 0u);
+            acc_s += (double)p;
+            acc_q = __builtin_fma((double)p, (double)p, acc_q);
+            if (out)
+                out[grid_path_index(geo, k)] = p * out_scale;
+        }
+    }
+    group_sum2(acc_s, acc_q);
+    finish_group(acc_s, acc_q);
+}
+
+// CVA: cva_path is the hot kernel's per-path function; a path draws for the dates whose `t -= dt` is still >= 0
+// (w.ext_per_unit of them, dp/MonteCarloKernel.cu:249), the remaining dates of its blocks read 0 without drawing.
+template <class Real>
+__global__ __launch_bounds__(GRID_MAX_THREADS) void grid_cva_kernel(const Tail /* first argument, read late */, const CvaArgs<Real> o, const Work w,
+                                                                    const GridGeom geo, Real *__restrict__ out)
+{
+    stage_tables<Real>();
+    double acc_s = 0.0, acc_q = 0.0;
+    if (threadIdx.x < geo.num_threads) {
+        const uint32_t n_t = grid_thread_paths(geo);
+        GenGridStream<false> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
+        for (uint32_t k = 0; k < n_t; ++k) {
+            const Real p = cva_path<false>(gen, o, w, 0u);
+            acc_s += (double)p;
+            acc_q = __builtin_fma((double)p, (double)p, acc_q);
+            if (out)
+                out[grid_path_index(geo, k)] = p;
+        }
+    }
+    group_sum2(acc_s, acc_q);
+    finish_group(acc_s, acc_q);
 }
 
 }  // namespace mc

@@ -260,6 +260,8 @@ struct GenXorwow {
         x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], d = p[5];
     }
     __device__ __forceinline__ explicit GenXorwow(const Work &w) : GenXorwow(w.xorwow) {}
+    struct Row {};   // tag: `p` already points at this lane's own six words (the launch-geometry kernels index by (block, thread))
+    __device__ __forceinline__ GenXorwow(const uint32_t *p, Row) { x0 = p[0], x1 = p[1], x2 = p[2], x3 = p[3], x4 = p[4], d = p[5]; }
     __device__ __forceinline__ uint32_t next()
     {
         const uint32_t t = x0 ^ (x0 >> 2);

@@ -319,6 +319,19 @@ class Engine:
                                                                 C.byref(r)))
         return _estimate(r)
 
+    def set_grid_form(self, form: str):
+        """Launch-geometry mode: 'auto' (fused kernels where they exist), 'staged' (normals through HBM: the checker) or
+        'fused' (test hook, mc_mi355x_test.h)."""
+        check(lib().mc_context_set_grid_form(self._ctx, _lib.GRID_FORM[form]))
+
+    def paths_grid(self, prod, inputs, num_blocks, num_threads, paths_per_block, precision="f64"):
+        """Per-path values of a launch-geometry call in the call's path order, (num_blocks, paths_per_block) (test hook)."""
+        struct, keep = self.prepared(prod, precision, inputs)
+        out = np.empty((num_blocks, paths_per_block), dtype=NP[precision])
+        check(getattr(lib(), f"mc_{prod}_paths_grid_{precision}")(self._ctx, C.byref(struct), num_blocks, num_threads, paths_per_block,
+                                                                  out.ctypes.data_as(C.POINTER(_lib.CT[precision]))))
+        return out
+
     def grid_normals(self, num_blocks, num_threads, count):
         """The first `count` normals of every thread's stream: (num_blocks, num_threads, count) float32."""
         out = np.empty((num_blocks, num_threads, count), dtype=np.float32)

@@ -22,14 +22,37 @@ def mc():
     return mc
 
 
+def _declared(header):
+    text = open(os.path.join(INC, header)).read()
+    return set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", text)) - {"mc_context"}
+
+
 def test_library_exports_every_declared_symbol(mc):
+    """The product header declares the drop-in surface, the test header the hooks; the .so exports every one of them."""
     L = mc._lib.lib()
-    header = open(os.path.join(INC, "mc_mi355x.h")).read()
-    declared = set(re.findall(r"\b(mc_[a-z0-9_]+)\s*\(", header))
-    declared -= {"mc_context"}
-    assert declared == set(mc._lib.EXPORTS), declared ^ set(mc._lib.EXPORTS)
-    for name in sorted(declared):
+    product, hooks = _declared("mc_mi355x.h"), _declared("mc_mi355x_test.h")
+    assert product == set(mc._lib.EXPORTS), product ^ set(mc._lib.EXPORTS)
+    assert hooks == set(mc._lib.TEST_EXPORTS), hooks ^ set(mc._lib.TEST_EXPORTS)
+    for name in sorted(product | hooks):
         assert hasattr(L, name), name
+
+
+def test_every_exported_symbol_is_declared_in_exactly_one_header(mc):
+    """nm on the shipping library: each exported mc_* function is declared by the product header or by the test-hook header,
+    never by both, never by neither -- and the product header advertises no test hook (the switches that
+    reproduce the reference's CPU-path bugs are not part of the public surface)."""
+    out = subprocess.check_output(["nm", "-D", "--defined-only", mc._lib.LIB_PATH], text=True)
+    exported = {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("mc_")}
+    exported -= {"mc_internal_fail"}      # the error text shared with the CPU twin's object (mc_hostmath.c), not an entry point
+    product, hooks = _declared("mc_mi355x.h"), _declared("mc_mi355x_test.h")
+    assert not (product & hooks), product & hooks
+    assert exported == product | hooks, exported ^ (product | hooks)
+    text = open(os.path.join(INC, "mc_mi355x.h")).read()
+    for word in ("from_normals", "MC_FROM_NORMALS", "mc_grid_normals", "mc_normals_f", "NO_VOL", "HOST_ORDER"):
+        assert word not in text, word
+    integration = open(os.path.join(ROOT, "INTEGRATION.md")).read()      # lists the product header only
+    for word in ("from_normals", "mc_mi355x_test.h", "mc_grid_normals", "NO_VOL"):
+        assert word not in integration, word
 
 
 @pytest.mark.parametrize("X", ["f64", "f32"])
@@ -114,7 +137,7 @@ def test_multi_library_exports_every_declared_symbol(mc):
     L = C.CDLL(MULTI_LIB)
     header = open(os.path.join(INC, "mc_multi.h")).read()
     declared = set(re.findall(r"\b(mc_multi_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 18, sorted(declared)
+    assert len(declared) == 20, sorted(declared)      # round 4: + mc_multi_launcher_threads, mc_multi_last_fanout_us
     for name in sorted(declared):
         assert hasattr(L, name), name
     needed = subprocess.check_output(["readelf", "-d", MULTI_LIB], text=True)

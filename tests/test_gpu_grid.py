@@ -15,6 +15,11 @@ HIP build of the reference calls through hipRAND -- is, as headers, so THAT is t
       and everything downstream is the hot kernels' code, parity-tested in test_gpu_from_normals.py / test_gpu_parity.py;
   (4) per path against the oracle's device formulas on those normals, at the bounds of test_gpu_parity.py;
   (5) prices against closed forms within the confidence interval.
+Round 4: the call is FUSED -- the reference's launch itself, every thread's stream in registers (mc_grid.hpp: grid_*_kernel);
+(3) is asserted on round 3's STAGED form (normals through HBM: the checker, mc_context_set_grid_form), and
+  (6) the fused form's per-path values are the staged form's BIT FOR BIT (mc_*_paths_grid_*), its (sum, sum2) agree within
+      the order of the additions (3e-6 fp32 / 1e-12 fp64), for every product, both precisions, every basket size that has a
+      fused kernel, geometries with T not dividing N_PATH, N_PATH < T, partial waves (T = 1, 7, 100) and 1024-thread blocks.
 Equality with an NVIDIA run of the reference is not claimed: cuRAND seeds XORWOW with other constants ("parity unpinned").
 """
 import math
@@ -57,6 +62,37 @@ def basket_inputs(mc, n, X, rho=0.5):
     return dict(s=[100.0] * n, v=v, p=L.tolist(), d=[0.0] * n, w=[1.0 / n] * n, k=100.0, t=1.0, r=0.048790164)
 
 
+def both_forms(eng, prod, inputs, G, T, per_block, X, fused_exists=True):
+    """(staged estimate, fused estimate): the two forms of one launch-geometry call, per-path values compared bit for bit."""
+    try:
+        eng.set_grid_form("staged")
+        st = eng.run_grid(prod, inputs, G, T, per_block, X)
+        st_vals = eng.paths_grid(prod, inputs, G, T, per_block, X)
+        eng.set_grid_form("fused")
+        if not fused_exists:
+            import montecarlocuda_amd as mc
+            with pytest.raises(mc.McError, match="no fused kernel"):
+                eng.run_grid(prod, inputs, G, T, per_block, X)
+            eng.set_grid_form("auto")      # falls back to the staged form: same bits as the staged call
+            au = eng.run_grid(prod, inputs, G, T, per_block, X)
+            assert (au.sum, au.sum2, au.n) == (st.sum, st.sum2, st.n)
+            return st, au
+        fu = eng.run_grid(prod, inputs, G, T, per_block, X)
+        fu_vals = eng.paths_grid(prod, inputs, G, T, per_block, X)
+    finally:
+        eng.set_grid_form("auto")
+    U = np.uint32 if X == "f32" else np.uint64
+    assert np.array_equal(st_vals.view(U), fu_vals.view(U)), (prod, X, G, T, per_block, int((st_vals.view(U) != fu_vals.view(U)).sum()))
+    assert fu.n == st.n == G * per_block
+    assert fu.sum == pytest.approx(st.sum, rel=SUMS[X], abs=1e-300) and fu.sum2 == pytest.approx(st.sum2, rel=SUMS[X], abs=1e-300)
+    # the fused call's own sums are the sums of its per-path values
+    v = fu_vals.astype(np.float64)
+    assert fu.sum == pytest.approx(v.sum(), rel=SUMS[X], abs=1e-300) and fu.sum2 == pytest.approx((v * v).sum(), rel=SUMS[X], abs=1e-300)
+    au = eng.run_grid(prod, inputs, G, T, per_block, X)      # the default form is the fused one
+    assert (au.sum, au.sum2) == (fu.sum, fu.sum2)
+    return st, fu
+
+
 def cva_draws(t, n_grid, X):
     """dates whose `t -= dt` is still >= 0 in the build's arithmetic (dp/MonteCarloKernel.cu:249)"""
     R = NP[X]
@@ -96,7 +132,7 @@ def test_streams_match_oracle(eng, po, G, T, count):
     assert len({r.tobytes() for r in flat}) == G * T
 
 
-GEOMS = [(1, 1, 1), (1, 64, 64), (3, 64, 200), (4, 100, 37), (2, 256, 1000), (5, 7, 1001)]
+GEOMS = [(1, 1, 1), (1, 64, 64), (3, 64, 200), (4, 100, 37), (2, 256, 1000), (5, 7, 1001), (2, 1024, 5000), (3, 128, 7)]
 
 
 @pytest.mark.parametrize("X", ["f32", "f64"])
@@ -104,30 +140,30 @@ GEOMS = [(1, 1, 1), (1, 64, 64), (3, 64, 200), (4, 100, 37), (2, 256, 1000), (5,
 def test_vanilla_grid_is_the_hot_kernel_on_the_reference_arrangement(mc, eng, po, X, G, T, per_block):
     streams = eng.grid_normals(G, T, po.grid_draws_per_thread(T, per_block, 1))
     z = po.grid_path_normals(streams, per_block, 1).reshape(-1).astype(NP[X])       # dp: the float normal widened
-    e = eng.run_grid("vanilla", VAN, G, T, per_block, X)
+    e, fused = both_forms(eng, "vanilla", VAN, G, T, per_block, X)
     h, vals = eng.vanilla_from_normals(VAN, z, X)
     assert e.n == G * per_block == h.n
     assert (e.sum, e.sum2) == (h.sum, h.sum2)
     want, o = po.dev_vanilla_on_normals(X, VAN, z)
     assert np.abs(vals.astype(np.float64) - want).max() <= PAY[X] * VAN["s"]
-    assert e.sum == pytest.approx(o["sum"], rel=SUMS[X], abs=1e-9)
+    assert e.sum == pytest.approx(o["sum"], rel=SUMS[X], abs=1e-9) and fused.sum == pytest.approx(o["sum"], rel=SUMS[X], abs=1e-9)
 
 
 @pytest.mark.parametrize("X", ["f32", "f64"])
-@pytest.mark.parametrize("n_assets", [1, 3, 4, 7, 16, 33])
+@pytest.mark.parametrize("n_assets", [1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17, 33])
 def test_basket_grid_carries_the_kept_normal_across_paths(mc, eng, po, X, n_assets):
     """Odd asset counts: a path's last Box-Muller pair is split with the next path of the same thread."""
     b = basket_inputs(mc, n_assets, X)
     for G, T, per_block in ((3, 64, 200), (2, 10, 33), (1, 256, 100)):
         streams = eng.grid_normals(G, T, po.grid_draws_per_thread(T, per_block, n_assets))
         g = po.grid_path_normals(streams, per_block, n_assets).astype(NP[X])
-        e = eng.run_grid("basket", b, G, T, per_block, X)
+        e, fused = both_forms(eng, "basket", b, G, T, per_block, X, fused_exists=n_assets <= 16)
         h, vals = eng.basket_from_normals(b, g, X)
         assert e.n == G * per_block
         assert (e.sum, e.sum2) == (h.sum, h.sum2), (G, T, per_block)
         want, o = po.dev_basket_on_normals(X, b, g, 0)
         assert np.abs(vals.astype(np.float64) - want).max() <= PAY[X] * 100.0 * 4
-        assert e.sum == pytest.approx(o["sum"], rel=SUMS[X])
+        assert e.sum == pytest.approx(o["sum"], rel=SUMS[X]) and fused.sum == pytest.approx(o["sum"], rel=SUMS[X])
 
 
 @pytest.mark.parametrize("X", ["f32", "f64"])
@@ -144,7 +180,7 @@ def test_cva_grid_draws_only_for_the_dates_that_draw(mc, eng, po, X, n_grid):
     streams = eng.grid_normals(G, T, po.grid_draws_per_thread(T, per_block, draws))
     z = np.zeros((G * per_block, n_grid), dtype=NP[X])
     z[:, :draws] = po.grid_path_normals(streams, per_block, draws)
-    e = eng.run_grid("cva", c, G, T, per_block, X)
+    e, fused = both_forms(eng, "cva", c, G, T, per_block, X)
     h, vals = eng.cva_from_normals(c, z, X)
     assert (e.sum, e.sum2, e.n) == (h.sum, h.sum2, G * per_block)
     want, o = po.dev_cva_on_normals(X, c, z.astype(np.float64), 0)
@@ -178,6 +214,22 @@ def test_grid_prices_agree_with_closed_forms(mc, eng, po):
     p1 = eng.vanilla(VAN, 4096, precision="f64").sum
     assert x1 != p1
     assert eng.run_grid("vanilla", VAN, 16, 64, 1000, "f64").sum == a.sum
+
+
+def test_fused_form_speed_shape_and_state_cache(mc, eng):
+    """The reference drivers' shape (512 blocks of 128 threads, vanillaOpt.cu:13-15) at 1e8 paths: the fused call no longer
+    moves 0.4 GB of normals through HBM (0.40 ms in round 3); a geometry's start states are set up once and kept for the last
+    four geometries (a second call of a cached geometry is not slower than the first by a set-up)."""
+    per_block = 10 ** 8 // 512
+    eng.run_grid("vanilla", VAN, 512, 128, per_block, "f32")            # first use: state set-up
+    best = min(eng.run_grid("vanilla", VAN, 512, 128, per_block, "f32").kernel_ms for _ in range(5))
+    assert best < 0.30, best                                               # measured ~0.1 ms; the bound is loose on purpose
+    geoms = [(64, 64), (32, 128), (16, 256), (8, 512), (4, 1024)]          # five geometries through a cache of four
+    first = {g: eng.run_grid("vanilla", VAN, g[0], g[1], 1000, "f64").sum for g in geoms}
+    for g in geoms + geoms[::-1]:
+        assert eng.run_grid("vanilla", VAN, g[0], g[1], 1000, "f64").sum == first[g]
+    e = eng.run_grid("vanilla", VAN, 512, 128, per_block, "f32")
+    assert abs(e.expected - BS_EXACT) < 3.5 / 1.96 * e.confidence and e.n == 512 * per_block
 
 
 def test_grid_argument_errors(mc, eng):

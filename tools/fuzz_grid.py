@@ -80,7 +80,22 @@ for it in range(cases):
     streams = eng.grid_normals(G, T, po.grid_draws_per_thread(T, per_block, draws))
     z = np.zeros((G * per_block, row), dtype=NP[X])
     z[:, :draws] = po.grid_path_normals(streams, per_block, draws)
+    # staged form (round 3: normals through HBM) = the checker: bitwise against the from-normals hook below; fused form
+    # (round 4: the reference's launch itself) = per-path values bit-equal to the staged form's, sums within the order of additions
+    eng.set_grid_form("staged")
     e = eng.run_grid(prod, inp, G, T, per_block, X)
+    sv = eng.paths_grid(prod, inp, G, T, per_block, X)
+    eng.set_grid_form("auto")
+    f = eng.run_grid(prod, inp, G, T, per_block, X)
+    fv = eng.paths_grid(prod, inp, G, T, per_block, X)
+    U = np.uint32 if X == "f32" else np.uint64
+    if not np.array_equal(sv.view(U), fv.view(U)):
+        bad += 1
+        print("VIOLATION fused per-path values differ from the staged form's", what, int((sv.view(U) != fv.view(U)).sum()))
+    rel = 3e-6 if X == "f32" else 1e-12
+    if f.n != e.n or abs(f.sum - e.sum) > rel * abs(e.sum) or abs(f.sum2 - e.sum2) > rel * abs(e.sum2):
+        bad += 1
+        print("VIOLATION fused sums differ from the staged form's", what, (f.sum, f.sum2, f.n), (e.sum, e.sum2, e.n))
     if prod == "vanilla":
         h, vals = eng.vanilla_from_normals(inp, z.reshape(-1), X)
         want, _ = po.dev_vanilla_on_normals(X, inp, z.reshape(-1))

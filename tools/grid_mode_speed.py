@@ -1,6 +1,7 @@
 """What the launch-geometry compatibility mode (mc_*_run_grid_*) costs next to the engine's own streams, at the
 reference drivers' shape: 512 blocks x 128 threads (vanillaOpt.cu:13-15, basketOpt.cu:13-15), 1024 x 128 for the CVA
-(cvaOpt.cu:12-15), SIMS = k x 131072.  Wall time of the synchronous call, best of 5, first call (state set-up) apart.
+(cvaOpt.cu:12-15), SIMS = k x 131072.  Wall time of the synchronous call, best of 5, first call (state set-up) apart;
+fused = round 4's form (the reference's launch itself, streams in registers), staged = round 3's (normals through HBM).
     python tools/grid_mode_speed.py > gpurun_out/grid_mode_speed.log"""
 import os
 import sys
@@ -33,7 +34,10 @@ def best(f, reps=5):
 def main():
     eng = mc.Engine(0)
     eng.set_timing(False)
-    print(f"{'call':34s} {'paths':>11s} {'grid first ms':>14s} {'grid ms':>9s} {'engine ms':>10s}   price grid / engine (+- CI)")
+    t0 = time.perf_counter()
+    eng.run_grid("vanilla", VAN, 2, 64, 10, "f32")
+    print(f"first launch-geometry call of the process (jump matrices on the host + upload + set-up kernel): {(time.perf_counter() - t0) * 1e3:.1f} ms")
+    print(f"{'call':34s} {'paths':>11s} {'fused first ms':>14s} {'fused ms':>9s} {'staged ms':>10s} {'engine ms':>10s}   price fused / engine (+- CI)")
     rows = [("vanilla", VAN, 512, 128, 763), ("vanilla", VAN, 512, 128, 8), ("basket", None, 512, 128, 8), ("basket16", None, 512, 128, 8),
             ("cva", CVA, 1024, 128, 1)]
     for X in ("f32", "f64"):
@@ -51,8 +55,11 @@ def main():
             eng.run_grid(prod, inp_, G, T, per_block, X)
             first = (time.perf_counter() - t0) * 1e3
             tg, eg = best(lambda: eng.run_grid(prod, inp_, G, T, per_block, X))
+            eng.set_grid_form("staged")
+            ts, _ = best(lambda: eng.run_grid(prod, inp_, G, T, per_block, X))
+            eng.set_grid_form("auto")
             te, ee = best(lambda: getattr(eng, prod)(inp_, n, precision=X))
-            print(f"{name + ' ' + X + f' ({G}x{T})':34s} {n:11d} {first:14.3f} {tg:9.3f} {te:10.3f}   "
+            print(f"{name + ' ' + X + f' ({G}x{T})':34s} {n:11d} {first:14.3f} {tg:9.3f} {ts:10.3f} {te:10.3f}   "
                   f"{eg.expected:.6f} / {ee.expected:.6f} (+- {eg.confidence:.2g})")
     eng.close()
 
