@@ -84,11 +84,11 @@ struct mc_context {
     int rng = MC_RNG_PHILOX;
     uint64_t xorwow_base = 0;            // lane l of a launch runs subsequence xorwow_base + l
     uint32_t *d_xorwow = nullptr;        // start states of lanes [0, blocks * GROUP): 6 words each
-    uint32_t *d_xorwow_jump = nullptr;   // jump matrices A^(2^67 2^i), i < XORWOW_JUMP_BITS
+    uint32_t *d_xorwow_jump = nullptr;   // jump matrices A^(2^67 2^i), i < XORWOW_JUMP_BITS, then A^(2^i), i < XORWOW_OFFSET_BITS
     bool xorwow_valid = false;           // d_xorwow holds the states of (xorwow_seed, xorwow_state_base)
     uint64_t xorwow_seed = 0, xorwow_state_base = 0;
     // launch-geometry mode: one start state per (block, thread), cached for the last GRID_CACHE geometries used
-    struct GridStates { int blocks, threads; uint32_t *d; uint64_t last_used; };
+    struct GridStates { int blocks, threads; uint32_t sub, step; uint32_t *d; uint64_t last_used; };   // sub pieces per thread, step words apart
     std::vector<GridStates> grid_cache;
     uint64_t grid_clock = 0;
     int grid_form = MC_GRID_FORM_AUTO;   // fused kernels where they exist, otherwise staged through HBM (MC_GRID_FORM, mc_context_set_grid_form)
@@ -672,13 +672,20 @@ const std::vector<uint32_t> &xorwow_jump_table()
             e.w[c >> 5] = 1u << (c & 31);
             a.col[c] = xw_step(e);
         }
-        for (int i = 0; i < 67; ++i)
-            xw_square(a);
-        std::vector<uint32_t> t((size_t)XORWOW_JUMP_BITS * 160 * 5);
-        for (int i = 0; i < XORWOW_JUMP_BITS; ++i) {
+        std::vector<uint32_t> t((size_t)XORWOW_JUMP_MATRICES * 160 * 5);
+        const auto store = [&](int slot) {
             for (int c = 0; c < 160; ++c)
                 for (int k = 0; k < 5; ++k)
-                    t[((size_t)i * 160 + c) * 5 + k] = a.col[c].w[k];
+                    t[((size_t)slot * 160 + c) * 5 + k] = a.col[c].w[k];
+        };
+        // on the way from A to A^(2^67): the offset matrices A^(2^i), i < 32 (slots behind the subsequence matrices)
+        for (int i = 0; i < 67; ++i) {
+            if (i < XORWOW_OFFSET_BITS)
+                store(XORWOW_JUMP_BITS + i);
+            xw_square(a);
+        }
+        for (int i = 0; i < XORWOW_JUMP_BITS; ++i) {
+            store(i);
             xw_square(a);
         }
         return t;
@@ -1983,11 +1990,11 @@ static int grid_check(mc_context *c, const void *opt, int num_blocks, int num_th
 // process, ~20 ms on the host).  All launch-geometry work runs on the context's own stream, so a cached array is never read
 // by a kernel that started before it was filled.
 static constexpr size_t GRID_CACHE = 4;
-static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, const uint32_t **states)
+static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, uint32_t sub, uint32_t step, const uint32_t **states)
 {
-    const uint32_t lanes = (uint32_t)num_blocks * (uint32_t)num_threads;
+    const uint32_t lanes = (uint32_t)num_blocks * (uint32_t)num_threads * sub;
     for (mc_context::GridStates &g : c->grid_cache)
-        if (g.blocks == num_blocks && g.threads == num_threads) {
+        if (g.blocks == num_blocks && g.threads == num_threads && g.sub == sub && g.step == step) {
             g.last_used = ++c->grid_clock;
             *states = g.d;
             return MC_OK;
@@ -2004,14 +2011,34 @@ static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, con
     }
     uint32_t *d = nullptr;
     HIPCHK(hipMalloc(&d, sizeof(uint32_t) * 6 * (size_t)lanes));
-    xorwow_grid_init_kernel<<<(lanes + 255) / 256, 256, 0, c->stream>>>(c->d_xorwow_jump, (uint32_t)num_blocks, (uint32_t)num_threads, d);
+    xorwow_grid_init_kernel<<<(lanes + 255) / 256, 256, 0, c->stream>>>(c->d_xorwow_jump, (uint32_t)num_blocks, (uint32_t)num_threads, sub, step, d);
     if (hipGetLastError() != hipSuccess) {
         (void)hipFree(d);
         return fail(MC_ERR_HIP, "launch geometry: the state set-up kernel failed to launch");
     }
-    c->grid_cache.push_back({num_blocks, num_threads, d, ++c->grid_clock});
+    c->grid_cache.push_back({num_blocks, num_threads, sub, step, d, ++c->grid_clock});
     *states = d;
     return MC_OK;
+}
+
+// How many pieces the fused kernels cut every reference thread's stream into (mc_grid.hpp "sub-streams"): enough to put
+// ~8 waves on every SIMD (the reference's 512 x 128 launch alone is ONE), as long as a piece keeps >= 16 paths; a power
+// of two up to 32.  MC_GRID_SUB forces a count (1 = the reference's own layout).
+static void grid_pieces(int num_blocks, int num_threads, uint64_t paths_per_block, uint32_t *sub, uint32_t *seg)
+{
+    static const int forced = env_int("MC_GRID_SUB", 0, 0, 32);
+    const uint64_t n_max = (paths_per_block + (uint64_t)num_threads - 1) / (uint64_t)num_threads;   // thread 0's paths
+    const uint64_t lanes = (uint64_t)num_blocks * (uint64_t)((num_threads + 63) / 64 * 64), want = 8ull * 1024 * 64;
+    uint32_t s = 1;
+    if (forced > 0) {
+        while (s * 2 <= (uint32_t)forced) s *= 2;
+    } else {
+        while (s < 32 && lanes * s * 2 <= want && n_max >= 16ull * s * 2)
+            s *= 2;
+    }
+    const uint64_t per = (n_max + s - 1) / s;
+    *sub = s;
+    *seg = (uint32_t)((per + GRID_SEG_ALIGN - 1) / GRID_SEG_ALIGN * GRID_SEG_ALIGN);
 }
 
 extern "C" int mc_context_set_grid_form(mc_context *c, int form)
@@ -2033,7 +2060,7 @@ static int grid_run_staged(mc_context *c, int num_blocks, int num_threads, uint6
     HIPCHK(hipSetDevice(c->device));
     if (int rc = ensure_ext(c, padded * sizeof(Real))) return rc;
     const uint32_t *states = nullptr;
-    if (int rc = grid_states_ready(c, num_blocks, num_threads, &states)) return rc;
+    if (int rc = grid_states_ready(c, num_blocks, num_threads, 1, 0, &states)) return rc;
     if (padded > n * row)
         HIPCHK(hipMemsetAsync((Real *)c->d_ext + n * row, 0, (padded - n * row) * sizeof(Real), c->stream));
     const uint32_t lanes = (uint32_t)num_blocks * (uint32_t)num_threads;
@@ -2054,11 +2081,11 @@ static int grid_run_staged(mc_context *c, int num_blocks, int num_threads, uint6
 }
 
 // ---- fused form (round 4): the reference's launch itself, every thread's XORWOW stream in registers (mc_grid.hpp) -------
-// launch(tail, work, geo, workgroup size, stream, d_out) starts the product's grid kernel.  One (sum, sum2) pair per
-// reference block, closed by the last arriver like every other call.
+// launch(tail, work, geo, workgroups, workgroup size, stream, d_out) starts the product's grid kernel.  One (sum, sum2)
+// pair per workgroup (reference block x piece), closed by the last arriver like every other call.
 static bool grid_fused_fits(const mc_context *c, int num_blocks)
 {
-    return (uint64_t)num_blocks <= (uint64_t)MAX_SEGMENTS * (uint64_t)c->blocks * MAX_GRID_SCALE;   // the context's pair buffer
+    return (uint64_t)num_blocks * 32 <= (uint64_t)MAX_SEGMENTS * (uint64_t)c->blocks * MAX_GRID_SCALE;   // the context's pair buffer (<= 32 pieces)
 }
 template <class Real, class Launch>
 static int grid_run_fused(mc_context *c, int num_blocks, int num_threads, uint64_t paths_per_block, uint32_t draws, double scale1,
@@ -2069,15 +2096,21 @@ static int grid_run_fused(mc_context *c, int num_blocks, int num_threads, uint64
     const auto enqueue = [&](hipStream_t st, double *d_triple, Real *d_out) -> int {
         if (int rc = begin_call(c, st)) return rc;
         GridGeom geo;
-        if (int rc = grid_states_ready(c, num_blocks, num_threads, &geo.states)) return rc;
+        grid_pieces(num_blocks, num_threads, paths_per_block, &geo.sub, &geo.seg);
+        if ((uint64_t)geo.sub * geo.seg * draws >= (1ull << XORWOW_OFFSET_BITS)) {   // a piece's offset must fit the offset matrices: one piece
+            geo.seg = (uint32_t)(((paths_per_block + (uint64_t)num_threads - 1) / (uint64_t)num_threads + GRID_SEG_ALIGN - 1) / GRID_SEG_ALIGN * GRID_SEG_ALIGN);
+            geo.sub = 1;
+        }
+        if (int rc = grid_states_ready(c, num_blocks, num_threads, geo.sub, geo.sub > 1 ? geo.seg * draws : 0u, &geo.states)) return rc;
         geo.num_threads = (uint32_t)num_threads;
         geo.paths_per_block = (uint32_t)paths_per_block;
         Work w = make_work(0, Segment{0, 1u}, 0, 0);
         w.ext_per_unit = draws;
-        const Tail t = make_tail(c, num_blocks, scale1, scale2, n, d_triple);
+        const int groups = num_blocks * (int)geo.sub;     // one (sum, sum2) pair per workgroup
+        const Tail t = make_tail(c, groups, scale1, scale2, n, d_triple);
         const int group = (num_threads + 63) / 64 * 64;   // whole waves; the lanes beyond num_threads idle
-        if (int rc = launch(t, w, geo, group, st, d_out)) return rc;
-        return finish_call(c, t, num_blocks, st);
+        if (int rc = launch(t, w, geo, groups, group, st, d_out)) return rc;
+        return finish_call(c, t, groups, st);
     };
     if (h_values)
         return dump_sync<Real>(c, n, h_values, enqueue);
@@ -2120,7 +2153,7 @@ extern "C" int mc_grid_normals(mc_context *c, int num_blocks, int num_threads, u
     HIPCHK(hipSetDevice(c->device));
     if (int rc = ensure_ext(c, lanes * count * sizeof(float))) return rc;
     const uint32_t *states = nullptr;
-    if (int rc = grid_states_ready(c, num_blocks, num_threads, &states)) return rc;
+    if (int rc = grid_states_ready(c, num_blocks, num_threads, 1, 0, &states)) return rc;
     // every thread as the only path of its own row: paths_per_block = num_threads, one path per thread, `count` draws
     grid_normals_kernel<float><<<((uint32_t)lanes + 255) / 256, 256, 0, c->stream>>>(states, (uint32_t)num_blocks, (uint32_t)num_threads,
                                                                                     (uint64_t)num_threads, count, count, (float *)c->d_ext);
@@ -2138,8 +2171,11 @@ static int grid_basket_fused(mc_context *c, const typename BasketIn<Real>::type 
     double out_scale = 1.0;
     if (int rc = basket_fold<Real, NA>(c, *o, k, out_scale)) return rc;
     return grid_run_fused<Real>(c, nb, nt, ppb, (uint32_t)o->n, out_scale, out_scale * out_scale, std::exp(-(double)o->r * (double)o->t), h_values, out,
-                                [&](const Tail &t, const Work &w, const GridGeom &geo, int group, hipStream_t st, Real *d_out) -> int {
-                                    grid_basket_kernel<Real, NA><<<nb, group, 0, st>>>(t, k, w, geo, d_out, (Real)out_scale);
+                                [&](const Tail &t, const Work &w, const GridGeom &geo, int groups, int group, hipStream_t st, Real *d_out) -> int {
+                                    if (d_out)
+                                        grid_basket_kernel<Real, NA, true><<<groups, group, 0, st>>>(t, k, w, geo, d_out, (Real)out_scale);
+                                    else
+                                        grid_basket_kernel<Real, NA, false><<<groups, group, 0, st>>>(t, k, w, geo, d_out, (Real)out_scale);
                                     return MC_OK;
                                 });
 }
@@ -2162,11 +2198,18 @@ static int grid_vanilla(mc_context *c, const typename VanillaTraits<Real>::In *o
     double scale1, scale2;
     if (int rc = VanillaTraits<Real>::prepare(*o, k, scale1, scale2)) return rc;
     return grid_run_fused<Real>(c, nb, nt, ppb, 1u, scale1, scale2, disc, h_values, out,
-                                [&](const Tail &t, const Work &w, const GridGeom &geo, int group, hipStream_t st, Real *d_out) -> int {
-                                    if constexpr (sizeof(Real) == 4)
-                                        grid_vanilla_f32_kernel<<<nb, group, 0, st>>>(t, k, w, geo, d_out, (float)scale1);
-                                    else
-                                        grid_vanilla_f64_kernel<<<nb, group, 0, st>>>(t, k, w, geo, d_out, 1.0);
+                                [&](const Tail &t, const Work &w, const GridGeom &geo, int groups, int group, hipStream_t st, Real *d_out) -> int {
+                                    if constexpr (sizeof(Real) == 4) {
+                                        if (d_out)
+                                            grid_vanilla_f32_kernel<true><<<groups, group, 0, st>>>(t, k, w, geo, d_out, (float)scale1);
+                                        else
+                                            grid_vanilla_f32_kernel<false><<<groups, group, 0, st>>>(t, k, w, geo, d_out, (float)scale1);
+                                    } else {
+                                        if (d_out)
+                                            grid_vanilla_f64_kernel<true><<<groups, group, 0, st>>>(t, k, w, geo, d_out, 1.0);
+                                        else
+                                            grid_vanilla_f64_kernel<false><<<groups, group, 0, st>>>(t, k, w, geo, d_out, 1.0);
+                                    }
                                     return MC_OK;
                                 });
 }
@@ -2204,10 +2247,13 @@ static int grid_cva(mc_context *c, const typename CvaIn<Real>::type *o, int nb, 
         return grid_run_staged<Real>(c, nb, nt, ppb, draws, (uint32_t)o->n_grid, (uint32_t)o->n_grid, (size_t)n * (size_t)o->n_grid, 1.0, h_values, out,
                                      [&](hipStream_t st, double *t, Real *d) { return cva_enqueue<Real>(c, o, 0, 0, n, t, st, d); });
     return grid_run_fused<Real>(c, nb, nt, ppb, draws, 1.0, 1.0, 1.0, h_values, out,
-                                [&](const Tail &t, const Work &w, const GridGeom &geo, int group, hipStream_t st, Real *d_out) -> int {
+                                [&](const Tail &t, const Work &w, const GridGeom &geo, int groups, int group, hipStream_t st, Real *d_out) -> int {
                                     CvaArgs<Real> args;
                                     if (int rc = cva_table_ready<Real>(c, o, st, args)) return rc;
-                                    grid_cva_kernel<Real><<<nb, group, 0, st>>>(t, args, w, geo, d_out);
+                                    if (d_out)
+                                        grid_cva_kernel<Real, true><<<groups, group, 0, st>>>(t, args, w, geo, d_out);
+                                    else
+                                        grid_cva_kernel<Real, false><<<groups, group, 0, st>>>(t, args, w, geo, d_out);
                                     return MC_OK;
                                 });
 }

@@ -18,17 +18,25 @@ namespace mc {
 
 // ---- the reference's launch geometry (compatibility mode: mc_*_run_grid_*, include/mc_mi355x.h) -------------------
 // dp/MonteCarloKernel.cu:285-290 gives every THREAD of a (num_blocks x num_threads) launch its own XORWOW state:
-// curand_init(seed = blockIdx.x + gridDim.x, subsequence = threadIdx.x, offset 0).  Row b * T + t of `states` is that
-// state (rocRAND's seeding: what the same call gives through hipRAND on this hardware).
+// curand_init(seed = blockIdx.x + gridDim.x, subsequence = threadIdx.x, offset 0) (rocRAND's seeding: what the same call
+// gives through hipRAND on this hardware).
+// Sub-streams: the reference's 512 x 128 launch is ONE wave per SIMD of an MI355X, and a lone wave issues a dependent
+// instruction only every ~8 cycles.  So the fused kernels may cut every thread's stream into `sub` consecutive pieces of
+// `step` words each and run the pieces side by side (sub x the waves): row (b * sub + s) * T + t of `states` is thread
+// (b, t)'s state advanced by s * step words -- the xorshift part through the offset matrices A^(2^i), the Weyl word by
+// s * step * 362437.  The SAME stream, read from `sub` places at once; sub = 1 is the reference's layout (the staged form
+// and mc_grid_normals use it).
 __global__ __launch_bounds__(256) void xorwow_grid_init_kernel(const uint32_t *__restrict__ jump, uint32_t num_blocks, uint32_t num_threads,
-                                                               uint32_t *__restrict__ states)
+                                                               uint32_t sub, uint32_t step, uint32_t *__restrict__ states)
 {
     const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane >= num_blocks * num_threads)
+    if (lane >= num_blocks * sub * num_threads)
         return;
+    const uint32_t t = lane % num_threads, bs = lane / num_threads, s = bs % sub, b = bs / sub;
     uint32_t v[5], weyl;
-    xorwow_seed((uint64_t)(lane / num_threads) + num_blocks, v, weyl);
-    xorwow_jump(v, lane % num_threads, jump);
+    xorwow_seed((uint64_t)b + num_blocks, v, weyl);
+    xorwow_jump(v, t, jump);
+    xorwow_skip(v, weyl, s * step, jump);
 #pragma unroll
     for (int k = 0; k < 5; ++k)
         states[6 * (size_t)lane + k] = v[k];
@@ -130,76 +138,124 @@ struct GenGridStream {
     __device__ __forceinline__ void pairs_done(uint32_t) {}
 };
 
-// The reference's launch: num_blocks blocks of num_threads threads, paths_per_block paths per block; `states` = one start
-// state per (block, thread) (xorwow_grid_init_kernel).  The fused kernels are launched with num_blocks workgroups of
-// num_threads rounded up to whole waves (the extra lanes idle): blockIdx.x = the reference's block, threadIdx.x its thread.
+// The reference's launch: num_blocks blocks of num_threads threads, paths_per_block paths per block.  The fused kernels are
+// launched with num_blocks * sub workgroups of num_threads rounded up to whole waves (the extra lanes idle): workgroup
+// b * sub + s runs piece s of every thread of the reference's block b -- the thread's paths [s * seg, (s + 1) * seg) of its
+// own t, t + T, ... sequence (`seg` a multiple of 8 paths, so a piece starts on a Box-Muller pair boundary whatever a path
+// draws) -- from the start states xorwow_grid_init_kernel prepared for (sub, step = seg * draws per path).
 struct GridGeom {
     const uint32_t *states;
     uint32_t num_threads;
     uint32_t paths_per_block;
+    uint32_t sub, seg;   // pieces per thread; paths per piece
 };
 constexpr int GRID_MAX_THREADS = 1024;   // the reference's blockDim limit
+constexpr uint32_t GRID_SEG_ALIGN = 8;   // paths: a whole fp64 vanilla trip, and an even number of draws for any draws per path
 
-// paths of this thread: t, t + T, ... < paths_per_block
-__device__ __forceinline__ uint32_t grid_thread_paths(const GridGeom &geo)
+// this lane's piece of its reference thread's paths t, t + T, ... < paths_per_block: local path numbers [lo, hi)
+__device__ __forceinline__ void grid_thread_piece(const GridGeom &geo, uint32_t &lo, uint32_t &hi)
 {
-    return threadIdx.x < geo.paths_per_block ? (geo.paths_per_block - threadIdx.x + geo.num_threads - 1) / geo.num_threads : 0u;
+    const uint32_t n_t = threadIdx.x < geo.paths_per_block ? (geo.paths_per_block - threadIdx.x + geo.num_threads - 1) / geo.num_threads : 0u;
+    const uint32_t s = blockIdx.x % geo.sub;
+    lo = s * geo.seg;
+    hi = lo + geo.seg < n_t ? lo + geo.seg : n_t;
+    if (lo > hi)
+        lo = hi;
+}
+__device__ __forceinline__ const uint32_t *grid_state_row(const GridGeom &geo)
+{
+    return geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x);   // row (b * sub + s) * T + t
 }
 // index (in the call's path order, block-major) of this thread's k-th path: what `out` is indexed by
 __device__ __forceinline__ uint64_t grid_path_index(const GridGeom &geo, uint32_t k)
 {
-    return (uint64_t)blockIdx.x * geo.paths_per_block + threadIdx.x + (uint64_t)k * geo.num_threads;
+    return (uint64_t)(blockIdx.x / geo.sub) * geo.paths_per_block + threadIdx.x + (uint64_t)k * geo.num_threads;
 }
 
 // Vanilla: one draw per path, so a trip of NPB draws = NPB consecutive paths of the thread = NPB / 2 whole Box-Muller pairs.
 // vanilla_unit_pk / vanilla_unit are the hot kernels' per-unit functions (mc_kernels.hpp) on their external-normals path.
+// DUMP = the per-path values are also stored (tests): its own instantiation, so that the pricing form carries no store and
+// no path-index arithmetic.  Whole trips run unmasked; the thread's last, partial trip is peeled.
+template <bool DUMP>
 __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_vanilla_f32_kernel(const Tail /* first argument, read late */, const VanillaF32 o, const Work w,
                                                                             const GridGeom geo, float *__restrict__ out, float out_scale)
 {
     double acc_s = 0.0, acc_q = 0.0;
     if (threadIdx.x < geo.num_threads) {
-        const uint32_t n_t = grid_thread_paths(geo);
-        GenGridStream<true> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
-        for (uint32_t k = 0; k < n_t; k += 4) {
+        uint32_t lo, n_t;
+        grid_thread_piece(geo, lo, n_t);
+        const uint32_t whole = lo + ((n_t - lo) & ~3u);
+        GenGridStream<true> gen(grid_state_row(geo));
+        f2 s2 = {0.0f, 0.0f}, q2 = {0.0f, 0.0f};   // fp32 partial sums, flushed to fp64 every 8 trips like the hot kernel's
+        for (uint32_t k = lo; k < whole; k += 4) {
+            f2 pc, ps;   // {path k, k + 2}, {path k + 1, k + 3}
+            vanilla_unit_pk<false>(gen, o, w, 0u, pc, ps);
+            if (DUMP) {
+                out[grid_path_index(geo, k)] = pc.x * out_scale, out[grid_path_index(geo, k + 1)] = ps.x * out_scale;
+                out[grid_path_index(geo, k + 2)] = pc.y * out_scale, out[grid_path_index(geo, k + 3)] = ps.y * out_scale;
+            }
+            s2 += pc;
+            s2 += ps;
+            q2 = pk_fma(pc, pc, q2);
+            q2 = pk_fma(ps, ps, q2);
+            if ((k & 28u) == 28u) {
+                acc_s += (double)(s2.x + s2.y);
+                acc_q += (double)(q2.x + q2.y);
+                s2 = (f2){0.0f, 0.0f};
+                q2 = (f2){0.0f, 0.0f};
+            }
+        }
+        if (whole < n_t) {   // 1..3 paths left: the draws beyond them are made and dropped (nothing follows in this stream)
             float p[4];
             vanilla_unit<false>(gen, o, w, 0u, p);
-            float s = 0.0f, q = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (k + j >= n_t)
-                    p[j] = 0.0f;
-                else if (out)
-                    out[grid_path_index(geo, k + j)] = p[j] * out_scale;
-                s += p[j];
-                q = __builtin_fmaf(p[j], p[j], q);
-            }
-            acc_s += (double)s;
-            acc_q += (double)q;
+            for (int j = 0; j < 3; ++j)
+                if (whole + j < n_t) {
+                    if (DUMP)
+                        out[grid_path_index(geo, whole + j)] = p[j] * out_scale;
+                    s2.x += p[j];
+                    q2.x = __builtin_fmaf(p[j], p[j], q2.x);
+                }
         }
+        acc_s += (double)(s2.x + s2.y);
+        acc_q += (double)(q2.x + q2.y);
     }
     group_sum2(acc_s, acc_q);
     finish_group(acc_s, acc_q);
 }
+template <bool DUMP>
 __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_vanilla_f64_kernel(const Tail /* first argument, read late */, const VanillaF64 o, const Work w,
                                                                             const GridGeom geo, double *__restrict__ out, double out_scale)
 {
     stage_tables<double>();
     double acc_s = 0.0, acc_q = 0.0;
     if (threadIdx.x < geo.num_threads) {
-        const uint32_t n_t = grid_thread_paths(geo);
-        GenGridStream<true> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
-        for (uint32_t k = 0; k < n_t; k += 8) {
+        uint32_t lo, n_t;
+        grid_thread_piece(geo, lo, n_t);
+        const uint32_t whole = lo + ((n_t - lo) & ~7u);
+        GenGridStream<true> gen(grid_state_row(geo));
+        for (uint32_t k = lo; k < whole; k += 8) {
             double p[8];
             vanilla_unit<false>(gen, o, w, 0u, p);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                if (k + j >= n_t)
-                    p[j] = 0.0;
-                else if (out)
+                if (DUMP)
                     out[grid_path_index(geo, k + j)] = p[j] * out_scale;
                 acc_s += p[j];
                 acc_q = __builtin_fma(p[j], p[j], acc_q);
             }
+        }
+        if (whole < n_t) {
+            double p[8];
+            vanilla_unit<false>(gen, o, w, 0u, p);
+#pragma unroll
+            for (int j = 0; j < 7; ++j)
+                if (whole + j < n_t) {
+                    if (DUMP)
+                        out[grid_path_index(geo, whole + j)] = p[j] * out_scale;
+                    acc_s += p[j];
+                    acc_q = __builtin_fma(p[j], p[j], acc_q);
+                }
         }
     }
     group_sum2(acc_s, acc_q);
@@ -209,7 +265,7 @@ __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_vanilla_f64_kernel(cons
 // Basket: a path draws its n normals one after the other (an odd n makes a Box-Muller pair straddle two paths, as in the
 // reference).  basket_path is the kernel-argument family's per-path function; NA is the compiled size, a smaller basket
 // runs it zero-padded (rows beyond n: zero factor, base and weight -- they add exactly 0; w.ext_per_unit = n draws).
-template <class Real, int NA>
+template <class Real, int NA, bool DUMP>
 __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_basket_kernel(const Tail /* first argument, read late */, const BasketArgs<Real, NA> o, const Work w,
                                                                        const GridGeom geo, Real *__restrict__ out, Real out_scale)
 {
@@ -222,9 +278,10 @@ __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_basket_kernel(const Tai
         ConstsLds<Real, NA>::stage(lds_consts, o);
     double acc_s = 0.0, acc_q = 0.0;
     if (threadIdx.x < geo.num_threads) {
-        const uint32_t n_t = grid_thread_paths(geo);
-        GenGridStream<false> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
-        for (uint32_t k = 0; k < n_t; ++k) {
+        uint32_t lo, n_t;
+        grid_thread_piece(geo, lo, n_t);
+        GenGridStream<false> gen(grid_state_row(geo));
+        for (uint32_t k = lo; k < n_t; ++k) {
             Real p;
             if constexpr (IN_LDS)
                 p = basket_path<Real, NA, false>(gen, o, ConstsLds<Real, NA>{lds_consts}, w, 0u);
@@ -232,7 +289,7 @@ __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_basket_kernel(const Tai
                 p = basket_path<Real, NA, false>(gen, o, ConstsArg<Real, NA>{o}, w, 0u);
             acc_s += (double)p;
             acc_q = __builtin_fma((double)p, (double)p, acc_q);
-            if (out)
+            if (DUMP)
                 out[grid_path_index(geo, k)] = p * out_scale;
         }
     }
@@ -242,20 +299,21 @@ __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_basket_kernel(const Tai
 
 // CVA: cva_path is the hot kernel's per-path function; a path draws for the dates whose `t -= dt` is still >= 0
 // (w.ext_per_unit of them, dp/MonteCarloKernel.cu:249), the remaining dates of its blocks read 0 without drawing.
-template <class Real>
+template <class Real, bool DUMP>
 __global__ __launch_bounds__(GRID_MAX_THREADS) void grid_cva_kernel(const Tail /* first argument, read late */, const CvaArgs<Real> o, const Work w,
                                                                     const GridGeom geo, Real *__restrict__ out)
 {
     stage_tables<Real>();
     double acc_s = 0.0, acc_q = 0.0;
     if (threadIdx.x < geo.num_threads) {
-        const uint32_t n_t = grid_thread_paths(geo);
-        GenGridStream<false> gen(geo.states + 6u * (blockIdx.x * geo.num_threads + threadIdx.x));
-        for (uint32_t k = 0; k < n_t; ++k) {
+        uint32_t lo, n_t;
+        grid_thread_piece(geo, lo, n_t);
+        GenGridStream<false> gen(grid_state_row(geo));
+        for (uint32_t k = lo; k < n_t; ++k) {
             const Real p = cva_path<false>(gen, o, w, 0u);
             acc_s += (double)p;
             acc_q = __builtin_fma((double)p, (double)p, acc_q);
-            if (out)
+            if (DUMP)
                 out[grid_path_index(geo, k)] = p;
         }
     }

@@ -361,12 +361,17 @@ struct GenExternal {
 // bit c); the host computes them by repeated squaring (mc_api.hip).  A jump is one conditional xor of a column per set
 // state bit, per set bit of the subsequence number.
 constexpr int XORWOW_JUMP_BITS = 48;   // subsequence numbers below 2^48
-__device__ inline void xorwow_jump(uint32_t (&v)[5], uint64_t sub, const uint32_t *__restrict__ jump)
+// ... followed in the same table by XORWOW_OFFSET_BITS matrices A^(2^i), i = 0 .. 31: a jump by `offset` STEPS inside a
+// sequence (the launch-geometry kernels split a reference thread's stream into sub-streams, mc_grid.hpp).
+constexpr int XORWOW_OFFSET_BITS = 32;
+constexpr int XORWOW_JUMP_MATRICES = XORWOW_JUMP_BITS + XORWOW_OFFSET_BITS;
+// v <- (product of table[i] over the set bits i < bits of `value`) v
+__device__ inline void xorwow_apply_jumps(uint32_t (&v)[5], uint64_t value, int bits, const uint32_t *__restrict__ table)
 {
-    for (int i = 0; i < XORWOW_JUMP_BITS; ++i) {
-        if (!((sub >> i) & 1u))
+    for (int i = 0; i < bits; ++i) {
+        if (!((value >> i) & 1u))
             continue;
-        const uint32_t *m = jump + (size_t)i * 160 * 5;
+        const uint32_t *m = table + (size_t)i * 160 * 5;
         uint32_t r[5] = {0, 0, 0, 0, 0};
         for (int c = 0; c < 160; ++c) {
             const uint32_t mask = 0u - ((v[c >> 5] >> (c & 31)) & 1u);
@@ -378,6 +383,16 @@ __device__ inline void xorwow_jump(uint32_t (&v)[5], uint64_t sub, const uint32_
         for (int k = 0; k < 5; ++k)
             v[k] = r[k];
     }
+}
+__device__ inline void xorwow_jump(uint32_t (&v)[5], uint64_t sub, const uint32_t *__restrict__ jump)
+{
+    xorwow_apply_jumps(v, sub, XORWOW_JUMP_BITS, jump);
+}
+// `steps` words further in the same sequence: the xorshift words by the offset matrices, the Weyl word by steps * 362437
+__device__ inline void xorwow_skip(uint32_t (&v)[5], uint32_t &weyl, uint32_t steps, const uint32_t *__restrict__ jump)
+{
+    xorwow_apply_jumps(v, steps, XORWOW_OFFSET_BITS, jump + (size_t)XORWOW_JUMP_BITS * 160 * 5);
+    weyl += 362437u * steps;
 }
 
 // rocRAND's seeding (rocrand_xorwow.h, xorwow_engine constructor): fixed start words scrambled with the seed halves

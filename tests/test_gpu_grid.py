@@ -132,7 +132,9 @@ def test_streams_match_oracle(eng, po, G, T, count):
     assert len({r.tobytes() for r in flat}) == G * T
 
 
-GEOMS = [(1, 1, 1), (1, 64, 64), (3, 64, 200), (4, 100, 37), (2, 256, 1000), (5, 7, 1001), (2, 1024, 5000), (3, 128, 7)]
+# the last four make the fused kernels cut every thread's stream into 32, 2, 2 and 8 pieces (mc_api.hip: grid_pieces)
+GEOMS = [(1, 1, 1), (1, 64, 64), (3, 64, 200), (4, 100, 37), (2, 256, 1000), (5, 7, 1001), (2, 1024, 5000), (3, 128, 7),
+         (1, 64, 70000), (3, 100, 9001), (2, 256, 20000), (4, 128, 33001)]
 
 
 @pytest.mark.parametrize("X", ["f32", "f64"])
@@ -154,7 +156,7 @@ def test_vanilla_grid_is_the_hot_kernel_on_the_reference_arrangement(mc, eng, po
 def test_basket_grid_carries_the_kept_normal_across_paths(mc, eng, po, X, n_assets):
     """Odd asset counts: a path's last Box-Muller pair is split with the next path of the same thread."""
     b = basket_inputs(mc, n_assets, X)
-    for G, T, per_block in ((3, 64, 200), (2, 10, 33), (1, 256, 100)):
+    for G, T, per_block in ((3, 64, 200), (2, 10, 33), (1, 256, 100), (2, 64, 4100), (1, 32, 8200)):   # the last two: 2 and 8 pieces per thread
         streams = eng.grid_normals(G, T, po.grid_draws_per_thread(T, per_block, n_assets))
         g = po.grid_path_normals(streams, per_block, n_assets).astype(NP[X])
         e, fused = both_forms(eng, "basket", b, G, T, per_block, X, fused_exists=n_assets <= 16)
@@ -176,15 +178,15 @@ def test_cva_grid_draws_only_for_the_dates_that_draw(mc, eng, po, X, n_grid):
     assert 1 <= draws <= n_grid
     if X == "f32" and n_grid == 3:
         assert draws == 2
-    G, T, per_block = 3, 32, 70
-    streams = eng.grid_normals(G, T, po.grid_draws_per_thread(T, per_block, draws))
-    z = np.zeros((G * per_block, n_grid), dtype=NP[X])
-    z[:, :draws] = po.grid_path_normals(streams, per_block, draws)
-    e, fused = both_forms(eng, "cva", c, G, T, per_block, X)
-    h, vals = eng.cva_from_normals(c, z, X)
-    assert (e.sum, e.sum2, e.n) == (h.sum, h.sum2, G * per_block)
-    want, o = po.dev_cva_on_normals(X, c, z.astype(np.float64), 0)
-    assert np.abs(vals.astype(np.float64) - want).max() <= CVA_ABS[X]
+    for G, T, per_block in ((3, 32, 70), (2, 32, 1100)):      # the second: 2 pieces per thread
+        streams = eng.grid_normals(G, T, po.grid_draws_per_thread(T, per_block, draws))
+        z = np.zeros((G * per_block, n_grid), dtype=NP[X])
+        z[:, :draws] = po.grid_path_normals(streams, per_block, draws)
+        e, fused = both_forms(eng, "cva", c, G, T, per_block, X)
+        h, vals = eng.cva_from_normals(c, z, X)
+        assert (e.sum, e.sum2, e.n) == (h.sum, h.sum2, G * per_block)
+        want, o = po.dev_cva_on_normals(X, c, z.astype(np.float64), 0)
+        assert np.abs(vals.astype(np.float64) - want).max() <= CVA_ABS[X]
 
 
 def test_grid_prices_agree_with_closed_forms(mc, eng, po):

@@ -53,6 +53,8 @@ for it in range(cases):
     G = int(rng.choice([1, 2, 3, 5, 8, 13, 32, 40]))
     T = int(rng.choice([1, 2, 3, 7, 32, 64, 100, 128, 256, 1000, 1024]))
     per_block = int(rng.integers(1, 400))
+    if rng.random() < 0.2:      # long threads: the fused kernels then cut a thread's stream into several pieces (grid_pieces)
+        per_block = min(int(rng.integers(400, 40 * T + 2000)), 150000 // G)
     prod = str(rng.choice(["vanilla", "basket", "basket", "cva"]))
     spot = float(np.exp(rng.uniform(np.log(5), np.log(500))))
     r, t = float(rng.uniform(0.0, 0.08)), float(rng.choice([0.25, 0.5, 1.0, 2.0, 3.0]))
