@@ -85,14 +85,47 @@ def workload_settings(name):
     return {"normals": "f32"} if name.endswith("_n32") else {}
 
 
-def kernel_sources_sha256():
-    """Stamp of the device code the committed PMC counts were taken from: sha256 over the kernel headers, in this order
-    (tools/summarize_pmc.py writes it into profiles/pmc_traffic.json, bench.py compares)."""
+def elf_section(path, name):
+    """Bytes of one section of an ELF64 little-endian file (no binutils needed on the box)."""
+    import struct
+    b = open(path, "rb").read()
+    if b[:4] != b"\x7fELF" or b[4] != 2:
+        raise ValueError(f"{path}: not an ELF64 file")
+    shoff = struct.unpack_from("<Q", b, 0x28)[0]
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+
+    def header(i):
+        return struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize)
+    strtab = header(shstrndx)[4]
+    for i in range(shnum):
+        n, _, _, _, off, size, *_ = header(i)
+        if b[strtab + n:b.index(b"\0", strtab + n)].decode() == name:
+            return b[off:off + size]
+    raise KeyError(f"{path}: no section {name}")
+
+
+def launch_stamp(root=ROOT):
+    """Stamp of what a launch IS, for the committed PMC profiles (profiles/pmc_traffic.json, profiles/issue_model.json):
+      device_code   sha256 of the .hip_fatbin section of the built libmc_mi355x.so -- the code object the device runs
+                    (covers every kernel header, the math tables, the compiler and its flags; a rebuild of unchanged
+                    sources reproduces it bit for bit, whatever the directory);
+      launch_shape  sha256 of csrc/mc_launch_shape.hpp -- grid rules, kernel-family limits: what decides workgroups and
+                    waves per launch without touching the device code;
+      hipflags      the Makefile's HIPFLAGS line (a flag edit marks the counts stale even before the rebuild).
+    `stamp` = sha256 of the three.  tools/summarize_pmc.py writes it next to the counts (with the grid each PMC pass ran),
+    bench.py compares: stale counts are flagged and the instruction-count model is withheld."""
     import hashlib
-    h = hashlib.sha256()
-    for f in ("mc_kernels.hpp", "mc_rng.hpp", "mc_math_f64.hpp", "mc_reduce.hpp"):
-        h.update(open(os.path.join(ROOT, "montecarlocuda_amd", "csrc", f), "rb").read())
-    return h.hexdigest()
+    import re
+    csrc = os.path.join(root, "montecarlocuda_amd", "csrc")
+    so = os.path.join(csrc, "libmc_mi355x.so")
+    try:
+        device = hashlib.sha256(elf_section(so, ".hip_fatbin")).hexdigest()
+    except (OSError, KeyError, ValueError):
+        device = "library not built"
+    shape = hashlib.sha256(open(os.path.join(csrc, "mc_launch_shape.hpp"), "rb").read()).hexdigest()
+    flags = " ".join(m.strip() for m in re.findall(r"^HIPFLAGS\s*\??=.*$", open(os.path.join(csrc, "Makefile")).read(), re.M))
+    return {"stamp": hashlib.sha256("\n".join((device, shape, flags)).encode()).hexdigest(), "device_code_sha256": device,
+            "launch_shape_sha256": shape, "hipflags": flags}
 
 
 def kernel_name(prod, X, inputs):
@@ -656,8 +689,12 @@ def main():
                 committed = json.load(open(pmc)).get(args.workload, {})
             except Exception:
                 committed = {}
-        # the committed counts describe the kernels they were taken from: stale once the kernel headers change
-        traffic_stale = bool(committed) and committed.get("kernel_sources_sha256") != kernel_sources_sha256()
+        # the committed counts describe launches of one device code object and one launch shape: stale once either changes
+        # (launch_stamp), or when the grid this run launched differs from the grid the PMC passes ran
+        stamp = launch_stamp()
+        live_grid = eng.last_launch()[0] if exclusive else None
+        grid_mismatch = bool(committed) and live_grid is not None and committed.get("grid_workgroups") not in (None, live_grid)
+        traffic_stale = bool(committed) and (committed.get("launch_stamp") != stamp["stamp"] or grid_mismatch)
         out = {
             "metric": "Monte Carlo paths/sec", "value": value, "unit": "paths/s", "n_gpus": world, "steps": K,
             "warmup": W, "ms_per_step": step_s * 1e3, "higher_is_better": True, "scaling": args.scaling,
@@ -678,6 +715,7 @@ def main():
             "roofline": {"bound": "valu", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                          "frac": (ach / peak) if ach else None,
                          "traffic": committed.get("hbm_bytes_per_launch"), "traffic_stale": traffic_stale,
+                         "launch_stamp": stamp["stamp"][:16], "grid_workgroups": live_grid, "pmc_grid_workgroups": committed.get("grid_workgroups"),
                          "hbm_gbps": (committed["hbm_bytes_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
                                       / kernel_s / 1e9) if committed.get("hbm_bytes_per_launch") and kernel_s else None,
                          "hbm_frac_of_8TBps": (committed["hbm_bytes_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
@@ -698,30 +736,40 @@ def main():
                                        "paths_per_s_per_gpu": shard_count / step_s,
                                        "note": "flop of one GPU's step / step period (whole job, launch gaps and tails included)"}},
         }
-        # SURVEY 8d's second fraction: the issue-slot ceiling of the instruction mix the kernel actually issues, from the
-        # committed PMC instruction counts of this kernel (wave-instructions per launch: all VALU, fp32 transcendentals,
-        # fp64 rcp/sqrt) and the issue costs tools/ubench measured on MI355X: 4.1 cycles per VALU instruction of a
-        # wave64 next to multiplies, 8.1 per fp32 transcendental, 16.1 per v_rcp/sqrt_f64; 1024 SIMDs at 2.39 GHz.
+        # SURVEY 8d's second fraction: the VALU issue CEILING of the launch, from the kernel's own instruction stream --
+        # the opcode histogram of its hot loop (ISA listing) x the cheapest issue cost tools/ubench measured for each opcode,
+        # cross-checked against the hardware's instruction counters (tools/issue_model.py -> profiles/issue_model.json).
+        # A time no launch of this kernel can beat: issue_frac <= 1 by construction (round 3 charged every plain
+        # instruction its mixed-stream 4.1 cycles and reported 1.036 on the step period).
         if traffic_stale:
-            out["roofline"]["traffic_stale_note"] = ("the kernel headers changed since profiles/pmc_traffic.json was collected "
-                                                     "(tools/collect_pmc.sh + tools/summarize_pmc.py): traffic is the old kernels', issue_frac is withheld")
-        if committed.get("valu_insts_per_launch") and kernel_s and not traffic_stale:
-            v_all = committed["valu_insts_per_launch"] * shard_count / committed.get("paths_per_launch", shard_count)
-            t32 = committed.get("trans_f32_per_launch", 0.0) * shard_count / committed.get("paths_per_launch", shard_count)
-            t64 = committed.get("trans_f64_per_launch", 0.0) * shard_count / committed.get("paths_per_launch", shard_count)
-            cycles = (v_all - t32 - t64) * 4.1 + t32 * 8.1 + t64 * 16.1
-            ceil_s = cycles / 1024 / 2.39e9
+            out["roofline"]["traffic_stale_note"] = ("the device code object, the launch-shape rules (csrc/mc_launch_shape.hpp), HIPFLAGS or the "
+                                                     "launched grid changed since profiles/pmc_traffic.json was collected (tools/collect_pmc_all.sh): "
+                                                     "traffic is the old launches', issue_frac is withheld")
+        model = {}
+        try:
+            model = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json"))).get(args.workload, {})
+        except (OSError, ValueError):
+            model = {}
+        if model and kernel_s and not traffic_stale and model.get("launch_stamp") == stamp["stamp"] and \
+                (model.get("cross_check_ok") or model.get("rescaled_to_counters")):
+            waves_trips = shard_count / 64.0
+            ceil_s = model["min_cycles_per_path"] * waves_trips / model["simds"] / model["clock_hz"]
+            typ_s = model["typical_cycles_per_path"] * waves_trips / model["simds"] / model["clock_hz"]
             out["roofline"]["issue_frac"] = ceil_s / kernel_s
             out["roofline"]["issue_model"] = {
-                "valu_wave_insts_per_launch": v_all, "trans_f32": t32, "trans_f64_rcp_sqrt": t64, "cycles": cycles,
-                "simds": 1024, "clock_hz": 2.39e9, "ceiling_us": ceil_s * 1e6, "kernel_us": kernel_s * 1e6,
-                "frac_effective": ceil_s / step_s,
-                "source": committed.get("source", "") + " (committed PMC instruction counts, scaled to this launch's paths)",
-                "valu_busy_long_launch": committed.get("valu_busy_long_launch"),
-                "valu_busy_source": committed.get("valu_busy_source"),
-                "note": "issue_frac = time the SIMDs need just to issue this launch's VALU instructions / measured duration: "
-                        "Philox is integer work and transcendentals are half-rate, so the flop fraction cannot approach 1; "
-                        "this one can"}
+                "ceiling_us": ceil_s * 1e6, "kernel_us": kernel_s * 1e6, "frac_effective": ceil_s / step_s,
+                "typical_us": typ_s * 1e6, "typical_frac": typ_s / kernel_s,
+                "valu_insts_per_path": model["valu_per_path"], "min_cycles_per_path": model["min_cycles_per_path"],
+                "simds": model["simds"], "clock_hz": model["clock_hz"], "source": model.get("source"),
+                "cross_check": {"pmc_vs_histogram_valu": model.get("pmc_vs_model"), "ok_within_1pct": bool(model.get("cross_check_ok")),
+                                "rescaled_to_counters": bool(model.get("rescaled_to_counters"))},
+                "valu_busy_long_launch": committed.get("valu_busy_long_launch"), "valu_busy_source": committed.get("valu_busy_source"),
+                "note": "ceiling = sum over the hot loop's VALU instructions of the CHEAPEST issue cost measured for the opcode x wave-trips / "
+                        "(1024 SIMDs x 2.4 GHz): a lower bound on the launch time, so issue_frac <= 1; typical_us prices the same histogram at "
+                        "the costs of mixed streams (4.1 / 8.1 / 16.2 cycles) -- an estimate, not a bound"}
+        elif model:
+            out["roofline"]["issue_model_withheld"] = ("profiles/issue_model.json does not describe this build (stamp) or failed its cross-check "
+                                                       "against the hardware counters: re-run tools/collect_pmc_all.sh and tools/issue_model.py")
         if prod == "vanilla":
             out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
         if fp64_side:

@@ -117,6 +117,9 @@ int mc_context_device(const mc_context *ctx);
 /* The non-blocking HIP stream the context owns (the synchronous *_run_* calls use it). */
 void *mc_context_stream(const mc_context *ctx);
 int mc_context_blocks(const mc_context *ctx);
+/* Shape of the context's most recent simulation launch: workgroups and lanes per workgroup (0, 0 before the first).  The
+ * committed PMC profiles describe launches of one shape; bench.py compares (profiles/pmc_traffic.json "grid_workgroups"). */
+int mc_context_last_launch(const mc_context *ctx, int *workgroups, int *group_size);
 /* Name / CU count / clock of the context's device, for logs. */
 int mc_context_info(const mc_context *ctx, char *name, int name_len, int *compute_units, int *clock_mhz);
 

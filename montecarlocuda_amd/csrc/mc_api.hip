@@ -23,6 +23,7 @@
 #include "mc_hostmath.h"
 #include "mc_grid.hpp"
 #include "mc_kernels.hpp"
+#include "mc_launch_shape.hpp"
 
 using namespace mc;
 
@@ -43,8 +44,6 @@ using namespace mc;
 // ---------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------
-static constexpr int MAX_SEGMENTS = 8;  // per call: segments of <= 2^31 units, same high word
-static constexpr int MAX_GRID_SCALE = 6; // the heaviest kernels launch up to this many times the context's `blocks` (grid_for)
 
 struct mc_context {
     int device = 0;
@@ -102,6 +101,7 @@ struct mc_context {
     bool antithetic = false;      // estimator: plain (reference) or antithetic variates
     bool control = false;         // baskets: geometric-basket control variate
     // sampled device timing of the simulation kernels (mc_context_profile)
+    int last_grid = 0, last_group = 0;   // shape of the most recent simulation launch (mc_context_last_launch)
     int profile_every = 0;
     uint64_t launches = 0;
     std::vector<hipEvent_t> prof_start, prof_stop;
@@ -134,6 +134,7 @@ struct ProfileScope {
 template <class... KArgs, class... Args>
 static void launch_sim_lds(ProfileScope &prof, void (*kernel)(KArgs...), int grid, size_t dynamic_lds, hipStream_t st, Args... args)
 {
+    prof.c->last_grid = grid, prof.c->last_group = GROUP;
     if (prof.slot >= 0 && !prof.used) {
         prof.used = true;
         hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(GROUP), dynamic_lds, st, prof.c->prof_start[prof.slot],
@@ -257,6 +258,14 @@ extern "C" void mc_context_destroy(mc_context *c)
 }
 
 extern "C" int mc_context_device(const mc_context *c) { return c ? c->device : -1; }
+extern "C" int mc_context_last_launch(const mc_context *c, int *workgroups, int *group_size)
+{
+    if (!c)
+        return fail(MC_ERR_INVALID, "NULL context");
+    if (workgroups) *workgroups = c->last_grid;
+    if (group_size) *group_size = c->last_group;
+    return MC_OK;
+}
 extern "C" void *mc_context_stream(const mc_context *c) { return c ? (void *)c->stream : nullptr; }
 extern "C" int mc_context_blocks(const mc_context *c) { return c ? c->blocks : 0; }
 extern "C" int mc_context_info(const mc_context *c, char *name, int name_len, int *cus, int *mhz)
@@ -442,51 +451,6 @@ static Work context_work(const mc_context *c, uint64_t seed, const Segment &s, u
         w.xorwow = c->d_xorwow;
     }
     return w;
-}
-
-// Workgroups of a launch over n_units units: one lane per unit until the grid reaches `scale` x the context's `blocks`
-// (default 8 per CU = 2048), grid-stride beyond.  `scale` (halves: 2 = 1x) grows with the weight of a unit.  All workgroups
-// of a launch do equal work, but they do not finish together (CUs and XCDs run at slightly different rates, and a kernel
-// whose registers admit only 4-6 workgroups per CU runs the grid in several rounds): more, smaller workgroups even that
-// out.  Measured at the BASELINE sizes, grids of 4 ... 64 per CU interleaved in one process
-// (tools/grid_sweep_all.py, profiles/r03_grid_sweep.log), kernel time against 8 per CU:
-//     vanilla f32, basket f32 <= 12 assets    8 per CU is the optimum (16: +1...3 %)
-//     vanilla f64, CVA f64 / f32             12 per CU: -1.0 / -1.9 / -1.7 %  (flat beyond; vanilla worse from 32)
-//     tiled basket f32 (13..32 assets)       24 per CU: -1.8 %
-//     tiled basket f64 (9..32 assets)        48 per CU: -4.2 %  (C4's kernel: still improving slowly at 64)
-// The XORWOW policy keeps 1x (its per-lane states are sized by `blocks`), so do the secondary (Greeks) kernels.
-static int grid_for(const mc_context *c, uint32_t n_units, int scale_halves = 2)
-{
-    const uint64_t need = ((uint64_t)n_units + GROUP - 1) / GROUP, cap = (uint64_t)c->blocks * (uint64_t)scale_halves / 2;
-    return (int)(need < cap ? (need ? need : 1) : cap);
-}
-constexpr int GRID_SCALE_VANILLA_F64 = 3, GRID_SCALE_CVA = 3, GRID_SCALE_TILED_F32 = 6, GRID_SCALE_TILED_F64 = 2 * MAX_GRID_SCALE;
-
-// Vanilla launches whose units are cheap (4 or 2 paths each): a SMALL call is dominated by what grows with the grid --
-// dispatch, one pair and one ticket per workgroup, the last arriver's sum over the pairs -- not by the simulation.  So a
-// lane gets at least 4 units before the grid grows beyond one workgroup per CU: the 8 x 131 072-path call (the reference
-// drivers' smallest size) runs 256 workgroups instead of 1024 (kernel 7.9 instead of 8.8 us in fp32, 10.1 instead of 12.0 in fp64:
-// profiles/r02_call_latency.log); from 2.1e6 units (8.4e6 fp32 paths) on the grid is the context's `blocks` as before (16 units per lane
-// measured no better at 1e7 paths).  MC_VANILLA_UNITS_PER_LANE=1 restores
-// one unit per lane.
-static int vanilla_units_per_lane()
-{
-    static const int v = [] {
-        const char *e = getenv("MC_VANILLA_UNITS_PER_LANE");
-        const int x = e ? atoi(e) : 4;
-        return x < 1 ? 1 : (x > 1024 ? 1024 : x);
-    }();
-    return v;
-}
-static int grid_for_vanilla(const mc_context *c, uint32_t n_units, int scale_halves)
-{
-    const int full = grid_for(c, n_units, scale_halves);
-    const uint64_t per = (uint64_t)GROUP * (uint64_t)vanilla_units_per_lane();
-    uint64_t want = ((uint64_t)n_units + per - 1) / per;
-    const uint64_t floor_wgs = (uint64_t)(c->compute_units > 0 ? c->compute_units : 256);
-    if (want < floor_wgs)
-        want = floor_wgs;
-    return (int)(want < (uint64_t)full ? want : (uint64_t)full);
 }
 
 // One pricing call = one or more simulation launches that share the context's pair buffer.  The Tail tells every
@@ -945,7 +909,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
         if (int rc = xorwow_one_segment(one)) return rc;
         if (int rc = xorwow_ready(c, seed, st)) return rc;
         const Work w = context_work(c, seed, one[0], first, end);
-        const int g = grid_for(c, one[0].count);
+        const int g = grid_for(c->blocks, one[0].count);
         Tail t = make_tail(c, g, scale1, scale2, n, d_triple);
         if (!out && first % NPB == 0 && end % NPB == 0) {   // whole units only (what the legacy symbols ask for): the hot kernel,
             ProfileScope prof(c);                           // same lanes, same draws, same sums up to fp32 partial-sum order
@@ -973,7 +937,7 @@ static int vanilla_enqueue(mc_context *c, const typename VanillaTraits<Real>::In
     if (c->ext && (segs.size() > 1 || first != 0))
         return fail(MC_ERR_INVALID, "external normals: one segment starting at path 0");
     const int scale = (sizeof(Real) == 8 && !c->ext) ? GRID_SCALE_VANILLA_F64 : 2;
-    const auto grid = [&](uint32_t units) { return out ? grid_for(c, units) : grid_for_vanilla(c, units, scale); };
+    const auto grid = [&](uint32_t units) { return out ? grid_for(c->blocks, units) : grid_for_vanilla(c->blocks, c->compute_units, units, scale); };
     int total = (has_head ? 1 : 0) + (has_tail ? 1 : 0);
     for (const Segment &s : segs)
         total += grid(s.count);
@@ -1064,14 +1028,14 @@ static int planes_run(mc_context *c, size_t real_bytes, int planes, int grid_y, 
     HIPCHK(hipEventRecord(c->ev0, st));
     int pairs = 0;
     for (const Segment &s : segs)
-        pairs += grid_for(c, s.count);
+        pairs += grid_for(c->blocks, s.count);
     Tail t = make_tail(c, pairs, 1.0, 1.0, n, c->g_triples, planes, 2 * c->blocks + 2);
     t.partials = c->g_pairs;
     if (c->fused)
         t.total = (uint32_t)(pairs * grid_y);
     int slot = 0;
     for (const Segment &s : segs) {
-        const int g = grid_for(c, s.count);
+        const int g = grid_for(c->blocks, s.count);
         t.slot_base = (uint32_t)slot;
         t.ticket_base = (uint32_t)(slot * grid_y);
         launch(t, s, g, st);
@@ -1275,12 +1239,12 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
     if (int rc = basket_fold<Real, NA>(c, o, k, out_scale)) return rc;
     int total = 0, slot = 0;
     for (const Segment &s : segs)
-        total += grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
+        total += grid_for(c->blocks, is_f32 ? (s.count + 1) / 2 : s.count);
     Tail t = make_tail(c, total, out_scale, out_scale * out_scale, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = context_work(c, seed, s, 0, 0);
-        const int g = grid_for(c, is_f32 ? (s.count + 1) / 2 : s.count);
+        const int g = grid_for(c->blocks, is_f32 ? (s.count + 1) / 2 : s.count);
         t.slot_base = t.ticket_base = (uint32_t)slot;
         if (int rc = basket_launch_kernel<NA>(c, prof, c->antithetic, k, w, t, out ? out + done : (Real *)nullptr, out_scale, g, st))
             return rc;
@@ -1288,45 +1252,6 @@ static int basket_launch_n(mc_context *c, ProfileScope &prof, const typename Bas
         done += s.count;
     }
     return finish_call(c, t, total, st);
-}
-
-// Which kernel family prices a basket of n assets (measured on MI355X: tools/generic_basket_speed.py, runs
-// alternated in one gpurun call):
-//   n <= basket_static_max (fp32: 12, fp64: 8)
-//                      constants as kernel arguments / LDS-staged (basket_f32_kernel, basket_kernel)
-//   up to 32 assets    constants as scalar-loaded tiles, normals in registers (basket_tiled_f32_kernel,
-//                      basket_tiled_kernel).  fp64 9..16, one kernel per size: +3 % at 9, +14...+20 % at 10..16 over
-//                      the kernel-argument form; fp32 13, 14, 16 (15 runs the 16 kernel): +5...+8 %, below 12 the
-//                      LDS-staged form wins; 17..32: one kernel per multiple of 4 on the zero-padded buffer,
-//                      +19...+39 % over the generic kernel
-//   33..64 assets      generic tiled kernel, normals in LDS (basket_dyn_kernel, basket_dyn_f32_kernel)
-//   MC_BASKET_MFMA=1   fp64, 13..16 assets: the mat-vec as v_mfma_f64_16x16x4_f64 (basket_mfma_f64_kernel).  Off by
-//                      default: 5-6 % slower than the tiled kernel, the f64 matrix instruction does not run beside
-//                      the vector pipe on gfx950 (profiles/r02_mfma_basket.log)
-// MC_BASKET_STATIC_MAX_F32 / _F64 and MC_BASKET_TILED_MIN (read once per process) move the limits for
-// experiments and for the tests that compare the families.
-static int env_int(const char *name, int fallback, int lo, int hi)
-{
-    const char *e = getenv(name);
-    const int v = e ? atoi(e) : fallback;
-    return v < lo ? lo : (v > hi ? hi : v);
-}
-template <class Real>
-static int basket_static_max()
-{
-    static const int limit = sizeof(Real) == 4 ? env_int("MC_BASKET_STATIC_MAX_F32", 12, 0, MC_MAX_ASSETS)
-                                               : env_int("MC_BASKET_STATIC_MAX_F64", 8, 0, MC_MAX_ASSETS);
-    return limit;
-}
-static bool basket_mfma()
-{
-    static const int on = env_int("MC_BASKET_MFMA", 0, 0, 1);
-    return on != 0;
-}
-static int basket_tiled_min()
-{
-    static const int limit = env_int("MC_BASKET_TILED_MIN", 9, 9, 1000);
-    return limit;
 }
 
 // The table-driven families: fold the constants exactly like basket_launch_n (no power-of-two rescale:
@@ -1467,12 +1392,12 @@ static int basket_launch_dyn(mc_context *c, ProfileScope &prof, const typename B
     const int scale = (lds == 0 && tiled_ok && gen != GEN_XORWOW) ? (sizeof(Real) == 8 ? GRID_SCALE_TILED_F64 : GRID_SCALE_TILED_F32) : 2;
     int total = 0, slot = 0;
     for (const Segment &s : segs)
-        total += grid_for(c, pairs ? (s.count + 1) / 2 : s.count, scale);
+        total += grid_for(c->blocks, pairs ? (s.count + 1) / 2 : s.count, scale);
     Tail tail = make_tail(c, total, 1.0, 1.0, n_paths, d_triple);
     uint64_t done = 0;
     for (const Segment &s : segs) {
         const Work w = context_work(c, seed, s, 0, 0);
-        const int g = grid_for(c, pairs ? (s.count + 1) / 2 : s.count, scale);
+        const int g = grid_for(c->blocks, pairs ? (s.count + 1) / 2 : s.count, scale);
         tail.slot_base = tail.ticket_base = (uint32_t)slot;
         launch_sim_lds(prof, kernel, g, lds, st, tail, k, w, out ? out + done : (Real *)nullptr);
         slot += g;
@@ -1655,7 +1580,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     const int scale = (c->rng == MC_RNG_XORWOW && !c->ext) ? 2 : GRID_SCALE_CVA;
     int total = 0, slot = 0;
     for (const Segment &s : segs)
-        total += grid_for(c, s.count, scale);
+        total += grid_for(c->blocks, s.count, scale);
     Tail t = make_tail(c, total, 1.0, 1.0, n, d_triple);
     uint64_t done = 0;
     ProfileScope prof(c);
@@ -1669,7 +1594,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     }
     for (const Segment &s : segs) {
         const Work w = context_work(c, seed, s, 0, 0);
-        const int g = grid_for(c, s.count, scale);
+        const int g = grid_for(c->blocks, s.count, scale);
         t.slot_base = t.ticket_base = (uint32_t)slot;
         Real *dst = out ? out + done : (Real *)nullptr;
         constexpr unsigned ALLOW = GEN_PHILOX | GEN_XORWOW | GEN_EXTERNAL | (sizeof(Real) == 8 ? GEN_F32N : 0);
@@ -2023,26 +1948,6 @@ static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, uin
     return MC_OK;
 }
 
-// How many pieces the fused kernels cut every reference thread's stream into (mc_grid.hpp "sub-streams"): enough to put
-// ~8 waves on every SIMD (the reference's 512 x 128 launch alone is ONE), as long as a piece keeps >= 16 paths; a power
-// of two up to 32.  MC_GRID_SUB forces a count (1 = the reference's own layout).
-static void grid_pieces(int num_blocks, int num_threads, uint64_t paths_per_block, uint32_t *sub, uint32_t *seg)
-{
-    static const int forced = env_int("MC_GRID_SUB", 0, 0, 32);
-    const uint64_t n_max = (paths_per_block + (uint64_t)num_threads - 1) / (uint64_t)num_threads;   // thread 0's paths
-    const uint64_t lanes = (uint64_t)num_blocks * (uint64_t)((num_threads + 63) / 64 * 64), want = 8ull * 1024 * 64;
-    uint32_t s = 1;
-    if (forced > 0) {
-        while (s * 2 <= (uint32_t)forced) s *= 2;
-    } else {
-        while (s < 32 && lanes * s * 2 <= want && n_max >= 16ull * s * 2)
-            s *= 2;
-    }
-    const uint64_t per = (n_max + s - 1) / s;
-    *sub = s;
-    *seg = (uint32_t)((per + GRID_SEG_ALIGN - 1) / GRID_SEG_ALIGN * GRID_SEG_ALIGN);
-}
-
 extern "C" int mc_context_set_grid_form(mc_context *c, int form)
 {
     if (!c || (form != MC_GRID_FORM_AUTO && form != MC_GRID_FORM_STAGED && form != MC_GRID_FORM_FUSED))
@@ -2111,6 +2016,7 @@ static int grid_run_fused(mc_context *c, int num_blocks, int num_threads, uint64
         const int groups = num_blocks * (int)geo.sub;     // one (sum, sum2) pair per workgroup
         const Tail t = make_tail(c, groups, scale1, scale2, n, d_triple);
         const int group = (num_threads + 63) / 64 * 64;   // whole waves; the lanes beyond num_threads idle
+        c->last_grid = groups, c->last_group = group;
         if (int rc = launch(t, w, geo, groups, group, st, d_out)) return rc;
         return finish_call(c, t, groups, st);
     };
@@ -2393,9 +2299,9 @@ static int grid_cva(mc_context *c, const typename CvaIn<Real>::type *o, int nb, 
             for (const Segment &s : segs) {                                                                  \
                 const Work w = make_work(seed, s, 0, 0);                                                     \
                 if (sizeof(Real) == 8 && c->normals_f32)                                                     \
-                    normals_kernel<Real, GenPhiloxF32N><<<grid_for(c, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
+                    normals_kernel<Real, GenPhiloxF32N><<<grid_for(c->blocks, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
                 else                                                                                         \
-                    normals_kernel<Real><<<grid_for(c, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
+                    normals_kernel<Real><<<grid_for(c->blocks, s.count), GROUP, 0, st>>>(w, block, domain, d + done * NPB); \
                 done += s.count;                                                                             \
             }                                                                                                \
             HIPCHK(hipGetLastError());                                                                       \

@@ -142,6 +142,12 @@ class Engine:
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value,
                 "blocks": self.blocks}
 
+    def last_launch(self):
+        """(workgroups, lanes per workgroup) of the most recent simulation launch of this context."""
+        g, t = C.c_int(), C.c_int()
+        check(lib().mc_context_last_launch(self._ctx, C.byref(g), C.byref(t)))
+        return g.value, t.value
+
     def set_antithetic(self, on: bool):
         """Plain Monte Carlo (the reference's estimator) or antithetic variates (pair means)."""
         check(lib().mc_context_set_antithetic(self._ctx, 1 if on else 0))

@@ -51,10 +51,14 @@ def test_bench_contract_single_gpu():
     assert r["in_region"]["avg_kernel_us"] >= r["avg_kernel_us"] * 0.95
     assert 0 < r["effective"]["frac"] < 1 and d["timed_region_s"] == pytest.approx(d["ms_per_step"] * 40e-3, rel=1e-9)
     assert "not measured in this run" in r["traffic_source"]
-    if r["traffic_stale"]:     # the kernel headers changed since the committed PMC passes: the instruction-count model is withheld
+    if r["traffic_stale"]:     # device code, launch-shape rules or grid changed since the committed PMC passes: the model is withheld
         assert "issue_frac" not in r and "traffic_stale_note" in r
+    elif "issue_frac" in r:    # a CEILING now: the cheapest measured cost of every opcode of the hot loop -- never above 1, on the step period either
+        assert 0.5 < r["issue_frac"] <= 1.0 and r["issue_model"]["frac_effective"] <= 1.0
+        assert r["issue_model"]["ceiling_us"] <= r["issue_model"]["typical_us"]
     else:
-        assert 0.5 < r["issue_frac"] < 1.1
+        assert "issue_model_withheld" in r
+    assert r["grid_workgroups"] == 2048 and len(r["launch_stamp"]) == 16
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 1e6
     assert abs(d["fp64"]["price"] - BS) < 0.05
@@ -84,7 +88,7 @@ def test_bench_contract_single_gpu():
 def test_bench_two_ranks_share_the_gpu(scaling):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--scaling", scaling,
-           "--steps", "30", "--warmup", "3", "--regions", "2", "--cpu-seconds", "0", "--fp64-steps", "4", "--strong-reps", "2"]
+           "--steps", "30", "--warmup", "3", "--regions", "2", "--cpu-seconds", "0", "--fp64-steps", "4", "--strong-reps", "2", "--strong-preheat-ms", "30"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     d = _json_line(out.stdout)
@@ -104,7 +108,7 @@ def test_bench_rccl_plumbing_world_of_one():
     device barrier and the MAX over ranks all run through RCCL."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "60", "--warmup", "5",
-           "--cpu-seconds", "0", "--fp64-steps", "4"]
+           "--cpu-seconds", "0", "--fp64-steps", "4", "--strong-reps", "2", "--strong-preheat-ms", "30"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0, out.stderr[-3000:]

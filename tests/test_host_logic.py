@@ -114,3 +114,60 @@ def test_multi_gpu_host_control_flow_without_a_gpu(tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     print(out.stdout)
     assert out.returncode == 0 and "all checks passed" in out.stdout and "FAILED" not in out.stdout, out.stdout + out.stderr
+
+
+def test_pmc_stamp_covers_the_launch(tmp_path):
+    """The stamp that decides `traffic_stale` (bench.launch_stamp) covers what a launch IS: the device code object (the
+    .hip_fatbin section of the built library), the launch-shape rules (csrc/mc_launch_shape.hpp: grid scales, kernel-family
+    limits) and HIPFLAGS -- shown on a patched COPY of the tree (VERDICT r03 "next" #3; round 3 hashed four headers and
+    missed the grid rules that had moved into mc_api.hip)."""
+    import os
+    import re
+    import shutil
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    src = os.path.join(root, "montecarlocuda_amd", "csrc")
+    copy = tmp_path / "tree" / "montecarlocuda_amd" / "csrc"
+    copy.mkdir(parents=True)
+    for f in ("libmc_mi355x.so", "mc_launch_shape.hpp", "Makefile"):
+        shutil.copy(os.path.join(src, f), copy / f)
+    base = bench.launch_stamp(root)
+    assert base == bench.launch_stamp(str(tmp_path / "tree")) and len(base["device_code_sha256"]) == 64     # where the tree lies does not matter
+
+    def stamp_after(name, edit, binary=False):
+        path = copy / name
+        old = path.read_bytes() if binary else path.read_text()
+        path.write_bytes(edit(old)) if binary else path.write_text(edit(old))
+        out = bench.launch_stamp(str(tmp_path / "tree"))
+        path.write_bytes(old) if binary else path.write_text(old)
+        return out
+    # a grid scale: vanilla f64 from 12 to 16 workgroups per CU
+    shape = stamp_after("mc_launch_shape.hpp", lambda t: re.sub(r"GRID_SCALE_VANILLA_F64 = 3", "GRID_SCALE_VANILLA_F64 = 4", t, count=1))
+    assert shape["stamp"] != base["stamp"] and shape["launch_shape_sha256"] != base["launch_shape_sha256"]
+    assert shape["device_code_sha256"] == base["device_code_sha256"]
+    # an optimisation flag
+    flags = stamp_after("Makefile", lambda t: t.replace("HIPFLAGS ?= -O3", "HIPFLAGS ?= -O2", 1))
+    assert flags["stamp"] != base["stamp"] and "-O2" in flags["hipflags"] and "-O3" in base["hipflags"]
+    # one byte of device code
+    sect = bench.elf_section(os.path.join(src, "libmc_mi355x.so"), ".hip_fatbin")
+    at = (copy / "libmc_mi355x.so").read_bytes().index(sect[:64]) + len(sect) // 2
+
+    def flip(b):
+        b = bytearray(b)
+        b[at] ^= 1
+        return bytes(b)
+    code = stamp_after("libmc_mi355x.so", flip, binary=True)
+    assert code["stamp"] != base["stamp"] and code["device_code_sha256"] != base["device_code_sha256"]
+    # host-only bytes of the library (outside the code object) do not matter
+    def flip_host(b):
+        b = bytearray(b)
+        b[16] ^= 1          # e_type of the ELF header
+        return bytes(b)
+    host = stamp_after("libmc_mi355x.so", flip_host, binary=True)
+    assert host["stamp"] == base["stamp"]
+    # ... and bench.py's comparison: a committed profile with another stamp, or another grid, is stale
+    committed = {"launch_stamp": base["stamp"], "grid_workgroups": 2048}
+    stale = lambda c, stamp, grid: c.get("launch_stamp") != stamp or c.get("grid_workgroups") not in (None, grid)   # noqa: E731
+    assert not stale(committed, base["stamp"], 2048) and stale(committed, shape["stamp"], 2048) and stale(committed, base["stamp"], 3072)

@@ -17,13 +17,19 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 w = sys.argv[1] if len(sys.argv) > 1 else "vanilla_f32"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 base = os.path.join(ROOT, "gpurun_out", f"pmc_{w}")
 acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
+grids = defaultdict(set)                       # kernel -> {(workgroups, lanes per workgroup)} seen in the passes
 files = []
+x2 = defaultdict(lambda: defaultdict(list))    # the same for the pass at twice the paths per launch (sq1x2)
 for d in glob.glob(os.path.join(base, "*", "")):      # one directory per pass; keep its newest run only
     runs = sorted(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
-    if runs:
+    if runs and os.path.basename(os.path.dirname(d)) == "sq1x2":
+        for row in csv.DictReader(open(runs[-1])):
+            if "mc::" in row["Kernel_Name"]:
+                x2[row["Kernel_Name"].split("(")[0].replace("void ", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    elif runs:
         files.append(runs[-1])
 for f in files:
     for row in csv.DictReader(open(f)):
@@ -32,10 +38,12 @@ for f in files:
             continue
         k = k.split("(")[0].replace("void ", "")
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if row.get("Grid_Size") and row.get("Workgroup_Size"):
+            grids[k].add((int(row["Grid_Size"]) // int(row["Workgroup_Size"]), int(row["Workgroup_Size"])))
 lines = []
 summary = {}
 for k in sorted(acc):
-    lines.append(f"kernel {k}")
+    lines.append(f"kernel {k}   launched as (workgroups x lanes): {sorted(grids[k])}")
     avg = {}
     for c in sorted(acc[k]):
         v = acc[k][c]
@@ -59,6 +67,7 @@ print(text)
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{w}.txt"), "w").write(
     f"# rocprofv3 --pmc passes of `python3 bench.py --workload {w} --steps 20 --warmup 2 --regions 1` (tools/collect_pmc.sh)\n" + text + "\n")
+print(f"launch stamp {__import__('bench').launch_stamp()['stamp'][:16]}")
 main = [k for k in summary if "finish" not in k and "masked" not in k]
 if main and "FETCH_SIZE" in summary[main[0]]:
     a = summary[main[0]]
@@ -67,7 +76,20 @@ if main and "FETCH_SIZE" in summary[main[0]]:
     keep = {k: v for k, v in d.get(w, {}).items() if k.startswith("valu_busy")}   # filled by tools/clock_probe.py runs
     paths = {"vanilla": 10 ** 8, "basket4": 10 ** 8, "basket16": 125 * 10 ** 6, "cva256": 1250000}[w.split("_")[0]]
     sys.path.insert(0, ROOT)
-    from bench import kernel_sources_sha256   # the stamp bench.py compares: stale counts are flagged, not used
+    from bench import launch_stamp   # the stamp bench.py compares: stale counts are flagged, not used
+    stamp = launch_stamp()
+    # hot-loop slope: (counts at 2 x paths - counts at 1 x paths) / paths, in wave-instructions per path
+    slope = {}
+    b = {c: sum(v) / len(v) for c, v in x2.get(main[0], {}).items()}
+    if b and abs(b.get("SQ_WAVES", 0) - a.get("SQ_WAVES", -1)) < 0.5:
+        for c, key in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_VALU_TRANS_F32", "trans_f32"), ("SQ_INSTS_VALU_TRANS_F64", "trans_f64"),
+                       ("SQ_INSTS_SALU", "salu"), ("SQ_INSTS_SMEM", "smem"), ("SQ_INSTS_LDS", "lds")):
+            if c in a and c in b:
+                slope[key + "_wave_insts_per_path"] = (b[c] - a[c]) / paths
+        print("hot-loop slope (wave-instructions per path, x 64 = per lane): " + ", ".join(f"{k.split('_wave')[0]} {v * 64:.3f}" for k, v in slope.items()))
+    shapes = sorted(grids[main[0]])
+    if len(shapes) != 1:
+        print(f"WARNING: {main[0]} ran with several launch shapes in the passes: {shapes}")
     d[w] = {"kernel": main[0], "fetch_bytes_raw": a["FETCH_SIZE"] * 1024, "write_bytes": a["WRITE_SIZE"] * 1024,
             "hbm_bytes_per_launch": 2 * a["FETCH_SIZE"] * 1024 + a["WRITE_SIZE"] * 1024,
             "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts wide reads at half); per simulation-kernel launch",
@@ -75,5 +97,7 @@ if main and "FETCH_SIZE" in summary[main[0]]:
             # wave-instructions per launch, for bench.py's issue-slot model (roofline.issue_frac)
             "paths_per_launch": paths, "valu_insts_per_launch": a.get("SQ_INSTS_VALU"),
             "trans_f32_per_launch": a.get("SQ_INSTS_VALU_TRANS_F32", 0.0), "trans_f64_per_launch": a.get("SQ_INSTS_VALU_TRANS_F64", 0.0),
-            "waves_per_launch": a.get("SQ_WAVES"), "kernel_sources_sha256": kernel_sources_sha256(), **keep}
+            "waves_per_launch": a.get("SQ_WAVES"), "grid_workgroups": shapes[0][0] if shapes else None,
+            "group_size": shapes[0][1] if shapes else None, "launch_stamp": stamp["stamp"], "device_code_sha256": stamp["device_code_sha256"],
+            "launch_shape_sha256": stamp["launch_shape_sha256"], "hipflags": stamp["hipflags"], "hot_loop_slope": slope, **keep}
     json.dump(d, open(j, "w"), indent=1)
