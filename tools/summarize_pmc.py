@@ -16,6 +16,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)   # bench.py (launch_stamp) lives at the repo root; `python tools/summarize_pmc.py` does not put it on the path
 w = sys.argv[1] if len(sys.argv) > 1 else "vanilla_f32"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 base = os.path.join(ROOT, "gpurun_out", f"pmc_{w}")
@@ -75,17 +76,20 @@ if main and "FETCH_SIZE" in summary[main[0]]:
     d = json.load(open(j)) if os.path.exists(j) else {}
     keep = {k: v for k, v in d.get(w, {}).items() if k.startswith("valu_busy")}   # filled by tools/clock_probe.py runs
     paths = {"vanilla": 10 ** 8, "basket4": 10 ** 8, "basket16": 125 * 10 ** 6, "cva256": 1250000}[w.split("_")[0]]
-    sys.path.insert(0, ROOT)
     from bench import launch_stamp   # the stamp bench.py compares: stale counts are flagged, not used
     stamp = launch_stamp()
     # hot-loop slope: (counts at 2 x paths - counts at 1 x paths) / paths, in wave-instructions per path
     slope = {}
-    b = {c: sum(v) / len(v) for c, v in x2.get(main[0], {}).items()}
+    # the MEDIAN dispatch: besides its K + W steps a bench run makes a launch or two of other sizes (23 dispatches with one at the
+    # default path count in the basket and CVA passes), which an average would mix in
+    med = lambda v: sorted(v)[len(v) // 2]
+    b = {c: med(v) for c, v in x2.get(main[0], {}).items()}
+    a1 = {c: med(v) for c, v in acc[main[0]].items()}
     if b and abs(b.get("SQ_WAVES", 0) - a.get("SQ_WAVES", -1)) < 0.5:
         for c, key in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_VALU_TRANS_F32", "trans_f32"), ("SQ_INSTS_VALU_TRANS_F64", "trans_f64"),
                        ("SQ_INSTS_SALU", "salu"), ("SQ_INSTS_SMEM", "smem"), ("SQ_INSTS_LDS", "lds")):
-            if c in a and c in b:
-                slope[key + "_wave_insts_per_path"] = (b[c] - a[c]) / paths
+            if c in a1 and c in b:
+                slope[key + "_wave_insts_per_path"] = (b[c] - a1[c]) / paths
         print("hot-loop slope (wave-instructions per path, x 64 = per lane): " + ", ".join(f"{k.split('_wave')[0]} {v * 64:.3f}" for k, v in slope.items()))
     shapes = sorted(grids[main[0]])
     if len(shapes) != 1:
