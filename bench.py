@@ -377,7 +377,7 @@ def main():
     ap.add_argument("--regions", type=int, default=5,
                     help="the K-step timed region is repeated this many times back to back (fresh path ranges each time, one "
                          "pre-heat before the first); ms_per_step and value are the MEDIAN region's, min and max are reported: a "
-                         "20-step region is 1 ms, one sample of it moves by +-4 % between runs")
+                         "20-step region is 1 ms, one sample of it moves by +-4 %% between runs")
     ap.add_argument("--workload", default="vanilla_f32")
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")

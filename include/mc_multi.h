@@ -67,7 +67,8 @@ int mc_multi_set_timing(mc_multi *m, int on);
 int mc_multi_set_reduce(mc_multi *m, int mode);
 /* Launcher threads (created with the handle when it has more than one device; MC_MULTI_THREADS=0 in the environment keeps
  * the serial fan-out from the calling thread).  A launcher thread spins on its flag word for MC_MULTI_LINGER_US (default
- * 2000) after its last job and then sleeps, so back-to-back calls pay no wake-up and an idle handle uses no core.
+ * 100000: longer than any call a handle is likely to be given, since the time between two hand-offs is the previous
+ * call's whole duration) after its last job and then sleeps, so back-to-back calls pay no wake-up and an idle handle uses no core.
  * mc_multi_launcher_threads: how many the handle runs (0 = serial).  mc_multi_last_fanout_us: host time from the entry of
  * the last mc_multi_*_run_* call until the LAST device's launch had been enqueued.  One calling thread per handle. */
 int mc_multi_launcher_threads(const mc_multi *m);

@@ -62,6 +62,8 @@ static int fail(int code, const char *fmt, ...)
             return fail(rc_, "device %d: %s", m->devices[g], mc_last_error()); \
     } while (0)
 
+constexpr int MAX_DEVICES = 64;   // mc_multi_create's limit
+
 struct mc_multi {
     std::vector<int> devices;
     std::vector<mc_context *> ctx;
@@ -80,6 +82,7 @@ struct mc_multi {
     std::unique_ptr<mc_host::LaunchCrew> crew;
     std::vector<std::string> worker_error;     // text of a worker's failed launch (mc_last_error is per thread)
     double last_fanout_us = 0.0;               // call entry -> the last device's launch enqueued, of the last call
+    bool trace = false;                        // MC_MULTI_TRACE=1: one stderr line per call with every device's hand-off and enqueue time
 };
 
 extern "C" void mc_multi_destroy(mc_multi *m)
@@ -137,7 +140,7 @@ extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc
         return fail(MC_ERR_NO_DEVICE, "no HIP device visible (the HIP engine has no CPU fallback)");
     if (!devices && n_devices <= 0)
         n_devices = visible;
-    if (n_devices <= 0 || n_devices > 64)
+    if (n_devices <= 0 || n_devices > MAX_DEVICES)
         return fail(MC_ERR_INVALID, "mc_multi_create: n_devices=%d", n_devices);
     mc_multi *m = new mc_multi;
     for (int g = 0; g < n_devices; ++g) {
@@ -158,12 +161,14 @@ extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc
     }
     // Launcher threads: device g's launches are issued by thread g (its own hipSetDevice, arm and launch), started through
     // one flag word each, so that device G-1 starts with device 0 instead of (G-1) x ~4 us later.  A worker spins for
-    // MC_MULTI_LINGER_US (default 2000) after its last job and then sleeps: back-to-back calls never pay a wake-up, an
+    // MC_MULTI_LINGER_US (default 100 000: longer than any BASELINE shard lasts -- C4 x 10 is 34 ms per device -- because the
+    // time between two hand-offs is the whole previous call) after its last job and then sleeps: back-to-back calls never pay a wake-up, an
     // idle handle burns no core.
+    m->trace = getenv("MC_MULTI_TRACE") && atoi(getenv("MC_MULTI_TRACE")) != 0;
     const char *th = getenv("MC_MULTI_THREADS");
     if (n_devices > 1 && !(th && atoi(th) == 0)) {
         const char *lg = getenv("MC_MULTI_LINGER_US");
-        const long linger_us = lg ? atol(lg) : 2000;
+        const long linger_us = lg ? atol(lg) : 100000;
         m->worker_error.resize((size_t)n_devices);
         m->crew.reset(new mc_host::LaunchCrew(
             n_devices, std::chrono::microseconds(linger_us < 0 ? 0 : linger_us),
@@ -304,7 +309,9 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     const auto wall0 = std::chrono::steady_clock::now();
     InFlight fl(m);
     bool direct = !m->timing && !m->readback_copy;
-    std::vector<const volatile double *> slot((size_t)G + 1, nullptr);   // [G] = the all-reduced triple's slot
+    // per-device scratch of the call on the stack (mc_multi_create admits at most 64 devices): no allocation between the
+    // call's entry and the first launch
+    const volatile double *slot[MAX_DEVICES + 1] = {};   // [G] = the all-reduced triple's slot
     // device g's part of the call; runs on the calling thread or on launcher thread g.  Returns an MC_* status; the text
     // of a failure goes to `err` (mc_last_error is thread-local: a worker's text would be lost otherwise).
     struct Job {
@@ -313,8 +320,8 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
         bool want_direct;
         const volatile double **slot;
         Launch *launch;
-        std::vector<char> armed;
-    } job{m, first, n, direct, slot.data(), &launch, std::vector<char>((size_t)G, 0)};
+        char armed[MAX_DEVICES];
+    } job{m, first, n, direct, slot, &launch, {}};
     const auto device_part = [](void *jp, int g) -> int {
         Job &j = *static_cast<Job *>(jp);
         mc_multi *m = j.m;
@@ -347,10 +354,10 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
         return MC_OK;
     };
     fl.touched = G;   // from here on any device may have work of this call
-    std::vector<int> rcs((size_t)G, MC_OK);
-    std::vector<int64_t> at_ns((size_t)G, 0);
+    int rcs[MAX_DEVICES] = {};
+    int64_t at_ns[MAX_DEVICES] = {}, seen_ns[MAX_DEVICES] = {};
     if (m->crew) {
-        m->crew->run_all(device_part, &job, rcs.data(), wall0, at_ns.data());
+        m->crew->run_all(device_part, &job, rcs, wall0, at_ns, seen_ns);
     } else {
         for (int g = 0; g < G; ++g) {
             rcs[(size_t)g] = device_part(&job, g);
@@ -369,6 +376,14 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
             direct = false;
     }
     m->last_fanout_us = last_ns * 1e-3;
+    if (m->trace) {   // MC_MULTI_TRACE=1: when each launcher thread saw the call and when its launch had been enqueued
+        fprintf(stderr, "mc_multi fan-out (us since call entry; %s):", m->crew ? (m->crew->yields() ? "launcher threads, yielding spin" : "launcher threads") : "serial");
+        for (int g = 0; g < G; ++g)
+            fprintf(stderr, "  [%d] %.2f -> %.2f", g, seen_ns[(size_t)g] * 1e-3, at_ns[(size_t)g] * 1e-3);
+        if (m->crew)
+            fprintf(stderr, "  | jobs taken over by the caller so far: %llu", (unsigned long long)m->crew->stolen());
+        fprintf(stderr, "\n");
+    }
     if (!direct)
         for (int g = 0; g < G; ++g)
             slot[(size_t)g] = nullptr;
@@ -390,7 +405,7 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     if (direct) {
         // one polling loop over every flag word; after 50 ms (BASELINE's C4 and C5 shards take 1-40 ms) hand the core
         // back and wait in the runtime, which is also the way out if a device faulted and will never write
-        if (!mc_host::poll_slots(slot.data(), G + 1, wall0, std::chrono::milliseconds(50), [&] { fl.settle(); }))
+        if (!mc_host::poll_slots(slot, G + 1, wall0, std::chrono::milliseconds(50), [&] { fl.settle(); }))
             return fail(MC_ERR_HIP, "a device never delivered its result");
         for (int g = 0; g < G; ++g)
             for (int k = 0; k < 3; ++k)

@@ -72,6 +72,12 @@ static bool poll_slots(const volatile double *const *slots, int n, std::chrono::
 // caller), every spin iteration yields the CPU instead (sched_yield): a spinning thread that sits on the core the
 // thread it waits for needs would otherwise cost a whole scheduler quantum (measured: 2 ms per hand-off with 9 threads
 // on 8 CPUs, 3 us with the yield).
+// A job belongs to whoever CLAIMS it (one compare-exchange on the worker's `claim` word): normally worker g, but when
+// worker g has not claimed its job `steal_after` after the hand-off -- it is parked and still waking up, or the kernel
+// scheduler took its core away in the middle of a spin (seen once in 41 calls on a shared 256-thread host: a 9.5 ms
+// fan-out) -- the CALLER claims it and runs it on its own thread.  The worst case of a fan-out is then the serial
+// fan-out of rounds 2-3, not a scheduler quantum; a handle whose workers sleep is served serially instead of through G
+// wake-ups.  Every job still runs exactly once.
 // ---------------------------------------------------------------------------------------------------------------
 static inline int cpus_allowed()
 {
@@ -86,8 +92,9 @@ class LaunchCrew {
 public:
     typedef int (*JobFn)(void *ctx, int g);
 
-    LaunchCrew(int n, std::chrono::nanoseconds linger, void (*thread_init)(void *, int) = nullptr, void *init_ctx = nullptr)
-        : linger_(linger), yield_(cpus_allowed() < n + 1), workers_((size_t)n)
+    LaunchCrew(int n, std::chrono::nanoseconds linger, void (*thread_init)(void *, int) = nullptr, void *init_ctx = nullptr,
+               std::chrono::nanoseconds steal_after = std::chrono::microseconds(15))
+        : linger_(linger), steal_after_(steal_after), yield_(cpus_allowed() < n + 1), workers_((size_t)n)
     {
         for (int g = 0; g < n; ++g) {
             workers_[(size_t)g].reset(new Worker);
@@ -115,10 +122,13 @@ public:
 
     int size() const { return (int)workers_.size(); }
     bool yields() const { return yield_; }
+    uint64_t stolen() const { return stolen_; }   // jobs the calling thread ran itself because their worker was late
 
     // Runs fn(ctx, g) on worker g for every g, waits for all of them; rc[g] = fn's return value.
     // enqueued_ns[g] (optional) = steady_clock time at which worker g's job returned, in ns since `t0`.
-    void run_all(JobFn fn, void *ctx, int *rc, std::chrono::steady_clock::time_point t0 = {}, int64_t *enqueued_ns = nullptr)
+    // seen_ns[g] (optional) = the time at which worker g SAW the call: hand-off latency apart from the job's own duration.
+    void run_all(JobFn fn, void *ctx, int *rc, std::chrono::steady_clock::time_point t0 = {}, int64_t *enqueued_ns = nullptr,
+                 int64_t *seen_ns = nullptr)
     {
         fn_ = fn, ctx_ = ctx, t0_ = t0;
         const uint32_t seq = ++seq_;
@@ -129,22 +139,38 @@ public:
                 w->cv.notify_one();
             }
         }
+        const auto handed = std::chrono::steady_clock::now();
         for (size_t g = 0; g < workers_.size(); ++g) {
             Worker &w = *workers_[g];
-            while (w.done.load(std::memory_order_acquire) != seq)
+            while (w.done.load(std::memory_order_acquire) != seq) {
+                if (w.claim.load(std::memory_order_relaxed) != seq && std::chrono::steady_clock::now() - handed > steal_after_) {
+                    uint32_t expect = seq - 1;
+                    if (w.claim.compare_exchange_strong(expect, seq, std::memory_order_acq_rel)) {   // the worker is late: the job is ours
+                        w.seen_ns = -1;
+                        w.rc = fn_(ctx_, (int)g);
+                        w.at_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+                        w.done.store(seq, std::memory_order_release);
+                        ++stolen_;
+                        break;
+                    }
+                }
                 relax();
+            }
             rc[g] = w.rc;
             if (enqueued_ns)
                 enqueued_ns[g] = w.at_ns;
+            if (seen_ns)
+                seen_ns[g] = w.seen_ns;
         }
     }
 
 private:
     struct alignas(128) Worker {
         std::atomic<uint32_t> go{0};
+        alignas(128) std::atomic<uint32_t> claim{0};   // the last call whose job somebody took: worker g, or the caller when g was late
         alignas(128) std::atomic<uint32_t> done{0};
         int rc = 0;
-        int64_t at_ns = 0;
+        int64_t at_ns = 0, seen_ns = 0;
         alignas(128) std::atomic<bool> parked{false};
         std::mutex mu;
         std::condition_variable cv;
@@ -173,9 +199,13 @@ private:
                 }
             }
             seen = cur;
-            w.rc = fn_(ctx_, g);
-            w.at_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
-            w.done.store(cur, std::memory_order_release);
+            uint32_t expect = cur - 1;
+            if (w.claim.compare_exchange_strong(expect, cur, std::memory_order_acq_rel)) {
+                w.seen_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+                w.rc = fn_(ctx_, g);
+                w.at_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+                w.done.store(cur, std::memory_order_release);
+            }   // else: the caller ran this one (or a later one) itself; its words are the caller's to write
             idle_since = std::chrono::steady_clock::now();
         }
     }
@@ -188,8 +218,9 @@ private:
             MC_CPU_RELAX();
     }
 
-    std::chrono::nanoseconds linger_;
+    std::chrono::nanoseconds linger_, steal_after_;
     bool yield_;
+    uint64_t stolen_ = 0;
     std::vector<std::unique_ptr<Worker>> workers_;
     std::atomic<bool> quit_{false};
     JobFn fn_ = nullptr;

@@ -81,7 +81,9 @@ int main()
     {
         struct Ctx { std::atomic<int> calls{0}; std::thread::id ids[8]; int inited[8]; } ctx;
         memset(ctx.inited, 0, sizeof ctx.inited);
-        LaunchCrew crew(8, std::chrono::milliseconds(2), [](void *c, int g) { static_cast<Ctx *>(c)->inited[g] = g + 1; }, &ctx);
+        // steal_after = 10 s: the caller never takes a job over in this block, so "each on its own thread" can be asserted
+        LaunchCrew crew(8, std::chrono::milliseconds(2), [](void *c, int g) { static_cast<Ctx *>(c)->inited[g] = g + 1; }, &ctx,
+                        std::chrono::seconds(10));
         int rc[8];
         int64_t at[8];
         const auto job = [](void *c, int g) -> int {
@@ -129,6 +131,47 @@ int main()
         int rc[3] = {-1, -1, -1};
         crew.run_all([](void *, int g) { return g; }, nullptr, rc);
         EXPECT(rc[0] == 0 && rc[1] == 1 && rc[2] == 2, "linger 0: a call on parked workers completes");
+    }
+    // ---- late workers: the caller claims their jobs (every job still runs exactly once) -------------------------------------
+    {
+        struct Ctx { std::atomic<int> calls{0}; std::atomic<int> per[4]; std::atomic<int> on_caller{0}; std::thread::id caller; } ctx;
+        for (auto &x : ctx.per) x.store(0);
+        ctx.caller = std::this_thread::get_id();
+        const auto job = [](void *c, int g) -> int {
+            Ctx &x = *static_cast<Ctx *>(c);
+            x.calls.fetch_add(1), x.per[g].fetch_add(1);
+            if (std::this_thread::get_id() == x.caller) x.on_caller.fetch_add(1);
+            return 7 * g;
+        };
+        int rc[4];
+        {
+            // parked workers (linger 0) and steal_after 0: a worker needs a futex wake-up, the caller needs one compare-exchange
+            LaunchCrew crew(4, std::chrono::nanoseconds(0), nullptr, nullptr, std::chrono::nanoseconds(0));
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            bool statuses = true;
+            for (int i = 0; i < 200; ++i) {
+                crew.run_all(job, &ctx, rc);
+                for (int g = 0; g < 4; ++g) statuses = statuses && rc[g] == 7 * g;
+                if (i % 20 == 0) std::this_thread::sleep_for(std::chrono::milliseconds(2));
+            }
+            bool once = ctx.calls.load() == 4 * 200;
+            for (auto &x : ctx.per) once = once && x.load() == 200;
+            EXPECT(once && statuses, "parked workers, steal_after 0: 200 calls x 4 jobs, every job ran exactly once, statuses in their slots");
+            EXPECT(crew.stolen() > 0 && (int)crew.stolen() == ctx.on_caller.load(), "... some of them on the calling thread, and stolen() counts exactly those");
+            printf("   %d of 800 jobs ran on the caller\n", ctx.on_caller.load());
+        }
+        {
+            // spinning workers and a steal_after of about one hand-off: worker and caller race for every job
+            for (auto &x : ctx.per) x.store(0);
+            ctx.calls.store(0), ctx.on_caller.store(0);
+            LaunchCrew crew(4, std::chrono::milliseconds(50), nullptr, nullptr, std::chrono::nanoseconds(400));
+            for (int i = 0; i < 20000; ++i)
+                crew.run_all(job, &ctx, rc);
+            bool once = ctx.calls.load() == 4 * 20000;
+            for (auto &x : ctx.per) once = once && x.load() == 20000;
+            EXPECT(once, "spinning workers racing the caller for 20 000 x 4 jobs: every job ran exactly once");
+            printf("   %d of 80000 jobs ran on the caller\n", ctx.on_caller.load());
+        }
     }
     if (failures) {
         printf("%d check(s) FAILED\n", failures);

@@ -116,6 +116,23 @@ def test_multi_gpu_host_control_flow_without_a_gpu(tmp_path):
     assert out.returncode == 0 and "all checks passed" in out.stdout and "FAILED" not in out.stdout, out.stdout + out.stderr
 
 
+def test_multi_gpu_host_control_flow_is_race_free_under_tsan(tmp_path):
+    """The same program under ThreadSanitizer: the crew's hand-off words, the claim protocol by which the calling thread takes
+    over the job of a late worker (round 4) and the parked-worker wake-up are data-race free.  Sanitizers run on the CPU build
+    only (GPU sanitizers are not available on the pool)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "multi_host_check_tsan"
+    build = subprocess.run(["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-pthread", "-I", os.path.join(root, "montecarlocuda_amd", "csrc"),
+                            os.path.join(root, "tests", "cpp", "multi_host_check.cpp"), "-o", str(exe)], capture_output=True, text=True)
+    if build.returncode != 0 and "tsan" in (build.stderr or "").lower():
+        pytest.skip("libtsan is not installed")
+    assert build.returncode == 0, build.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "all checks passed" in out.stdout and "ThreadSanitizer" not in out.stderr, out.stdout[-3000:] + out.stderr[-3000:]
+
+
 def test_pmc_stamp_covers_the_launch(tmp_path):
     """The stamp that decides `traffic_stale` (bench.launch_stamp) covers what a launch IS: the device code object (the
     .hip_fatbin section of the built library), the launch-shape rules (csrc/mc_launch_shape.hpp: grid scales, kernel-family

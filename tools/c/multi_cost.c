@@ -85,8 +85,12 @@ int main(int argc, char **argv)
             mc_multi_destroy(m);
         }
     }
-    /* fan-out over 8 "devices" */
-    for (int threads = 0; threads < 2; ++threads) {
+    /* fan-out over 8 "devices", pinned-slot read-back (the product's default; rounds up to r04's first log measured this
+     * section with MC_MULTI_READBACK=copy still set by the loop above: every call then ends in 8 copies + 8 synchronizes,
+     * and the launches that follow a synchronize cost 2-4 x as much host time each) and, for comparison, the copy form */
+    for (int pass = 0; pass < 4; ++pass) {
+        const int threads = pass & 1, copy = pass >> 1;
+        if (copy) setenv("MC_MULTI_READBACK", "copy", 1); else unsetenv("MC_MULTI_READBACK");
         if (threads) unsetenv("MC_MULTI_THREADS"); else setenv("MC_MULTI_THREADS", "0", 1);
         const int dev8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         mc_multi *m;
@@ -100,8 +104,8 @@ int main(int argc, char **argv)
             if (i >= 0) wall[i] = now_us() - t0, fan[i] = mc_multi_last_fanout_us(m);
         }
         qsort(fan, REPS, sizeof *fan, cmp);
-        printf("fan-out over 8 contexts, %-28s call entry -> last launch enqueued: median %6.2f us  (min %5.2f, max %6.2f)   call wall median %8.1f us   [%d launcher threads]\n",
-               threads ? "one launcher thread each:" : "serial (MC_MULTI_THREADS=0):", fan[REPS / 2], fan[0], fan[REPS - 1], median(wall), mc_multi_launcher_threads(m));
+        printf("fan-out over 8 contexts, %-13s %-28s call entry -> last launch enqueued: median %6.2f us  (min %5.2f, max %6.2f)   call wall median %8.1f us   [%d launcher threads]\n",
+               copy ? "copies + sync," : "pinned slots,", threads ? "one launcher thread each:" : "serial (MC_MULTI_THREADS=0):", fan[REPS / 2], fan[0], fan[REPS - 1], median(wall), mc_multi_launcher_threads(m));
         mc_multi_destroy(m);
     }
     return 0;
