@@ -617,6 +617,10 @@ def main():
         eng.profile(0)
         if ex_samples:
             exclusive = (ex_samples, ex_ms / ex_samples * 1e-3)
+    # the shape the workload's OWN kernel was just launched with -- read here, before the fp64 side measurement and the strong
+    # rows put other kernels (other grids) on this context: read at the end, the default run compared the committed fp32 grid
+    # (2048 workgroups) with the fp64 side kernel's (3072) and called fresh counters stale
+    live_grid = eng.last_launch()[0] if exclusive else None
 
     # BASELINE.json's metric names both precisions: the same step in fp64, measured after (and
     # outside) the headline region, reported as a side figure.
@@ -692,7 +696,6 @@ def main():
         # the committed counts describe launches of one device code object and one launch shape: stale once either changes
         # (launch_stamp), or when the grid this run launched differs from the grid the PMC passes ran
         stamp = launch_stamp()
-        live_grid = eng.last_launch()[0] if exclusive else None
         grid_mismatch = bool(committed) and live_grid is not None and committed.get("grid_workgroups") not in (None, live_grid)
         traffic_stale = bool(committed) and (committed.get("launch_stamp") != stamp["stamp"] or grid_mismatch)
         out = {

@@ -59,6 +59,16 @@ def test_bench_contract_single_gpu():
     else:
         assert "issue_model_withheld" in r
     assert r["grid_workgroups"] == 2048 and len(r["launch_stamp"]) == 16
+    # counters collected from THIS build at THIS grid must not be called stale (round 4: the grid used to be read after the
+    # fp64 side run and the strong rows, i.e. from another kernel's launch, and fresh counters were flagged)
+    sys.path.insert(0, ROOT)
+    import bench
+    committed = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("vanilla_f32", {})
+    if committed.get("launch_stamp") == bench.launch_stamp()["stamp"] and committed.get("grid_workgroups") == 2048:
+        assert r["traffic_stale"] is False and r["pmc_grid_workgroups"] == 2048
+        model = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json"))).get("vanilla_f32", {})
+        if model.get("launch_stamp") == committed["launch_stamp"] and (model.get("cross_check_ok") or model.get("rescaled_to_counters")):
+            assert "issue_frac" in r
     c = d["cpu_baseline"]
     assert c["cores"] == 1 and c["kind"] in ("reference", "port") and c["value"] > 1e6
     assert abs(d["fp64"]["price"] - BS) < 0.05
