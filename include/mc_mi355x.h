@@ -109,7 +109,10 @@ typedef struct mc_context mc_context;
 
 int mc_device_count(void);
 /* Create the per-GPU context (replaces dp/MonteCarloKernel.cu:296 MonteCarlo_init).
- * blocks = simulation grid size; 0 picks the default (8 workgroups of 256 per CU). */
+ * blocks = simulation grid size; 0 picks the default (8 workgroups of 256 per CU).
+ * Current device: every call that takes a context makes that context's device the calling thread's current HIP device
+ * (hipSetDevice) and leaves it so -- a thread that also drives other devices through HIP re-selects its own afterwards.
+ * (libmc_multi, which visits several devices per call, puts the caller's device back itself: mc_multi.h.) */
 int mc_context_create(int device, int blocks, mc_context **out);
 /* Replaces dp/MonteCarloKernel.cu:344 MonteCarlo_closing. */
 void mc_context_destroy(mc_context *ctx);

@@ -78,6 +78,7 @@ int mc_multi_set_reduce(mc_multi *m, int mode);
  * the last mc_multi_*_run_* call until the LAST device's launch had been enqueued.  One calling thread per handle. */
 int mc_multi_launcher_threads(const mc_multi *m);
 double mc_multi_last_fanout_us(const mc_multi *m);
+/* The calling thread's current HIP device is unchanged by mc_multi_create / _destroy / _*_run_* (restored on the way out). */
 /* Text of the last failure of an mc_multi_* call on this thread ("" if none). */
 const char *mc_multi_last_error(void);
 /* |RCCL sum - host sum| / |host sum| of the last call's `sum` (0 when the host did the reduction) */

@@ -85,10 +85,22 @@ struct mc_multi {
     bool trace = false;                        // MC_MULTI_TRACE=1: one stderr line per call with every device's hand-off and enqueue time
 };
 
+// The calling thread's current HIP device is the caller's business: every entry point that visits the handle's devices
+// (creation, destruction, a sharded run -- serially, or when the caller takes over a late launcher thread's job) puts it
+// back on the way out.  The launcher threads have their own current device and never touch the caller's.
+struct CallerDevice {
+    int prev = -1;
+    CallerDevice() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~CallerDevice() { if (prev >= 0) (void)hipSetDevice(prev); }
+    CallerDevice(const CallerDevice &) = delete;
+    CallerDevice &operator=(const CallerDevice &) = delete;
+};
+
 extern "C" void mc_multi_destroy(mc_multi *m)
 {
     if (!m)
         return;
+    CallerDevice keep;
     m->crew.reset();   // joins the launcher threads: none of them is inside a launch after this
     for (size_t g = 0; g < m->ctx.size(); ++g) {
         (void)hipSetDevice(m->devices[g]);
@@ -135,6 +147,7 @@ extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc
     if (!out)
         return fail(MC_ERR_INVALID, "mc_multi_create: out is NULL");
     *out = nullptr;
+    CallerDevice keep;
     const int visible = mc_device_count();
     if (visible <= 0)
         return fail(MC_ERR_NO_DEVICE, "no HIP device visible (the HIP engine has no CPU fallback)");
@@ -304,6 +317,7 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     if (!out) return fail(MC_ERR_INVALID, "NULL output pointer");
     if (n == 0) return fail(MC_ERR_INVALID, "n_paths == 0");
     const int G = (int)m->devices.size();
+    CallerDevice keep;   // declared before InFlight: the drain of a failed call runs first, then the device goes back
     if (m->reduce == MC_REDUCE_RCCL)
         if (int rc = ensure_comms(m)) return rc;
     const auto wall0 = std::chrono::steady_clock::now();
