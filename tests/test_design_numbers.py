@@ -15,6 +15,10 @@ def test_design_md_is_short_and_its_figures_are_in_the_files_it_cites():
     r = subprocess.run([sys.executable, TOOL], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert " 0 not found" in r.stdout
+    # the other two documents that quote measurements with their source
+    for doc in ("README.md", "INTEGRATION.md"):
+        r = subprocess.run([sys.executable, TOOL, os.path.join(ROOT, doc)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, doc + "\n" + r.stdout[-4000:] + r.stderr[-2000:]
 
 
 def test_checker_finds_a_stale_figure_and_a_missing_file(tmp_path):
