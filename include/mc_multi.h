@@ -71,7 +71,7 @@ int mc_multi_set_reduce(mc_multi *m, int mode);
  * call's whole duration) after its last job and then sleeps, so back-to-back calls pay no wake-up and an idle handle uses no core.
  * A job whose worker has not taken it 15 us after the hand-off (still waking up, or descheduled) is run by the calling thread.
  * What the threads buy is measured with timing OFF (mc_multi_set_timing(m, 0): pinned-slot read-back, what the legacy
- * symbols use) -- eight launches enqueued in 7.7 us instead of 24.3; with timing on, every call ends in a copy and a
+ * symbols use) -- eight launches enqueued in 8.8 us instead of 22.2; with timing on, every call ends in a copy and a
  * synchronize per device, and launches that follow a synchronize serialise inside the HIP runtime whatever thread
  * issues them (profiles/r04_multi_fixed_cost_and_fanout_2.log).
  * mc_multi_launcher_threads: how many the handle runs (0 = serial).  mc_multi_last_fanout_us: host time from the entry of

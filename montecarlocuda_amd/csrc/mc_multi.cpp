@@ -173,7 +173,7 @@ extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc
         return rc;
     }
     // Launcher threads: device g's launches are issued by thread g (its own hipSetDevice, arm and launch), started through
-    // one flag word each, so that device G-1 starts with device 0 instead of (G-1) x ~4 us later.  A worker spins for
+    // one call-number word the crew watches, so that device G-1 starts with device 0 instead of (G-1) x ~4 us later.  A worker spins for
     // MC_MULTI_LINGER_US (default 100 000: longer than any BASELINE shard lasts -- C4 x 10 is 34 ms per device -- because the
     // time between two hand-offs is the whole previous call) after its last job and then sleeps: back-to-back calls never pay a wake-up, an
     // idle handle burns no core.
@@ -300,7 +300,7 @@ struct InFlight {
 // Fan-out.  G == 1 (or MC_MULTI_THREADS=0): the calling thread enqueues every device's launch itself, one after the
 // other -- an asynchronous launch costs it ~4.2 us (profiles/r02_launch_cost.log), so device 7 of 8 started ~30 us after
 // device 0: 3 % of C5's 1 ms shard.  G > 1: every device has its own launcher thread (LaunchCrew), the calling thread
-// bumps G flag words and the launches are issued concurrently; `last_fanout_us` = call entry -> the last device's launch
+// bumps the crew's call number and the launches are issued concurrently; `last_fanout_us` = call entry -> the last device's launch
 // enqueued (tools/c/multi_cost.c prints it).
 //
 // Read-back.  With timing off (what the legacy symbols and the benchmarks use) nothing is copied and nothing sleeps:

@@ -5,7 +5,7 @@
 //                 which the caller's `settle` (drain every stream the call touched) runs once and the words are looked
 //                 at one last time -- the way out when a device faulted and will never write
 //   LaunchCrew    one launcher thread per device: the calling thread hands every device's launch to that device's own
-//                 thread through one flag word each, so that all devices start together instead of ~4 us apart
+//                 thread through ONE call-number word the whole crew watches, so that all devices start together instead of ~4 us apart
 //
 // Nothing here exists in the reference (single device, default stream, synchronous: dp/MonteCarloKernel.cu:296-532).
 #pragma once
@@ -63,10 +63,10 @@ static bool poll_slots(const volatile double *const *slots, int n, std::chrono::
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One launcher thread per device.  A call publishes its job (a callable taking the device index) and bumps every
-// worker's `go` word; worker g runs job(g) on its own thread -- its own hipSetDevice, arm and launch -- stores the
+// One launcher thread per device.  A call publishes its job (a callable taking the device index) and bumps the crew's
+// ONE call-number word `go_`; worker g runs job(g) on its own thread -- its own hipSetDevice, arm and launch -- stores the
 // job's status and bumps `done`.  The caller spins on the `done` words.  Hand-off is one cache line each way, no
-// system call: a worker SPINS on its word while calls keep coming (for `linger` after its last job) and parks on a
+// system call: a worker SPINS on that word while calls keep coming (for `linger` after its last job) and parks on a
 // condition variable only when the handle has been idle for longer than that, so a sequence of calls never pays a
 // wake-up and an idle handle burns no core.  When the process may run on fewer CPUs than the crew has threads (+ the
 // caller), every spin iteration yields the CPU instead (sched_yield): a spinning thread that sits on the core the
@@ -132,8 +132,8 @@ public:
     {
         fn_ = fn, ctx_ = ctx, t0_ = t0;
         const uint32_t seq = ++seq_;
+        go_.store(seq, std::memory_order_seq_cst);             // ONE word for the whole crew: every worker sees the call at once
         for (auto &w : workers_) {
-            w->go.store(seq, std::memory_order_seq_cst);
             if (w->parked.load(std::memory_order_seq_cst)) {   // Dekker with the worker's (parked = true; read go)
                 std::lock_guard<std::mutex> lk(w->mu);
                 w->cv.notify_one();
@@ -166,7 +166,6 @@ public:
 
 private:
     struct alignas(128) Worker {
-        std::atomic<uint32_t> go{0};
         alignas(128) std::atomic<uint32_t> claim{0};   // the last call whose job somebody took: worker g, or the caller when g was late
         alignas(128) std::atomic<uint32_t> done{0};
         int rc = 0;
@@ -184,13 +183,13 @@ private:
         for (;;) {
             uint32_t cur;
             uint32_t spin = 0;
-            while ((cur = w.go.load(std::memory_order_acquire)) == seen) {
+            while ((cur = go_.load(std::memory_order_acquire)) == seen) {
                 if (quit_.load(std::memory_order_relaxed))
                     return;
                 if ((++spin & 1023u) == 0 && std::chrono::steady_clock::now() - idle_since > linger_) {
                     std::unique_lock<std::mutex> lk(w.mu);
                     w.parked.store(true, std::memory_order_seq_cst);
-                    while (w.go.load(std::memory_order_seq_cst) == seen && !quit_.load(std::memory_order_seq_cst))
+                    while (go_.load(std::memory_order_seq_cst) == seen && !quit_.load(std::memory_order_seq_cst))
                         w.cv.wait(lk);
                     w.parked.store(false, std::memory_order_seq_cst);
                     idle_since = std::chrono::steady_clock::now();
@@ -218,7 +217,11 @@ private:
             MC_CPU_RELAX();
     }
 
-    std::chrono::nanoseconds linger_, steal_after_;
+    // the call number, bumped once per run_all: all workers spin on this one (read-shared) line, so the last of them sees a
+    // call as early as the first -- with one word per worker the caller's G stores put worker 7 about 1.2 us behind worker 0
+    alignas(128) std::atomic<uint32_t> go_{0};
+    alignas(128) std::chrono::nanoseconds linger_;
+    std::chrono::nanoseconds steal_after_;
     bool yield_;
     uint64_t stolen_ = 0;
     std::vector<std::unique_ptr<Worker>> workers_;
