@@ -188,3 +188,42 @@ def test_pmc_stamp_covers_the_launch(tmp_path):
     committed = {"launch_stamp": base["stamp"], "grid_workgroups": 2048}
     stale = lambda c, stamp, grid: c.get("launch_stamp") != stamp or c.get("grid_workgroups") not in (None, grid)   # noqa: E731
     assert not stale(committed, base["stamp"], 2048) and stale(committed, shape["stamp"], 2048) and stale(committed, base["stamp"], 3072)
+
+
+def test_committed_issue_model_and_pmc_counts_describe_one_build():
+    """profiles/issue_model.json (tools/issue_model.py) and profiles/pmc_traffic.json (tools/summarize_pmc.py) are read by
+    bench.py as a pair: both must carry the same launch stamp for every workload, every ceiling must lie at or below the
+    mixed-stream estimate, and the histogram's VALU count per path must agree with the counters' hot-loop slope within 1 % --
+    or the model must say that it took its counts from the counters instead (the CVA date loops).  Whether the pair also
+    describes the CURRENT build is bench.py's run-time check (traffic_stale); here a mismatch is only reported, because the
+    counters can be re-collected on a GPU box alone."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    model = json.load(open(os.path.join(root, "profiles", "issue_model.json")))
+    pmc = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    workloads = {"vanilla_f32", "vanilla_f64", "vanilla_f64_n32", "basket4_f32", "basket16_f32", "basket16_f64", "basket16_f64_n32",
+                 "cva256_f64", "cva256_f64_n32", "cva256_f32"}
+    assert workloads <= set(model) and workloads <= set(pmc)
+    stamps = set()
+    for w in sorted(workloads):
+        m, p = model[w], pmc[w]
+        assert m["launch_stamp"] == p["launch_stamp"], w
+        stamps.add(m["launch_stamp"])
+        assert 0 < m["ceiling_us"] <= m["typical_us"], w
+        assert m["min_cycles_per_path"] <= m["typical_cycles_per_path"], w
+        assert m.get("cross_check_ok") or m.get("rescaled_to_counters"), w
+        slope = p["hot_loop_slope"]["valu_wave_insts_per_path"] * 64.0
+        if m.get("cross_check_ok"):
+            assert abs(slope / m["model_per_path"]["valu"] - 1.0) <= 0.01, w
+        else:   # counts taken from the counters: the model's VALU per path IS the slope
+            assert abs(m["valu_per_path"] / slope - 1.0) <= 1e-6 and abs(m["pmc_vs_model"] - 1.0) <= 0.05, w
+        assert p["grid_workgroups"] in (2048, 3072, 6144, 12288) and p["group_size"] == 256, w
+    assert len(stamps) == 1
+    sys.path.insert(0, root)
+    import bench
+    live = bench.launch_stamp(root)["stamp"]
+    if live not in stamps:
+        print("NOTE: the committed counters describe another build than the one in the tree (bench.py will flag traffic_stale): "
+              "re-run tools/collect_pmc_all.sh and tools/issue_model.py on a GPU box")
