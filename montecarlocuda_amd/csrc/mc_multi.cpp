@@ -10,7 +10,9 @@
 // themselves and the calling thread polls (run_sharded).  With G > 1 every device's launch is issued by that device's
 // own launcher thread (mc_multi_host.hpp: LaunchCrew), so the devices start together; the collective stays ONE grouped
 // call on the calling thread.  NOTE: the grouped all-reduce has only ever run with a communicator of ONE rank (one-GPU
-// test boxes; RCCL refuses a repeated device): the G > 1 collective is unexercised.
+// test boxes; RCCL refuses a repeated device): the G > 1 collective is unexercised.  The G > 1 CALL SEQUENCE of this file
+// (buffers, streams and communicators per rank, publish, cross-check) does run in the GPU suite, with three ranks on one
+// device against a test double of the six RCCL entry points (tests/cpp/rccl_mock.hip, MC_MULTI_ALLOW_REPEATED_DEVICES=1).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -260,7 +262,10 @@ static int ensure_comms(mc_multi *m)
     if (!m->comm.empty())
         return MC_OK;
     const int G = (int)m->devices.size();
-    for (int a = 0; a < G; ++a)
+    // MC_MULTI_ALLOW_REPEATED_DEVICES=1 is for the test double of the collective (tests/cpp/rccl_mock.hip, preloaded in front
+    // of librccl.so), whose ranks may share a device; RCCL itself fails such a list in ncclCommInitAll
+    const char *rep = getenv("MC_MULTI_ALLOW_REPEATED_DEVICES");
+    for (int a = 0; a < G && !(rep && atoi(rep) != 0); ++a)
         for (int b = a + 1; b < G; ++b)
             if (m->devices[a] == m->devices[b])
                 return fail(MC_ERR_INVALID, "device %d is listed twice: RCCL needs distinct devices (MC_REDUCE_HOST accepts the list)",

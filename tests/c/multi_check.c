@@ -52,14 +52,21 @@ int main(void)
     const int d0 = 0, d000[3] = {0, 0, 0};
     CHECK(mc_multi_create(&d0, 1, 0, &m_one));
     CHECK(mc_multi_create(d000, 3, 0, &m_three));
-    CHECK(mc_multi_set_reduce(m_three, MC_REDUCE_HOST));
+    /* MC_MULTI_ALLOW_REPEATED_DEVICES=1 (with tests/cpp/rccl_mock.hip preloaded: a test double of the collective whose ranks
+     * may share a device): the three shards on device 0 go through the GROUPED all-reduce call sequence -- the G > 1 control
+     * flow that real RCCL cannot be given on a one-GPU box */
+    const char *rep = getenv("MC_MULTI_ALLOW_REPEATED_DEVICES");
+    const int mock_collective = rep && atoi(rep) != 0;
+    if (!mock_collective)
+        CHECK(mc_multi_set_reduce(m_three, MC_REDUCE_HOST));
     if (visible > 1)
         CHECK(mc_multi_create(NULL, 0, 0, &m_all));
-    printf("handles: {0} RCCL, {0,0,0} host reduce%s\n", m_all ? ", all devices RCCL" : "");
+    printf("handles: {0} RCCL, {0,0,0} %s%s\n", mock_collective ? "grouped all-reduce through the preloaded test double" : "host reduce",
+           m_all ? ", all devices RCCL" : "");
 
     const uint64_t seed = MC_DEFAULT_SEED;
     mc_multi *handles[3] = {m_one, m_three, m_all};
-    const char *names[3] = {"{0} rccl", "{0,0,0} host", "all rccl"};
+    const char *names[3] = {"{0} rccl", mock_collective ? "{0,0,0} mock collective" : "{0,0,0} host", "all rccl"};
     char label[128];
 
     /* market data: the reference drivers' (vanillaOpt.cu:22-26, cvaOpt.cu:22-34), BASELINE's 4-asset basket */
@@ -179,7 +186,7 @@ int main(void)
                 CHECK(mc_multi_cva_run_f64(m_three, &c64, seed, first + rep, cnt, &a));
                 CHECK(mc_multi_cva_run_f64(serial, &c64, seed, first + rep, cnt, &b));
                 same = same && a.sum == b.sum && a.sum2 == b.sum2 && a.n == b.n;
-                if (rep % 100 == 99) {   /* let the workers park (linger 2 ms), then call again */
+                if (rep % 100 == 99) {   /* let the workers park (MC_MULTI_LINGER_US=2000 from the test wrapper), then call again */
                     struct timespec ts = {0, 5000000};
                     nanosleep(&ts, NULL);
                 }
@@ -220,8 +227,12 @@ int main(void)
     const int d00[2] = {0, 0};
     CHECK(mc_multi_create(d00, 2, 0, &dup));
     CHECK(mc_multi_set_reduce(dup, MC_REDUCE_RCCL));
-    if (mc_multi_vanilla_run_f64(dup, &v64, seed, 0, 1000, &got) == MC_OK) ++failures;
-    printf("error text for a repeated device under RCCL: %s\n", mc_multi_last_error());
+    if (!mock_collective) {
+        if (mc_multi_vanilla_run_f64(dup, &v64, seed, 0, 1000, &got) == MC_OK) ++failures;
+        printf("error text for a repeated device under RCCL: %s\n", mc_multi_last_error());
+    } else {   /* the duplicate check is lifted for the test double: the call goes through */
+        if (mc_multi_vanilla_run_f64(dup, &v64, seed, 0, 1000, &got) != MC_OK || got.n != 1000) ++failures;
+    }
     mc_multi_destroy(dup);
 
     mc_multi_destroy(m_one);

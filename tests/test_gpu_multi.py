@@ -25,13 +25,38 @@ def build_check(tmp_path):
 
 def test_c_multi_device_path_matches_single_device(tmp_path):
     exe = build_check(tmp_path)
-    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900)
+    # linger 2 ms (the default is 100 ms): the program's 5 ms pauses then let the launcher threads park, so that the wake-up
+    # path (and the caller taking over a job whose worker is still waking up) is exercised as well as the spinning one
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=dict(os.environ, MC_MULTI_LINGER_US="2000"))
     print(out.stdout[-6000:])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "all checks passed" in out.stdout and "MISMATCH" not in out.stdout
     assert "{0} rccl" in out.stdout and "{0,0,0} host" in out.stdout
     if int(re.search(r"visible devices: (\d+)", out.stdout).group(1)) > 1:
         assert "all rccl" in out.stdout
+
+
+def test_grouped_allreduce_call_sequence_with_three_ranks_through_a_test_double(tmp_path):
+    """The G > 1 control flow of run_sharded's collective branch -- G calls of ncclAllReduce inside one group, rank g's own send /
+    receive buffers, stream and communicator, the publish of device 0's reduced triple, the cross-check against the host sum --
+    executed with THREE ranks on the one GPU.  Real RCCL refuses a repeated device, so a test double of its six entry points
+    (tests/cpp/rccl_mock.hip: event-ordered sum of the ranks' buffers in rank order) is preloaded in front of librccl.so and
+    MC_MULTI_ALLOW_REPEATED_DEVICES=1 lifts the library's own duplicate check.  This proves the call sequence and the indexing,
+    NOT RCCL or xGMI: the multi-rank collective itself stays unexercised on one-GPU boxes."""
+    mock = tmp_path / "librccl_mock.so"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC",
+                           os.path.join(ROOT, "tests", "cpp", "rccl_mock.hip"), "-o", str(mock)])
+    exe = build_check(tmp_path)
+    env = dict(os.environ, LD_PRELOAD=str(mock), MC_MULTI_ALLOW_REPEATED_DEVICES="1", RCCL_MOCK_VERBOSE="1", MC_MULTI_LINGER_US="2000")
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=env)
+    print(out.stdout[-6000:])
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "all checks passed" in out.stdout and "MISMATCH" not in out.stdout
+    assert "{0,0,0} mock collective" in out.stdout and "grouped all-reduce through the preloaded test double" in out.stdout
+    assert "communicator set of 3 ranks" in out.stderr          # the double, not RCCL, served the three-rank handle
+    groups = re.findall(r"rccl_mock: (\d+) grouped all-reduces of (\d+) calls in all", out.stderr)
+    # hundreds of grouped calls, and more all-reduce calls than groups: groups of three went through (the {0} handle's are of one)
+    assert groups and max(int(g) for g, _ in groups) > 100 and max(int(c) - int(g) for g, c in groups) > 200, out.stderr[-2000:]
 
 
 @pytest.mark.parametrize("X", ["f64", "f32"])
