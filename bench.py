@@ -25,7 +25,15 @@ and timed_region_s are the MEDIAN region's (min / max / all regions reported bes
 over RCCL the barrier that closes a region is the all-reduce of its last bucket of triples (an
 all-reduce is a barrier; --closing barrier adds a separate dist.barrier()).
 
-Reported besides the contract fields:
+OUTPUT.  stdout carries ONE line: a JSON object of at most 4096 bytes -- the contract fields, `config`, `roofline`,
+`cpu_baseline`, `fp64`, `region_ms_per_step`, `strong_summary` and, at N > 1, the roster of ranks (`ranks`) -- built by
+compact_line() from the full record.  The full record (every strong row, every line of the C library's child process,
+host-side timings, the prose that explains each field) goes to --detail-file (default bench_detail.json next to this
+script; the line names it as `detail`), never to stdout or stderr.  (Round 4's line had grown to 32 KB and the driver
+could not parse it.)  --detail full adds the rows that --detail brief (default) leaves out: the x10 sizes on fp32 normals,
+shard 0 of 2 and of 4, the -O0 build of the reference's CPU path.
+
+In the full record, besides the contract fields:
   roofline      dominant kernel (the simulation kernel): achieved = algorithmic flop per launch (SURVEY 8d:
                 15.5 flop/path vanilla, n^2+12.5n+6 basket, 60/path-step CVA) / its launch duration, measured live
                 with HIP events bound to the dispatch over 50 launches one at a time right after the timed region
@@ -148,7 +156,7 @@ def kernel_name(prod, X, inputs):
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md; fp64 vector = half)
 
 
-def cpu_baseline(prod, X, inputs, seconds):
+def cpu_baseline(prod, X, inputs, seconds, full=False):
     """Time the reference's CPU path on ONE host core for about `seconds` seconds."""
     from oracle import pyoracle as po   # checker / baseline only
     po.build()
@@ -168,10 +176,11 @@ def cpu_baseline(prod, X, inputs, seconds):
     n = int(min(2 ** 31 - 1, max(n, n * seconds / max(dt, 1e-3))))
     t0 = time.perf_counter(); run(n); dt = time.perf_counter() - t0
     out = {"value": n * per_unit / dt, "unit": unit, "cores": 1, "kind": "reference" if use_ref else "port",
+           "sample_short": f"{n} paths of the same workload in {dt:.1f} s, 1 thread, gcc -O2",
            "sample": f"{n} paths of the same workload in {dt:.1f} s, single thread (the reference is single-threaded: "
                      f"MonteCarloHost.c:185-229), gcc -O2 -ffp-contract=off",
            "host_cores_available": len(os.sched_getaffinity(0)), "host_cpus_granted": cpus_granted()}
-    if prod == "vanilla" and po.ref_available(X, 3, "_O0"):
+    if full and prod == "vanilla" and po.ref_available(X, 3, "_O0"):
         # footnote: the reference's own Makefile compiles the host file without -O (Makefile:157,252-253)
         n0 = max(1000, int(n * min(1.0, 3.0 / max(dt, 1e-3))))
         t0 = time.perf_counter(); po.Ref(X, 3, "_O0").vanilla(inputs, n0, 12345); dt0 = time.perf_counter() - t0
@@ -221,7 +230,7 @@ def cpu_all_cores(seconds=2.0):
             "note": "threads = OpenMP's default capped by the container's cgroup CPU quota (MC_HOST_THREADS overrides)"}
 
 
-def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, backend, barrier, reps, preheat_ms=300.0):
+def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, backend, barrier, reps, preheat_ms=300.0, full=False):
     """BASELINE.json's strong-scaling target, measured on this N: ONE pricing call of configs[3] (C4: basket, 16 assets,
     1e9 paths, fp64) and of configs[4] (C5: CVA, 256 dates x 1e7 paths, fp64) -- and of 10x those sizes, and of
     all four once more on fp32 normals (the reference's own dp arithmetic: shorter kernels, fixed costs weigh more) --
@@ -244,6 +253,8 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
              ("C5", "cva", CVA, 10 ** 7, c5d, "native", True), ("C5x10", "cva", CVA, 10 ** 8, "the same, 1e8 paths", "native", False),
              ("C4_n32", "basket", c4, 10 ** 9, c4d + n32, "f32", True), ("C4x10_n32", "basket", c4, 10 ** 10, "the same, 1e10 paths", "f32", False),
              ("C5_n32", "cva", CVA, 10 ** 7, c5d + n32, "f32", True), ("C5x10_n32", "cva", CVA, 10 ** 8, "the same, 1e8 paths", "f32", False)]
+    if not full:     # --detail brief: the x10 sizes on fp32 normals only under --detail full
+        specs = [sp for sp in specs if sp[0] not in ("C4x10_n32", "C5x10_n32")]
     out = torch.zeros(3, dtype=torch.float64, device="cuda")
     scratch = torch.zeros(3, dtype=torch.float64, device="cuda")
     pinned = torch.zeros(3, dtype=torch.float64).pin_memory()
@@ -253,7 +264,7 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
     shard_rows = []
     runs = [(spec, 1) for spec in specs]
     if world == 1:
-        runs += [(spec, S) for S in (2, 4, 8) for spec in specs]
+        runs += [(spec, S) for S in ((2, 4, 8) if full else (8,)) for spec in specs]
     t_full, t_full_cold = {}, {}
 
     def one_call(prod, struct, first, count):
@@ -343,7 +354,7 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
                     "own N = 1, 2, 4, 8 lines"}
 
 
-def c_multi_block(max_seconds):
+def c_multi_block(max_seconds, full=False):
     """The same strong-scaling rows through the C library alone: drivers/multiBench (plain C, libmc_multi.so: ONE
     process drives G = 1, 2, 4, 8 ... of the visible GPUs, shards + one direct RCCL all-reduce).  Run as a child
     process with a time limit so that nothing it does can disturb the headline measurement above."""
@@ -352,7 +363,8 @@ def c_multi_block(max_seconds):
     if not os.path.exists(exe):
         return {"error": "drivers/multiBench not built (make -C drivers)"}
     try:
-        out = subprocess.run([exe, "--reps", "10"], capture_output=True, text=True, timeout=max_seconds)
+        cmd = [exe, "--reps", "10"] + ([] if full else ["--brief"])
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=max_seconds)
     except subprocess.TimeoutExpired:
         return {"error": f"drivers/multiBench exceeded {max_seconds} s"}
     rows = []
@@ -361,12 +373,126 @@ def c_multi_block(max_seconds):
             rows.append(json.loads(line))
         except ValueError:
             pass
-    res = {"command": "drivers/multiBench --reps 10", "rc": out.returncode, "rows": rows,
+    res = {"command": "drivers/" + " ".join(["multiBench"] + cmd[1:]), "rc": out.returncode, "rows": rows,
            "what": "one C process, libmc_multi.so: mc_shard_range + mc_*_launch_* per device + ONE ncclAllReduce(3, ncclDouble); "
                    "wall-clock first launch -> closed estimate"}
     if out.returncode != 0:
         res["error"] = (out.stderr or out.stdout)[-400:]
     return res
+
+
+LINE_LIMIT = 4096   # bytes of the ONE stdout line (the driver keeps an 8 KB tail of stdout: a longer line arrives headless)
+
+
+def _sig(x, n=6):
+    """Floats to n significant digits, recursively (the compact line only; the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _pick(d, *keys):
+    return {k: d[k] for k in keys if d and k in d and d[k] is not None}
+
+
+def strong_summary(detail):
+    """A few numbers per strong-scaling config out of the full record's rows.
+    N = 1: t1_ms = one call of the whole config on this GPU (wall, hot, median), t8_ms = shard 0 of 8 of it, eff8 / eff8_cold =
+    T(1) / (8 T(shard)) hot / cold -- the device side of the 8-GPU point, everything but the all-reduce between ranks; each as
+    [bench.py's torch path, the C library (drivers/multiBench, libmc_multi.so)].  `c_devices`: the C library over G > 1 of the
+    visible devices (real RCCL), [wall ms, efficiency vs its own G = 1, fan-out us].
+    N > 1: wall_ms = one call sharded over the N ranks, first launch -> all-reduced triple, max over ranks."""
+    strong = detail.get("strong") or {}
+    rows = {r["config"]: r for r in strong.get("rows", [])}
+    if not rows:
+        return None
+    if detail.get("n_gpus", 1) > 1:
+        return {c: _pick(r, "wall_ms_median", "paths_per_gpu", "value") for c, r in rows.items()}
+    shard = {(r["config"], r["shard_of"]): r for r in strong.get("shard_rows", [])}
+    crows_all = (detail.get("c_multi") or {}).get("rows", [])
+    crows = {r.get("config"): r for r in crows_all if r.get("devices") == 1 and "shard_of" not in r and "config" in r}
+    cshard = {(r.get("config"), r["shard_of"]): r for r in crows_all if "shard_of" in r}
+    out = {}
+    for c, r in rows.items():
+        s8, c1, c8 = shard.get((c, 8)), crows.get(c), cshard.get((c, 8))
+        e = {"t1_ms": [r["wall_ms_median"], c1["wall_ms_median"] if c1 else None]}
+        if s8 or c8:
+            e["t8_ms"] = [s8["wall_ms_median"] if s8 else None, c8["wall_ms_median"] if c8 else None]
+            e["eff8"] = [s8["device_side_efficiency"] if s8 else None, c8["device_side_efficiency"] if c8 else None]
+            cold = [(x or {}).get("cold", {}).get("device_side_efficiency") for x in (s8, c8)]
+            if any(v is not None for v in cold):
+                e["eff8_cold"] = cold
+        multi = {str(x["devices"]): [x["wall_ms_median"], x.get("strong_efficiency_vs_1"), x.get("fanout_us")]
+                 for x in crows_all if x.get("config") == c and x.get("devices", 1) > 1 and "shard_of" not in x}
+        if multi:
+            e["c_devices"] = multi
+        out[c] = e
+    return out
+
+
+def compact_line(detail, detail_name="bench_detail.json"):
+    """The ONE stdout line: contract fields + config + roofline + cpu_baseline + fp64 + strong_summary (+ roster), floats at
+    6 significant digits (value / ms_per_step / timed_region_s in full), at most LINE_LIMIT bytes.  Pure function of the
+    full record, so that a CPU test can bound its size from a recorded fixture (tests/test_bench_cli.py)."""
+    d = detail
+    line = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                              "vs_baseline", "dtype", "data") if k in d}
+    cfg = d.get("config", {})
+    line["config"] = _pick(cfg, "workload", "paths_per_gpu_per_step", "global_paths_per_step", "parallelism", "rng", "seed", "grid",
+                           "streams", "finish", "preheat_ms", "engine_settings", "detail")
+    line.update(_pick(d, "timed_region_s", "regions"))
+    body = _pick(d, "ms_per_step_min", "ms_per_step_max", "region_ms_per_step", "price", "confidence_95", "paths_priced",
+                 "price_error_vs_black_scholes")
+    r = d.get("roofline") or {}
+    roof = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "kernel", "flop_per_path", "avg_kernel_us",
+                 "kernel_samples", "issue_frac", "hbm_gbps", "launch_stamp", "grid_workgroups")
+    roof.setdefault("traffic", None)
+    if r.get("in_region"):
+        roof["in_region"] = _pick(r["in_region"], "avg_kernel_us", "kernel_samples", "concurrent_launches", "step_period_us")
+    if r.get("effective"):
+        roof["effective"] = _pick(r["effective"], "achieved", "frac")
+    if r.get("issue_model"):
+        roof["issue_model"] = _pick(r["issue_model"], "ceiling_us", "frac_effective", "valu_insts_per_path", "valu_busy_long_launch")
+    elif r.get("issue_model_withheld"):
+        roof["issue_model"] = "withheld: committed counters do not describe this build"
+    body["roofline"] = roof
+    if d.get("cpu_baseline"):
+        c = d["cpu_baseline"]
+        body["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind", "host_cpus_granted", "value_at_O0")
+        body["cpu_baseline"]["sample"] = c.get("sample_short") or str(c.get("sample", ""))[:80]
+    if d.get("cpu_all_cores"):
+        body["cpu_all_cores"] = _pick(d["cpu_all_cores"], "value", "unit", "cores")
+    if d.get("fp64"):
+        body["fp64"] = _pick(d["fp64"], "value", "unit", "steps", "ms_per_step", "price_error_vs_black_scholes")
+    ss = strong_summary(d)
+    if ss:
+        body["strong_summary"] = ss
+    body.update(_pick(d, "world_size", "backend", "rccl_version", "ranks", "devices_visible", "device"))
+    line.update(_sig(body))
+    line["detail"] = detail_name
+    # never above the limit: shed the least important parts first, and say so
+    dropped = []
+
+    def size():
+        return len(json.dumps(dict(line, dropped_for_size=dropped) if dropped else line))
+    for k in ("cpu_all_cores", "region_ms_per_step", "strong_summary.c_devices", "fp64", "strong_summary", "ranks"):
+        if size() <= LINE_LIMIT:
+            break
+        if k == "strong_summary.c_devices":
+            hit = [e.pop("c_devices", None) for e in (line.get("strong_summary") or {}).values() if isinstance(e, dict)]
+            if any(h is not None for h in hit):
+                dropped.append(k)
+        elif line.pop(k, None) is not None:
+            dropped.append(k)
+    if dropped:
+        line["dropped_for_size"] = dropped
+    if len(json.dumps(line)) > LINE_LIMIT:
+        raise RuntimeError(f"bench line is {len(json.dumps(line))} bytes (> {LINE_LIMIT}) even without {dropped}")
+    return line
 
 
 def main():
@@ -380,7 +506,12 @@ def main():
                          "20-step region is 1 ms, one sample of it moves by +-4 %% between runs")
     ap.add_argument("--workload", default="vanilla_f32")
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--detail", default="brief", choices=["brief", "full"],
+                    help="brief (default): strong rows C4, C5, their 10x sizes, C4 / C5 on fp32 normals, shard 0 of 8 -- the driver's run "
+                         "stays under a minute.  full: also the 10x sizes on fp32 normals, shard 0 of 2 and of 4, the -O0 CPU build")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where rank 0 writes the full record (every row; the stdout line carries the summary and names this file)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU simulates `paths` per step. strong: `paths` per step in total, "
                          "rank g taking mc_shard_range(paths, g, N) of every step")
@@ -414,7 +545,7 @@ def main():
     ap.add_argument("--strong-preheat-ms", type=float, default=300.0,
                     help="device load before every strong-scaling row (this rank's own shard, back to back), so that T(1) and "
                          "T(shard) are both measured at the sustained clock; 0 = off")
-    ap.add_argument("--c-multi-seconds", type=int, default=240,
+    ap.add_argument("--c-multi-seconds", type=int, default=150,
                     help="N=1 only: time limit of the child process drivers/multiBench (the C library's own multi-GPU path over "
                          "1, 2, 4, 8 ... of the visible GPUs); 0 = skip")
     ap.add_argument("--poll", type=int, default=0,
@@ -453,6 +584,7 @@ def main():
         if "normals" in settings:
             e_.set_normals(settings["normals"])
     eng = engines[0]
+    eng_info = eng.info()
     prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
     if callable(inputs):
         inputs = inputs()
@@ -660,7 +792,14 @@ def main():
     strong = None
     if args.strong_reps > 0 and args.workload == "vanilla_f32":
         strong = strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, args.backend, barrier,
-                                      args.strong_reps, args.strong_preheat_ms)
+                                      args.strong_reps, args.strong_preheat_ms, full=args.detail == "full")
+
+    # who took part: one entry per rank -- local device index, its PCI bus id (hipDeviceGetPCIBusId through the C ABI), host
+    me = {"rank": rank, "device": local, "pci": mc.pci_bus_id(local), "host": os.uname().nodename, "pid": os.getpid()}
+    roster = [me]
+    if grouped and world > 1:
+        roster = [None] * world
+        dist.all_gather_object(roster, me)
 
     if rank == 0:
         tot = triples[W:].sum(dim=0).cpu().tolist()           # every step's triple is already all-reduced
@@ -780,17 +919,40 @@ def main():
         if strong:
             out["strong"] = strong
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(prod, X, inputs, args.cpu_seconds, full=args.detail == "full")
             if prod == "vanilla" and X == "f32":
-                extra = cpu_all_cores()
+                extra = cpu_all_cores(1.5)
                 if extra:
                     out["cpu_all_cores"] = extra
         if world == 1 and args.c_multi_seconds > 0 and args.workload == "vanilla_f32":
             for e in engines:       # the child process gets the GPU to itself
                 e.close()
             engines = []
-            out["c_multi"] = c_multi_block(args.c_multi_seconds)
-        print(json.dumps(out), flush=True)
+            out["c_multi"] = c_multi_block(args.c_multi_seconds, full=args.detail == "full")
+        # the participants ("did RCCL see N ranks?" must be answerable from the record)
+        out["world_size"] = dist.get_world_size() if grouped else 1
+        out["backend"] = (dist.get_backend() if grouped else "none (single process)")
+        if grouped and args.backend == "nccl":
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                out["rccl_version"] = None
+        if world > 1:
+            out["ranks"] = [{"rank": m_["rank"], "device": m_["device"], "pci": m_["pci"], "host": m_["host"]} for m_ in roster]
+            out["distinct_devices"] = len({(m_["host"], m_["pci"]) for m_ in roster})
+        else:
+            out["devices_visible"] = torch.cuda.device_count()
+            out["device"] = {"index": local, "pci": me["pci"], "name": eng_info["name"], "compute_units": eng_info["compute_units"]}
+        out["config"]["detail"] = args.detail
+        detail_name = os.path.relpath(args.detail_file, ROOT) if os.path.abspath(args.detail_file).startswith(ROOT + os.sep) else args.detail_file
+        line = compact_line(out, detail_name)
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail_file)), exist_ok=True)
+            with open(args.detail_file, "w") as f:
+                json.dump(dict(out, line=line), f, indent=1)
+        except OSError as e_:
+            line["detail"] = f"not written: {e_}"[:120]
+        print(json.dumps(line), flush=True)
     if grouped:
         barrier()
         dist.destroy_process_group()

@@ -21,8 +21,10 @@
  * Then, on the first device alone, shard 0 of G = 2, 4, 8 of every workload: the device side of the scaling curve,
  * measurable without the other devices ("shard_of" lines).
  *
- *   multiBench [--reps R] [--max-devices G] [--small] [--events] [--no-cold] [--no-n32] [--preheat-ms MS]
- *              (--small: 1/100 of the sizes and no pre-heat, for tests)
+ *   multiBench [--reps R] [--max-devices G] [--small] [--events] [--no-cold] [--no-n32] [--brief] [--preheat-ms MS]
+ *              (--small: 1/100 of the sizes and no pre-heat, for tests;
+ *               --brief: what bench.py's default run embeds -- the base sizes only (C4, C5, and both on fp32 normals), shard 0
+ *               of 8 only, and the G = 1 handle re-used for the shard rows: one RCCL communicator set-up instead of two)
  */
 #include <unistd.h>
 
@@ -45,6 +47,7 @@ static int cmp_double(const void *a, const void *b)
 
 enum { NA = 16, MAX_REPS = 100 };
 typedef struct {
+    const char *config;      /* the key bench.py's rows use: C4, C4x10, C5, C5x10, and the same with _n32 */
     const char *name;
     int is_cva, n32, base;   /* base: a BASELINE size (measured cold as well) */
     uint64_t paths;
@@ -93,7 +96,7 @@ static int time_row(mc_multi *m, const Work *w, uint64_t first, uint64_t n, int 
 
 int main(int argc, char **argv)
 {
-    int reps = 10, max_devices = 64, small = 0, events = 0, cold = 1, n32 = 1;
+    int reps = 10, max_devices = 64, small = 0, events = 0, cold = 1, n32 = 1, brief = 0;
     double preheat_ms = 300.0;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--reps") && i + 1 < argc) reps = atoi(argv[++i]);
@@ -104,8 +107,9 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[i], "--no-events")) events = 0;   /* the default, accepted for old command lines */
         else if (!strcmp(argv[i], "--no-cold")) cold = 0;
         else if (!strcmp(argv[i], "--no-n32")) n32 = 0;
+        else if (!strcmp(argv[i], "--brief")) brief = 1;
         else {
-            fprintf(stderr, "usage: %s [--reps R] [--max-devices G] [--small] [--events] [--no-cold] [--no-n32] [--preheat-ms MS]\n", argv[0]);
+            fprintf(stderr, "usage: %s [--reps R] [--max-devices G] [--small] [--events] [--no-cold] [--no-n32] [--brief] [--preheat-ms MS]\n", argv[0]);
             return 1;
         }
     }
@@ -127,15 +131,22 @@ int main(int argc, char **argv)
         return 1;
     c4 = (mc_basket_f64){NA, s, v, L, d, w, 100., 1., 0.048790164};
     const uint64_t scale = small ? 100 : 1;
-    const Work work[8] = {
-        {"C4 basket n=16 f64, 1e9 paths", 0, 0, 1, 1000000000ull / scale}, {"C4 x10: basket n=16 f64, 1e10 paths", 0, 0, 0, 10000000000ull / scale},
-        {"C5 CVA 256 dates f64, 1e7 paths", 1, 0, 1, 10000000ull / scale}, {"C5 x10: CVA 256 dates f64, 1e8 paths", 1, 0, 0, 100000000ull / scale},
-        {"C4 on fp32 normals: basket n=16 f64, 1e9 paths", 0, 1, 1, 1000000000ull / scale},
-        {"C4 x10 on fp32 normals: basket n=16 f64, 1e10 paths", 0, 1, 0, 10000000000ull / scale},
-        {"C5 on fp32 normals: CVA 256 dates f64, 1e7 paths", 1, 1, 1, 10000000ull / scale},
-        {"C5 x10 on fp32 normals: CVA 256 dates f64, 1e8 paths", 1, 1, 0, 100000000ull / scale}};
-    const int n_work = n32 ? 8 : 4;
+    const Work all_work[8] = {
+        {"C4", "C4 basket n=16 f64, 1e9 paths", 0, 0, 1, 1000000000ull / scale},
+        {"C4x10", "C4 x10: basket n=16 f64, 1e10 paths", 0, 0, 0, 10000000000ull / scale},
+        {"C5", "C5 CVA 256 dates f64, 1e7 paths", 1, 0, 1, 10000000ull / scale},
+        {"C5x10", "C5 x10: CVA 256 dates f64, 1e8 paths", 1, 0, 0, 100000000ull / scale},
+        {"C4_n32", "C4 on fp32 normals: basket n=16 f64, 1e9 paths", 0, 1, 1, 1000000000ull / scale},
+        {"C4x10_n32", "C4 x10 on fp32 normals: basket n=16 f64, 1e10 paths", 0, 1, 0, 10000000000ull / scale},
+        {"C5_n32", "C5 on fp32 normals: CVA 256 dates f64, 1e7 paths", 1, 1, 1, 10000000ull / scale},
+        {"C5x10_n32", "C5 x10 on fp32 normals: CVA 256 dates f64, 1e8 paths", 1, 1, 0, 100000000ull / scale}};
+    Work work[8];
+    int n_work = 0;
+    for (int k = 0; k < (n32 ? 8 : 4); ++k)
+        if (!brief || all_work[k].base)
+            work[n_work++] = all_work[k];
     double t1[8] = {0}, t1_cold[8] = {0};   /* medians at G = 1, for the efficiency columns */
+    mc_multi *first_handle = NULL;   /* --brief: the G = 1 handle serves the shard rows too */
     for (int G = 1; G <= visible && G <= max_devices; G *= 2) {
         mc_multi *m;
         const double t_create0 = now_s();
@@ -157,29 +168,34 @@ int main(int argc, char **argv)
             if (do_cold && time_row(m, &work[k], 0, work[k].paths, reps < 5 ? reps : 5, events, 0, 0, &cd, &r)) return 1;
             if (G == 1)
                 t1[k] = hot.med, t1_cold[k] = cd.med;
-            printf("{\"devices\": %d, \"workload\": \"%s\", \"normals\": \"%s\", \"paths\": %llu, \"reps\": %d, \"preheat_ms\": %.0f, \"wall_ms_median\": %.4f, "
+            printf("{\"devices\": %d, \"config\": \"%s\", \"workload\": \"%s\", \"normals\": \"%s\", \"paths\": %llu, \"reps\": %d, \"preheat_ms\": %.0f, \"wall_ms_median\": %.4f, "
                    "\"wall_ms_min\": %.4f, \"paths_per_s\": %.6g, \"strong_efficiency_vs_1\": %.4f, \"kernel_ms_slowest_device\": %.4f, "
                    "\"fanout_us\": %.2f, \"value\": %.9g, \"confidence_95\": %.3g, \"rccl_vs_host_rel\": %.3g",
-                   G, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)work[k].paths, reps, hot.preheat_ms, hot.med * 1e3, hot.min * 1e3,
-                   (double)work[k].paths / hot.med, t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0, kernel_ms, hot.fanout_us, res.expected, res.confidence, rel);
+                   G, work[k].config, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)work[k].paths, reps, hot.preheat_ms, hot.med * 1e3,
+                   hot.min * 1e3, (double)work[k].paths / hot.med, t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0, kernel_ms, hot.fanout_us, res.expected, res.confidence, rel);
             if (do_cold)
                 printf(", \"cold\": {\"wall_ms_median\": %.4f, \"wall_ms_min\": %.4f, \"strong_efficiency_vs_1\": %.4f, \"what\": \"0.5 s idle, 2 warm-up calls, 5 calls\"}",
                        cd.med * 1e3, cd.min * 1e3, t1_cold[k] > 0 ? t1_cold[k] / (G * cd.med) : 0.0);
             printf("}\n");
             fflush(stdout);
         }
-        mc_multi_destroy(m);
+        if (brief && G == 1)
+            first_handle = m;
+        else
+            mc_multi_destroy(m);
     }
     /* What ONE device does at G = 2, 4, 8, measured on the first device alone: shard 0 of G of every workload through
      * the same call (launch, all-reduce over a communicator of one, read-back, closing).  T(1) / (G T(shard)) is the
      * strong-scaling efficiency the device side allows -- everything except the G-rank all-reduce's extra latency --
      * and it can be measured on a one-GPU box. */
     {
-        mc_multi *m;
+        mc_multi *m = first_handle;
         mc_result r;
-        CHECK(mc_multi_create(NULL, 1, 0, &m));
-        CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, 0, 1000, &r));
-        for (int G = 2; G <= 8; G *= 2)
+        if (!m) {
+            CHECK(mc_multi_create(NULL, 1, 0, &m));
+            CHECK(mc_multi_cva_run_f64(m, &c5, MC_DEFAULT_SEED, 0, 1000, &r));
+        }
+        for (int G = brief ? 8 : 2; G <= 8; G *= 2)
             for (int k = 0; k < n_work; ++k) {
                 uint64_t lo = 0, cnt = 0;
                 mc_shard_range(work[k].paths, 0, G, &lo, &cnt);
@@ -190,9 +206,10 @@ int main(int argc, char **argv)
                 const float kernel_ms = r.kernel_ms;
                 const int do_cold = cold && work[k].base;
                 if (do_cold && time_row(m, &work[k], lo, cnt, reps < 5 ? reps : 5, events, 0, 0, &cd, &r)) return 1;
-                printf("{\"shard_of\": %d, \"devices\": 1, \"workload\": \"%s\", \"normals\": \"%s\", \"paths\": %llu, \"reps\": %d, \"preheat_ms\": %.0f, "
+                printf("{\"shard_of\": %d, \"devices\": 1, \"config\": \"%s\", \"workload\": \"%s\", \"normals\": \"%s\", \"paths\": %llu, \"reps\": %d, \"preheat_ms\": %.0f, "
                        "\"wall_ms_median\": %.4f, \"wall_ms_min\": %.4f, \"kernel_ms\": %.4f, \"device_side_efficiency\": %.4f",
-                       G, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)cnt, reps, hot.preheat_ms, hot.med * 1e3, hot.min * 1e3, kernel_ms,
+                       G, work[k].config, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)cnt, reps, hot.preheat_ms, hot.med * 1e3, hot.min * 1e3,
+                       kernel_ms,
                        t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0);
                 if (do_cold)
                     printf(", \"cold\": {\"wall_ms_median\": %.4f, \"device_side_efficiency\": %.4f}", cd.med * 1e3,

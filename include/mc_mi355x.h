@@ -108,6 +108,9 @@ typedef struct {
 typedef struct mc_context mc_context;
 
 int mc_device_count(void);
+/* PCI bus id of a visible device ("0000:75:00.0"; buf of >= 13 bytes): which physical GPU an index is -- what
+ * bench.py's roster and multiBench print for every rank / device of a multi-GPU run. */
+int mc_device_pci_bus_id(int device, char *buf, int len);
 /* Create the per-GPU context (replaces dp/MonteCarloKernel.cu:296 MonteCarlo_init).
  * blocks = simulation grid size; 0 picks the default (8 workgroups of 256 per CU).
  * Current device: every call that takes a context makes that context's device the calling thread's current HIP device

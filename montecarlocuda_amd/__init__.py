@@ -7,8 +7,8 @@ Importing it requires the built shared library; running anything requires an MI3
 from . import _lib
 from ._lib import MC_DEFAULT_SEED, McError, build
 from .engine import (CVA, Engine, Estimate, MultiOptionData, OptionData, OptionValue, basket_control_mean, chol, closing,
-                     dev_basketOpt, dev_cvaEquityOption, dev_vanillaOpt, factor_from_cov, shard_range)
+                     dev_basketOpt, dev_cvaEquityOption, dev_vanillaOpt, factor_from_cov, pci_bus_id, shard_range)
 
 __all__ = ["Engine", "OptionData", "MultiOptionData", "CVA", "OptionValue", "Estimate", "dev_vanillaOpt",
-           "dev_basketOpt", "dev_cvaEquityOption", "basket_control_mean", "chol", "factor_from_cov", "closing", "shard_range", "build", "McError",
+           "dev_basketOpt", "dev_cvaEquityOption", "basket_control_mean", "chol", "factor_from_cov", "closing", "shard_range", "pci_bus_id", "build", "McError",
            "MC_DEFAULT_SEED"]

@@ -75,7 +75,7 @@ CVA = {"f32": CvaF32, "f64": CvaF64}
 
 # every symbol include/mc_mi355x.h declares (the drop-in surface), then the test hooks of include/mc_mi355x_test.h;
 # tests/test_abi.py checks that the .so exports each of them and that each is declared in exactly one of the two headers
-EXPORTS = ["mc_last_error", "mc_device_count", "mc_context_create", "mc_context_destroy", "mc_context_device",
+EXPORTS = ["mc_last_error", "mc_device_count", "mc_device_pci_bus_id", "mc_context_create", "mc_context_destroy", "mc_context_device",
            "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_last_launch", "mc_context_profile", "mc_context_profile_read",
            "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing",
            "mc_context_order", "mc_context_idle", "mc_context_arm_direct", "mc_context_publish", "mc_context_set_generator",
@@ -99,6 +99,7 @@ def _declare(L: C.CDLL) -> C.CDLL:
     L.mc_last_error.restype = C.c_char_p
     L.mc_last_error.argtypes = []
     L.mc_device_count.restype = C.c_int
+    L.mc_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.mc_context_create.argtypes = [C.c_int, C.c_int, C.POINTER(ctx)]
     L.mc_context_destroy.argtypes = [ctx]
     L.mc_context_destroy.restype = None

@@ -157,6 +157,16 @@ extern "C" int mc_device_count(void)
     return n;
 }
 
+extern "C" int mc_device_pci_bus_id(int device, char *buf, int len)
+{
+    if (!buf || len < 13)
+        return fail(MC_ERR_INVALID, "mc_device_pci_bus_id: buffer of at least 13 bytes needed");
+    const hipError_t e = hipDeviceGetPCIBusId(buf, len, device);
+    if (e != hipSuccess)
+        return fail(MC_ERR_HIP, "hipDeviceGetPCIBusId(%d): %s", device, hipGetErrorString(e));
+    return MC_OK;
+}
+
 // Wait for everything the context has enqueued, on its own stream AND on the caller stream of its most recent call
 // (mc_*_launch_* may run anywhere; calls on earlier streams are ordered before that one by begin_call).  Used before
 // anything the kernels touch is freed or reallocated.

@@ -383,6 +383,13 @@ def closing(sum_, sum2, n, discount=1.0):
     return e.value, c.value
 
 
+def pci_bus_id(device):
+    """PCI bus id of a visible device ("0000:75:00.0"): which physical GPU an index is."""
+    buf = C.create_string_buffer(32)
+    check(lib().mc_device_pci_bus_id(device, buf, 32))
+    return buf.value.decode()
+
+
 def shard_range(total, rank, world):
     first, count = C.c_uint64(), C.c_uint64()
     lib().mc_shard_range(total, rank, world, C.byref(first), C.byref(count))

@@ -95,3 +95,21 @@ def test_strong_scaling_driver_emits_json():
     assert len(runs) >= 4 and all(r["wall_ms_median"] > 0 and r["rccl_vs_host_rel"] <= 1e-12 for r in runs)
     assert any(r["workload"].startswith("C4 basket n=16") and 9.5 < r["value"] < 9.9 for r in runs)
     assert any(r["workload"].startswith("C5 CVA") and 0.18 < r["value"] < 0.20 for r in runs)
+
+
+def test_c_library_over_all_devices_real_rccl_with_fanout_trace(tmp_path):
+    """multi_check's "all rccl" leg on a box with >= 2 devices: ncclCommInitAll over every visible device, the grouped all-reduce of
+    the triples over xGMI, multi == single to 1e-12 -- with MC_MULTI_TRACE=1, so that the log keeps every call's fan-out (when each
+    launcher thread saw the call, when its launch was enqueued).  Skips on one-GPU boxes; there the G > 1 collective stays
+    unexercised."""
+    import ctypes
+    n = ctypes.CDLL(os.path.join(CSRC, "libmc_mi355x.so")).mc_device_count()
+    if n < 2:
+        pytest.skip(f"needs >= 2 visible devices for a communicator of more than one rank ({n} visible)")
+    exe = build_check(tmp_path)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=1200, env=dict(os.environ, MC_MULTI_TRACE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    print(out.stdout[-6000:])
+    print(out.stderr[-6000:])          # the fan-out trace (one line per call)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "all checks passed" in out.stdout and "MISMATCH" not in out.stdout and "all rccl" in out.stdout
+    assert f"visible devices: {n}" in out.stdout and "mc_multi fan-out" in out.stderr
