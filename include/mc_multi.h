@@ -65,19 +65,34 @@ int mc_multi_set_generator(mc_multi *m, int generator, uint64_t subsequence_base
 int mc_multi_set_timing(mc_multi *m, int on);
 /* MC_REDUCE_RCCL (default; MC_MULTI_REDUCE=host in the environment selects the other) or MC_REDUCE_HOST */
 int mc_multi_set_reduce(mc_multi *m, int mode);
-/* Launcher threads (created with the handle when it has more than one device; MC_MULTI_THREADS=0 in the environment keeps
- * the serial fan-out from the calling thread).  A launcher thread spins on its flag word for MC_MULTI_LINGER_US (default
- * 100000: longer than any call a handle is likely to be given, since the time between two hand-offs is the previous
- * call's whole duration) after its last job and then sleeps, so back-to-back calls pay no wake-up and an idle handle uses no core.
- * A job whose worker has not taken it 15 us after the hand-off (still waking up, or descheduled) is run by the calling thread.
- * What the threads buy is measured with timing OFF (mc_multi_set_timing(m, 0): pinned-slot read-back, what the legacy
- * symbols use) -- eight launches enqueued in 8.8 us instead of 22.2; with timing on, every call ends in a copy and a
- * synchronize per device, and launches that follow a synchronize serialise inside the HIP runtime whatever thread
- * issues them (profiles/r04_multi_fixed_cost_and_fanout_2.log).
+/* Launcher threads: one per device, created with the handle when it has more than one device AND the process can keep
+ * devices + 1 threads running (affinity mask capped by the cgroup CPU quota: cpu.max / cfs quota); MC_MULTI_THREADS=0 in the
+ * environment keeps the serial fan-out from the calling thread, =1 forces the threads.  A launcher thread spins on the crew's
+ * call-number word for MC_MULTI_LINGER_US (default 5000) after its last job and then sleeps: calls shorter than that which
+ * follow each other pay no wake-up, an idle handle uses no core, and a handle called more rarely than every 5 ms is served by
+ * the calling thread -- a sleeping thread's job is run by the caller AT ONCE (no wake-up on the critical path; the sleepers are
+ * woken after the fan-out, and only when calls come within the linger time of each other), the job of a spinning thread that
+ * has not taken it 15 us after the hand-off (its core was taken away) likewise.  What no take-over can bound: a thread that loses
+ * its core INSIDE the job it has claimed (or a runtime call that blocks) -- counted as `slow_claimed`.
+ * What the threads buy, measured with timing OFF (mc_multi_set_timing(m, 0): pinned-slot read-back, what the legacy symbols
+ * use): eight launches enqueued in 8.8 us (median) instead of 22.2 serial; the tail is in profiles/r05_multi_soak_*.log
+ * (p50 / p99 / p99.9 / max of every call's fan-out, and who was late in the slowest twenty).  With timing on, every call ends
+ * in a copy and a synchronize per device, and launches that follow a synchronize serialise inside the HIP runtime whatever
+ * thread issues them (profiles/r04_multi_fixed_cost_and_fanout_2.log).
  * mc_multi_launcher_threads: how many the handle runs (0 = serial).  mc_multi_last_fanout_us: host time from the entry of
- * the last mc_multi_*_run_* call until the LAST device's launch had been enqueued.  One calling thread per handle. */
+ * the last mc_multi_*_run_* call until the LAST device's launch had been enqueued.  mc_multi_last_fanout_trace: the same call
+ * per device (returns the device count; fills at most `cap` entries): seen_us[g] = when device g's thread saw the call (-1:
+ * the caller ran the job because the thread was late, -2: because it was asleep, -3: serial fan-out), enqueued_us[g] = when its
+ * launch had been enqueued.  mc_multi_fanout_stats: what became of every job so far.  mc_multi_describe: the handle's resolved
+ * configuration as one line (printed to stderr at creation under MC_VERBOSE=2).  One calling thread per handle. */
 int mc_multi_launcher_threads(const mc_multi *m);
 double mc_multi_last_fanout_us(const mc_multi *m);
+int mc_multi_last_fanout_trace(const mc_multi *m, int cap, double *seen_us, double *enqueued_us);
+typedef struct {
+    uint64_t calls, by_worker, served_parked, stolen, slow_claimed, wakeups;
+} mc_multi_fanout_counts;
+int mc_multi_fanout_stats(const mc_multi *m, mc_multi_fanout_counts *out);
+int mc_multi_describe(const mc_multi *m, char *buf, int len);
 /* The calling thread's current HIP device is unchanged by mc_multi_create / _destroy / _*_run_* (restored on the way out). */
 /* Text of the last failure of an mc_multi_* call on this thread ("" if none). */
 const char *mc_multi_last_error(void);

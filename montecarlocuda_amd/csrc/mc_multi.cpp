@@ -84,6 +84,11 @@ struct mc_multi {
     std::unique_ptr<mc_host::LaunchCrew> crew;
     std::vector<std::string> worker_error;     // text of a worker's failed launch (mc_last_error is per thread)
     double last_fanout_us = 0.0;               // call entry -> the last device's launch enqueued, of the last call
+    double last_seen_us[MAX_DEVICES] = {};     // ... per device: when its launcher thread saw the call (-1: the caller ran it because the
+    double last_at_us[MAX_DEVICES] = {};       //     thread was late, -2: because it was parked; serial fan-out: -3), when its launch was enqueued
+    long linger_us = 0;                        // resolved configuration, for mc_multi_describe
+    int cpus = 0;
+    const char *threads_why = "";
     bool trace = false;                        // MC_MULTI_TRACE=1: one stderr line per call with every device's hand-off and enqueue time
 };
 
@@ -175,20 +180,42 @@ extern "C" int mc_multi_create(const int *devices, int n_devices, int blocks, mc
         return rc;
     }
     // Launcher threads: device g's launches are issued by thread g (its own hipSetDevice, arm and launch), started through
-    // one call-number word the crew watches, so that device G-1 starts with device 0 instead of (G-1) x ~4 us later.  A worker spins for
-    // MC_MULTI_LINGER_US (default 100 000: longer than any BASELINE shard lasts -- C4 x 10 is 34 ms per device -- because the
-    // time between two hand-offs is the whole previous call) after its last job and then sleeps: back-to-back calls never pay a wake-up, an
-    // idle handle burns no core.
+    // one call-number word the crew watches, so that device G-1 starts with device 0 instead of (G-1) x ~4 us later.
+    // A worker spins for MC_MULTI_LINGER_US after its last job (default 5000: the 13 us the threads save are worth having on
+    // calls of up to a few ms -- 0.3 % of a 5 ms call -- and calls shorter than the linger time that follow each other never
+    // find a worker asleep), then sleeps; a sleeping worker's job is run by the caller at once and the sleepers are woken, after
+    // the fan-out, only when calls come within the linger time of each other.  (Round 4's default was 100 000: a handle called
+    // every < 100 ms kept G cores spinning for good -- ADVICE r04.)
+    // No threads at all when the process cannot keep G + 1 threads running (affinity mask capped by the cgroup CPU quota):
+    // spinners that exhaust the quota get the whole process throttled; MC_MULTI_THREADS=1 forces them, =0 forbids them.
     m->trace = getenv("MC_MULTI_TRACE") && atoi(getenv("MC_MULTI_TRACE")) != 0;
     const char *th = getenv("MC_MULTI_THREADS");
-    if (n_devices > 1 && !(th && atoi(th) == 0)) {
-        const char *lg = getenv("MC_MULTI_LINGER_US");
-        const long linger_us = lg ? atol(lg) : 100000;
+    const char *lg = getenv("MC_MULTI_LINGER_US");
+    m->linger_us = lg ? atol(lg) : 5000;
+    if (m->linger_us < 0)
+        m->linger_us = 0;
+    m->cpus = mc_host::cpus_allowed();
+    const bool forced = th && atoi(th) > 0, forbidden = th && atoi(th) == 0;
+    if (n_devices <= 1)
+        m->threads_why = "one device";
+    else if (forbidden)
+        m->threads_why = "MC_MULTI_THREADS=0";
+    else if (!forced && m->cpus < n_devices + 1)
+        m->threads_why = "fewer CPUs granted (affinity mask, cgroup quota) than devices + 1";
+    else {
+        m->threads_why = forced ? "MC_MULTI_THREADS" : "default";
         m->worker_error.resize((size_t)n_devices);
         m->crew.reset(new mc_host::LaunchCrew(
-            n_devices, std::chrono::microseconds(linger_us < 0 ? 0 : linger_us),
-            [](void *h, int g) { (void)hipSetDevice(static_cast<mc_multi *>(h)->devices[(size_t)g]); }, m));
+            n_devices, std::chrono::microseconds(m->linger_us),
+            [](void *h, int g) { (void)hipSetDevice(static_cast<mc_multi *>(h)->devices[(size_t)g]); }, m,
+            std::chrono::microseconds(15), m->cpus));
     }
+    if (const char *v = getenv("MC_VERBOSE"))
+        if (atoi(v) >= 2) {
+            char buf[1024];
+            mc_multi_describe(m, buf, (int)sizeof buf);
+            fprintf(stderr, "%s\n", buf);
+        }
     *out = m;
     return MC_OK;
 }
@@ -200,6 +227,45 @@ extern "C" mc_context *mc_multi_context(mc_multi *m, int i)
 }
 extern "C" double mc_multi_last_reduce_error(const mc_multi *m) { return m ? m->last_reduce_error : 0.0; }
 extern "C" double mc_multi_last_fanout_us(const mc_multi *m) { return m ? m->last_fanout_us : 0.0; }
+extern "C" int mc_multi_last_fanout_trace(const mc_multi *m, int cap, double *seen_us, double *enqueued_us)
+{
+    if (!m)
+        return 0;
+    const int G = (int)m->devices.size();
+    for (int g = 0; g < G && g < cap; ++g) {
+        if (seen_us) seen_us[g] = m->last_seen_us[g];
+        if (enqueued_us) enqueued_us[g] = m->last_at_us[g];
+    }
+    return G;
+}
+extern "C" int mc_multi_fanout_stats(const mc_multi *m, mc_multi_fanout_counts *out)
+{
+    if (!m || !out)
+        return fail(MC_ERR_INVALID, "mc_multi_fanout_stats: NULL argument");
+    *out = mc_multi_fanout_counts{};
+    if (m->crew) {
+        const mc_host::LaunchCrew::Stats &s = m->crew->stats();
+        out->calls = s.calls, out->by_worker = s.by_worker, out->served_parked = s.served_parked, out->stolen = s.stolen;
+        out->slow_claimed = s.slow_claimed, out->wakeups = s.wakeups;
+    }
+    return MC_OK;
+}
+// The resolved configuration of a handle as one line of text (MC_VERBOSE=2 prints it at creation).
+extern "C" int mc_multi_describe(const mc_multi *m, char *buf, int len)
+{
+    if (!m || !buf || len <= 0)
+        return fail(MC_ERR_INVALID, "mc_multi_describe: bad argument");
+    int k = snprintf(buf, (size_t)len, "mc_multi config: devices=[");
+    for (size_t g = 0; g < m->devices.size() && k < len; ++g)
+        k += snprintf(buf + k, (size_t)(len - k), "%s%d", g ? "," : "", m->devices[g]);
+    if (k < len)
+        snprintf(buf + k, (size_t)(len - k), "] reduce=%s readback=%s launcher_threads=%d (%s) linger_us=%ld cpus_allowed=%d (mask %d, cgroup quota %d) "
+                 "spin=%s trace=%d",
+                 m->reduce == MC_REDUCE_RCCL ? "rccl" : "host", m->readback_copy ? "copy" : "pinned-slot", m->crew ? m->crew->size() : 0, m->threads_why,
+                 m->linger_us, m->cpus, mc_host::cpus_in_affinity_mask(), mc_host::cgroup_cpu_quota(),
+                 m->crew ? (m->crew->yields() ? "yield" : "pause") : "none", (int)m->trace);
+    return MC_OK;
+}
 extern "C" int mc_multi_launcher_threads(const mc_multi *m) { return (m && m->crew) ? m->crew->size() : 0; }
 
 extern "C" int mc_multi_set_antithetic(mc_multi *m, int on)
@@ -262,10 +328,15 @@ static int ensure_comms(mc_multi *m)
     if (!m->comm.empty())
         return MC_OK;
     const int G = (int)m->devices.size();
-    // MC_MULTI_ALLOW_REPEATED_DEVICES=1 is for the test double of the collective (tests/cpp/rccl_mock.hip, preloaded in front
-    // of librccl.so), whose ranks may share a device; RCCL itself fails such a list in ncclCommInitAll
-    const char *rep = getenv("MC_MULTI_ALLOW_REPEATED_DEVICES");
-    for (int a = 0; a < G && !(rep && atoi(rep) != 0); ++a)
+    bool allow_repeated = false;
+#ifdef MC_MULTI_TEST_HOOKS
+    // Test build only (make libmc_multi_testhooks): MC_MULTI_ALLOW_REPEATED_DEVICES=1 is for the test double of the collective
+    // (tests/cpp/rccl_mock.hip, preloaded in front of librccl.so), whose ranks may share a device; RCCL itself fails such a list
+    // in ncclCommInitAll.  The shipped library has no such switch.
+    if (const char *rep = getenv("MC_MULTI_ALLOW_REPEATED_DEVICES"))
+        allow_repeated = atoi(rep) != 0;
+#endif
+    for (int a = 0; a < G && !allow_repeated; ++a)
         for (int b = a + 1; b < G; ++b)
             if (m->devices[a] == m->devices[b])
                 return fail(MC_ERR_INVALID, "device %d is listed twice: RCCL needs distinct devices (MC_REDUCE_HOST accepts the list)",
@@ -395,10 +466,14 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
             direct = false;
     }
     m->last_fanout_us = last_ns * 1e-3;
+    for (int g = 0; g < G; ++g) {
+        m->last_seen_us[g] = m->crew ? (seen_ns[(size_t)g] < 0 ? (double)seen_ns[(size_t)g] : seen_ns[(size_t)g] * 1e-3) : -3.0;
+        m->last_at_us[g] = at_ns[(size_t)g] * 1e-3;
+    }
     if (m->trace) {   // MC_MULTI_TRACE=1: when each launcher thread saw the call and when its launch had been enqueued
         fprintf(stderr, "mc_multi fan-out (us since call entry; %s):", m->crew ? (m->crew->yields() ? "launcher threads, yielding spin" : "launcher threads") : "serial");
         for (int g = 0; g < G; ++g)
-            fprintf(stderr, "  [%d] %.2f -> %.2f", g, seen_ns[(size_t)g] * 1e-3, at_ns[(size_t)g] * 1e-3);
+            fprintf(stderr, "  [%d] %.2f -> %.2f", g, m->last_seen_us[g], m->last_at_us[g]);
         if (m->crew)
             fprintf(stderr, "  | jobs taken over by the caller so far: %llu", (unsigned long long)m->crew->stolen());
         fprintf(stderr, "\n");
@@ -476,6 +551,8 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     mc_closing(out->sum, out->sum2, out->n, discount, &out->expected, &out->confidence);
     out->expected += discount * add_back;
     out->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    if (m->crew)
+        m->crew->call_ended();
     return MC_OK;
 }
 

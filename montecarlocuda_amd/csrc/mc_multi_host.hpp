@@ -11,6 +11,9 @@
 #pragma once
 #include <sched.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <atomic>
 #include <chrono>
@@ -79,7 +82,38 @@ static bool poll_slots(const volatile double *const *slots, int n, std::chrono::
 // fan-out of rounds 2-3, not a scheduler quantum; a handle whose workers sleep is served serially instead of through G
 // wake-ups.  Every job still runs exactly once.
 // ---------------------------------------------------------------------------------------------------------------
-static inline int cpus_allowed()
+// CPUs' worth of time the cgroup grants (v2 `cpu.max` = "<quota> <period>" or "max <period>"; v1 cfs quota / period), rounded
+// up; 0 = no limit or unknown.  `root` is a parameter so that a test can point it at a directory with a faked quota.
+static inline int cgroup_cpu_quota(const char *root = "/sys/fs/cgroup")
+{
+    char path[512];
+    long long quota = -1, period = 100000;
+    snprintf(path, sizeof path, "%s/cpu.max", root);
+    if (FILE *f = fopen(path, "r")) {
+        char q[32] = "";
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0)
+            quota = atoll(q);
+        fclose(f);
+    } else {
+        snprintf(path, sizeof path, "%s/cpu/cpu.cfs_quota_us", root);
+        if (FILE *g = fopen(path, "r")) {
+            if (fscanf(g, "%lld", &quota) != 1)
+                quota = -1;
+            fclose(g);
+            snprintf(path, sizeof path, "%s/cpu/cpu.cfs_period_us", root);
+            if (FILE *h = fopen(path, "r")) {
+                if (fscanf(h, "%lld", &period) != 1)
+                    period = 100000;
+                fclose(h);
+            }
+        }
+    }
+    if (quota <= 0 || period <= 0)
+        return 0;
+    return (int)((quota + period - 1) / period);
+}
+
+static inline int cpus_in_affinity_mask()
 {
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) != 0)
@@ -88,14 +122,35 @@ static inline int cpus_allowed()
     return n > 0 ? n : 1;
 }
 
+// CPUs this process can actually keep busy: the affinity mask capped by the cgroup's CPU quota.  The GPU boxes show 256
+// hardware threads in the mask and grant 16 CPUs of time (cpu.max "1600000 100000"): round 4 counted the mask alone, so
+// nine spinning threads on a 8-CPU grant would have looked fine -- and would have been throttled for the rest of every period.
+static inline int cpus_allowed(const char *cgroup_root = "/sys/fs/cgroup")
+{
+    const int mask = cpus_in_affinity_mask(), quota = cgroup_cpu_quota(cgroup_root);
+    return (quota > 0 && quota < mask) ? quota : mask;
+}
+
 class LaunchCrew {
 public:
     typedef int (*JobFn)(void *ctx, int g);
+    // what happened to the jobs of all calls so far (mc_multi_fanout_stats; tools/c/multi_soak.c prints it)
+    struct Stats {
+        uint64_t calls = 0;
+        uint64_t by_worker = 0;        // jobs run by their own launcher thread
+        uint64_t served_parked = 0;    // jobs the caller ran at once because their worker was parked (no wake-up on the critical path)
+        uint64_t stolen = 0;           // jobs the caller took over `steal_after` after the hand-off: the worker was spinning but late
+        uint64_t slow_claimed = 0;     // jobs that took > 1 ms from claim to return on their worker: descheduled INSIDE the job (or a
+                                       // runtime call that blocked) -- the one case no take-over can bound
+        uint64_t wakeups = 0;          // parked workers woken up after a call because calls had started to come in quick succession
+    };
 
+    // `cpus` = CPUs the process can keep busy (cpus_allowed(): affinity mask capped by the cgroup quota); a test passes its own.
     LaunchCrew(int n, std::chrono::nanoseconds linger, void (*thread_init)(void *, int) = nullptr, void *init_ctx = nullptr,
-               std::chrono::nanoseconds steal_after = std::chrono::microseconds(15))
-        : linger_(linger), steal_after_(steal_after), yield_(cpus_allowed() < n + 1), workers_((size_t)n)
+               std::chrono::nanoseconds steal_after = std::chrono::microseconds(15), int cpus = cpus_allowed())
+        : linger_(linger), steal_after_(steal_after), yield_(cpus < n + 1), workers_((size_t)n)
     {
+        last_end_ = std::chrono::steady_clock::now() - std::chrono::hours(1);
         for (int g = 0; g < n; ++g) {
             workers_[(size_t)g].reset(new Worker);
             Worker *w = workers_[(size_t)g].get();
@@ -122,35 +177,55 @@ public:
 
     int size() const { return (int)workers_.size(); }
     bool yields() const { return yield_; }
-    uint64_t stolen() const { return stolen_; }   // jobs the calling thread ran itself because their worker was late
+    uint64_t stolen() const { return stats_.stolen + stats_.served_parked; }   // jobs the calling thread ran itself
+    const Stats &stats() const { return stats_; }
 
-    // Runs fn(ctx, g) on worker g for every g, waits for all of them; rc[g] = fn's return value.
-    // enqueued_ns[g] (optional) = steady_clock time at which worker g's job returned, in ns since `t0`.
-    // seen_ns[g] (optional) = the time at which worker g SAW the call: hand-off latency apart from the job's own duration.
+    // Runs fn(ctx, g) for every g -- on worker g, or on the calling thread when worker g is parked or late -- and waits for
+    // all of them; rc[g] = fn's return value.
+    // enqueued_ns[g] (optional) = steady_clock time at which job g returned, in ns since `t0`.
+    // seen_ns[g] (optional) = the time at which worker g SAW the call (hand-off latency apart from the job's own duration);
+    //                         -1 = the caller ran it because the worker was late, -2 = because the worker was parked.
     void run_all(JobFn fn, void *ctx, int *rc, std::chrono::steady_clock::time_point t0 = {}, int64_t *enqueued_ns = nullptr,
                  int64_t *seen_ns = nullptr)
     {
+        using clock = std::chrono::steady_clock;
         fn_ = fn, ctx_ = ctx, t0_ = t0;
         const uint32_t seq = ++seq_;
+        ++stats_.calls;
         go_.store(seq, std::memory_order_seq_cst);             // ONE word for the whole crew: every worker sees the call at once
-        for (auto &w : workers_) {
-            if (w->parked.load(std::memory_order_seq_cst)) {   // Dekker with the worker's (parked = true; read go)
-                std::lock_guard<std::mutex> lk(w->mu);
-                w->cv.notify_one();
-            }
+        const auto handed = clock::now();
+        // Calls in quick succession (this one began within `linger` of the last one's end) are worth spinning for: parked
+        // workers are woken up -- AFTER the fan-out, off its critical path.  A lone call after a long pause leaves them asleep.
+        const bool busy = handed - last_end_ <= linger_;
+        const auto on_caller = [&](Worker &w, size_t g, int64_t why) {
+            w.seen_ns = why;
+            w.rc = fn_(ctx_, (int)g);
+            w.at_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(clock::now() - t0_).count();
+            w.done.store(seq, std::memory_order_release);
+        };
+        // 1. parked workers first: a futex wake-up costs the caller ~3 us each and the sleeper tens of us to get going, the job
+        //    itself ~3-5 us -- the caller claims it and runs it right away (Dekker with the worker's parked = true; read go)
+        bool any_parked = false;
+        for (size_t g = 0; g < workers_.size(); ++g) {
+            Worker &w = *workers_[g];
+            if (!w.parked.load(std::memory_order_seq_cst))
+                continue;
+            any_parked = true;
+            uint32_t expect = seq - 1;
+            if (w.claim.compare_exchange_strong(expect, seq, std::memory_order_acq_rel)) {
+                on_caller(w, g, -2);
+                ++stats_.served_parked;
+            }   // else: it woke up by itself in between and has the job
         }
-        const auto handed = std::chrono::steady_clock::now();
+        // 2. the spinning ones: wait; one that has not claimed its job `steal_after` after the hand-off lost its core -- take over
         for (size_t g = 0; g < workers_.size(); ++g) {
             Worker &w = *workers_[g];
             while (w.done.load(std::memory_order_acquire) != seq) {
-                if (w.claim.load(std::memory_order_relaxed) != seq && std::chrono::steady_clock::now() - handed > steal_after_) {
+                if (w.claim.load(std::memory_order_relaxed) != seq && clock::now() - handed > steal_after_) {
                     uint32_t expect = seq - 1;
-                    if (w.claim.compare_exchange_strong(expect, seq, std::memory_order_acq_rel)) {   // the worker is late: the job is ours
-                        w.seen_ns = -1;
-                        w.rc = fn_(ctx_, (int)g);
-                        w.at_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
-                        w.done.store(seq, std::memory_order_release);
-                        ++stolen_;
+                    if (w.claim.compare_exchange_strong(expect, seq, std::memory_order_acq_rel)) {
+                        on_caller(w, g, -1);
+                        ++stats_.stolen;
                         break;
                     }
                 }
@@ -161,16 +236,33 @@ public:
                 enqueued_ns[g] = w.at_ns;
             if (seen_ns)
                 seen_ns[g] = w.seen_ns;
+            if (w.seen_ns >= 0) {
+                ++stats_.by_worker;
+                if (w.at_ns - w.seen_ns > 1000000)
+                    ++stats_.slow_claimed;
+            }
         }
+        if (any_parked && busy)
+            for (auto &w : workers_)
+                if (w->parked.load(std::memory_order_seq_cst)) {
+                    std::lock_guard<std::mutex> lk(w->mu);
+                    w->wake = true;
+                    w->cv.notify_one();
+                    ++stats_.wakeups;
+                }
     }
+    // The caller's side of "a call has ended" (run_sharded: the estimate is closed): the next call's distance from here decides
+    // whether parked workers are worth waking.
+    void call_ended() { last_end_ = std::chrono::steady_clock::now(); }
 
 private:
     struct alignas(128) Worker {
-        alignas(128) std::atomic<uint32_t> claim{0};   // the last call whose job somebody took: worker g, or the caller when g was late
+        alignas(128) std::atomic<uint32_t> claim{0};   // the last call whose job somebody took: worker g, or the caller when g was parked or late
         alignas(128) std::atomic<uint32_t> done{0};
         int rc = 0;
         int64_t at_ns = 0, seen_ns = 0;
         alignas(128) std::atomic<bool> parked{false};
+        bool wake = false;                             // under mu: "get up and spin" (set by the caller after a call in a busy phase)
         std::mutex mu;
         std::condition_variable cv;
         std::thread th;
@@ -187,10 +279,14 @@ private:
                 if (quit_.load(std::memory_order_relaxed))
                     return;
                 if ((++spin & 1023u) == 0 && std::chrono::steady_clock::now() - idle_since > linger_) {
+                    // Park.  A sleeper is not woken by the next call (the caller serves it), only by `wake` -- so it keeps
+                    // sleeping through lone calls and `seen` catches up with go_ when it gets up.
                     std::unique_lock<std::mutex> lk(w.mu);
+                    w.wake = false;
                     w.parked.store(true, std::memory_order_seq_cst);
-                    while (go_.load(std::memory_order_seq_cst) == seen && !quit_.load(std::memory_order_seq_cst))
-                        w.cv.wait(lk);
+                    if (go_.load(std::memory_order_seq_cst) == seen)          // Dekker: a call handed off before `parked` was visible is ours
+                        while (!w.wake && !quit_.load(std::memory_order_seq_cst))
+                            w.cv.wait(lk);
                     w.parked.store(false, std::memory_order_seq_cst);
                     idle_since = std::chrono::steady_clock::now();
                 } else {
@@ -223,7 +319,8 @@ private:
     alignas(128) std::chrono::nanoseconds linger_;
     std::chrono::nanoseconds steal_after_;
     bool yield_;
-    uint64_t stolen_ = 0;
+    Stats stats_;
+    std::chrono::steady_clock::time_point last_end_;
     std::vector<std::unique_ptr<Worker>> workers_;
     std::atomic<bool> quit_{false};
     JobFn fn_ = nullptr;

@@ -4,6 +4,9 @@
 // Prints one line per check, "all checks passed" and exit status 0 iff everything held (tests/test_host_logic.py).
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include "mc_multi_host.hpp"
 
@@ -131,6 +134,68 @@ int main()
         int rc[3] = {-1, -1, -1};
         crew.run_all([](void *, int g) { return g; }, nullptr, rc);
         EXPECT(rc[0] == 0 && rc[1] == 1 && rc[2] == 2, "linger 0: a call on parked workers completes");
+    }
+    // ---- CPUs the process can keep busy: affinity mask capped by the cgroup quota (round 4 counted the mask alone) ------------
+    {
+        char tmpl[] = "/tmp/mc_cgroup_XXXXXX";
+        const std::string root = mkdtemp(tmpl);
+        const auto put = [&](const std::string &rel, const char *text) {
+            FILE *f = fopen((root + "/" + rel).c_str(), "w");
+            fputs(text, f);
+            fclose(f);
+        };
+        EXPECT(cgroup_cpu_quota(root.c_str()) == 0, "no cpu.max and no cfs files: no quota");
+        put("cpu.max", "max 100000\n");
+        EXPECT(cgroup_cpu_quota(root.c_str()) == 0 && cpus_allowed(root.c_str()) == cpus_in_affinity_mask(), "cgroup v2 'max 100000': no quota, the mask counts");
+        put("cpu.max", "1600000 100000\n");
+        EXPECT(cgroup_cpu_quota(root.c_str()) == 16, "cgroup v2 '1600000 100000' (the GPU boxes): 16 CPUs");
+        put("cpu.max", "150000 100000\n");
+        EXPECT(cgroup_cpu_quota(root.c_str()) == 2, "a fractional grant rounds up: 1.5 -> 2");
+        put("cpu.max", "100000 100000\n");
+        EXPECT(cpus_allowed(root.c_str()) == 1, "quota of one CPU under a wider mask: cpus_allowed() = 1");
+        unlink((root + "/cpu.max").c_str());
+        mkdir((root + "/cpu").c_str(), 0700);
+        put("cpu/cpu.cfs_quota_us", "400000\n");
+        put("cpu/cpu.cfs_period_us", "50000\n");
+        EXPECT(cgroup_cpu_quota(root.c_str()) == 8, "cgroup v1 cfs quota 400000 / period 50000: 8 CPUs");
+        put("cpu/cpu.cfs_quota_us", "-1\n");
+        EXPECT(cgroup_cpu_quota(root.c_str()) == 0, "cgroup v1 quota -1: no limit");
+        unlink((root + "/cpu/cpu.cfs_quota_us").c_str()), unlink((root + "/cpu/cpu.cfs_period_us").c_str());
+        rmdir((root + "/cpu").c_str()), rmdir(root.c_str());
+        // what the crew makes of it: 8 workers + the caller need 9 CPUs to spin with `pause`; with fewer every spin yields
+        LaunchCrew scarce(8, std::chrono::nanoseconds(0), nullptr, nullptr, std::chrono::microseconds(15), 8);
+        LaunchCrew plenty(8, std::chrono::nanoseconds(0), nullptr, nullptr, std::chrono::microseconds(15), 16);
+        EXPECT(scarce.yields() && !plenty.yields(), "8 launcher threads: yielding spin on a grant of 8 CPUs, pause spin on 16");
+    }
+    // ---- sleeping workers: the caller serves them at once; they are woken only when calls come in quick succession ---------
+    {
+        struct Ctx { std::atomic<int> calls{0}; } ctx;
+        const auto job = [](void *c, int g) -> int { static_cast<Ctx *>(c)->calls.fetch_add(1); return g; };
+        int rc[4];
+        int64_t at[4], seen[4];
+        LaunchCrew crew(4, std::chrono::milliseconds(100), nullptr, nullptr, std::chrono::seconds(10));   // steal_after 10 s: no late take-over here
+        crew.run_all(job, &ctx, rc, clk::now(), at, seen);
+        crew.call_ended();
+        EXPECT(crew.stats().by_worker == 4 && crew.stats().served_parked == 0, "fresh crew (spinning): the four jobs ran on their workers");
+        std::this_thread::sleep_for(std::chrono::milliseconds(250));                                       // > linger: all four park
+        const auto t0 = clk::now();
+        crew.run_all(job, &ctx, rc, t0, at, seen);
+        crew.call_ended();
+        bool all_parked = true;
+        for (int g = 0; g < 4; ++g) all_parked = all_parked && seen[g] == -2 && rc[g] == g;
+        EXPECT(all_parked && crew.stats().served_parked == 4, "a lone call after a long pause: all four jobs served by the caller (seen = -2)");
+        EXPECT(crew.stats().wakeups == 0, "... and nobody was woken up for it");
+        std::this_thread::sleep_for(std::chrono::milliseconds(5));                                         // < linger since the last call ended
+        crew.run_all(job, &ctx, rc, clk::now(), at, seen);
+        crew.call_ended();
+        EXPECT(crew.stats().served_parked == 8 && crew.stats().wakeups == 4, "a second call soon after: served by the caller again, then the four sleepers are woken");
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));                                        // time to get up; they spin now
+        crew.run_all(job, &ctx, rc, clk::now(), at, seen);
+        crew.call_ended();
+        bool by_workers = true;
+        for (int g = 0; g < 4; ++g) by_workers = by_workers && seen[g] >= 0;
+        EXPECT(by_workers && crew.stats().by_worker == 8, "the third call finds them spinning: the jobs run on the workers again");
+        EXPECT(ctx.calls.load() == 16 && crew.stats().calls == 4 && crew.stats().stolen == 0, "16 jobs, each exactly once; none counted as a late take-over");
     }
     // ---- late workers: the caller claims their jobs (every job still runs exactly once) -------------------------------------
     {
