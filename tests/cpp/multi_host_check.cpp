@@ -85,7 +85,8 @@ int main()
         struct Ctx { std::atomic<int> calls{0}; std::thread::id ids[8]; int inited[8]; } ctx;
         memset(ctx.inited, 0, sizeof ctx.inited);
         // steal_after = 10 s: the caller never takes a job over in this block, so "each on its own thread" can be asserted
-        LaunchCrew crew(8, std::chrono::milliseconds(2), [](void *c, int g) { static_cast<Ctx *>(c)->inited[g] = g + 1; }, &ctx,
+        // linger 2 s: no worker goes to sleep before the first call, however slowly the eight threads start on a loaded box
+        LaunchCrew crew(8, std::chrono::seconds(2), [](void *c, int g) { static_cast<Ctx *>(c)->inited[g] = g + 1; }, &ctx,
                         std::chrono::seconds(10));
         int rc[8];
         int64_t at[8];
@@ -110,11 +111,17 @@ int main()
         for (int i = 0; i < 20000; ++i)
             crew.run_all(job, &ctx, rc);
         EXPECT(ctx.calls.load() == 8 * 20001, "20 000 back-to-back calls: no hand-off lost while the workers spin");
-        for (int i = 0; i < 30; ++i) {
-            std::this_thread::sleep_for(std::chrono::milliseconds(i % 3 == 0 ? 6 : 1));   // around the 2 ms linger time
-            crew.run_all(job, &ctx, rc);
+        {
+            LaunchCrew naps(8, std::chrono::milliseconds(2), nullptr, nullptr, std::chrono::seconds(10));
+            for (int i = 0; i < 30; ++i) {
+                std::this_thread::sleep_for(std::chrono::milliseconds(i % 3 == 0 ? 6 : 1));   // around the 2 ms linger time
+                naps.run_all(job, &ctx, rc);
+                naps.call_ended();
+            }
+            printf("   %llu of 240 jobs served by the caller for sleeping workers, %llu wake-ups\n", (unsigned long long)naps.stats().served_parked,
+                   (unsigned long long)naps.stats().wakeups);
         }
-        EXPECT(ctx.calls.load() == 8 * 20031, "30 calls with pauses around the linger time: parked workers wake up, none is lost");
+        EXPECT(ctx.calls.load() == 8 * 20031, "30 calls with pauses around the linger time: sleeping workers are served or woken, none is lost");
         // hand-off latency while the workers spin: call entry -> the last job returned
         double worst = 0, sum = 0;
         for (int i = 0; i < 2000; ++i) {
