@@ -184,6 +184,30 @@ int mc_context_set_finish(mc_context *ctx, int fused);
 int mc_basket_control_mean_f32(const mc_basket_f32 *opt, double *mean);
 int mc_basket_control_mean_f64(const mc_basket_f64 *opt, double *mean);
 
+/* Where the time of the context's last synchronous call (mc_*_run_*, mc_*_run_grid_*) went -- the reference prints the same
+ * stages from inside every call (RNG set-up dp/MonteCarloKernel.cu:317-323, allocations :326-341, kernel :380-386, copy :404-409,
+ * closing :415-427); here they are returned, and the legacy symbols print them under MC_VERBOSE=1.  Consecutive host-clock
+ * intervals, so setup + table_upload + launch + kernel + readback + closing = wall_ms (to the clamping of readback_ms at 0):
+ *   setup_ms         work a repeated identical call does not do again: XORWOW jump matrices and start states (the reference's
+ *                    randomSetup, paid there on EVERY call), launch-geometry states of a new (numBlocks, numThreads), buffer growth;
+ *                    waited for on the device, so that it is not inside kernel_ms
+ *   table_upload_ms  constant tables built on the host and uploaded when the inputs changed (CVA per-date rows, tiled basket matrix)
+ *   launch_ms        the rest of the host time before the wait: folding the inputs, the launch calls themselves -- on the first
+ *                    launch of a kernel in the process this includes loading its code object (~10 ms)
+ *   kernel_ms        device time of the call's kernels (HIP events; 0 with timing off -- the kernel is then inside readback_ms)
+ *   readback_ms      from the last launch call to the triple on the host, minus kernel_ms: launch latency, copy / poll
+ *   closing_ms       price and confidence interval on the host
+ *   context_create_ms  what mc_context_create took for this context (once; NOT part of wall_ms): HIP runtime start-up on the first
+ *                    context of a process, stream, buffers.  first_call = 1 on the context's first synchronous call. */
+typedef struct {
+    float setup_ms, table_upload_ms, launch_ms, kernel_ms, readback_ms, closing_ms, wall_ms, context_create_ms;
+    int first_call;
+} mc_call_stats;
+int mc_context_last_call_stats(const mc_context *ctx, mc_call_stats *out);
+/* The context's resolved configuration (device, grid, estimator, generator, kernel-family limits ...) as one line of text;
+ * printed to stderr by mc_context_create when MC_VERBOSE >= 2. */
+int mc_context_describe(const mc_context *ctx, char *buf, int len);
+
 /* Sampled device timing of the simulation kernel (not the finishing kernel): every `every`-th
  * launch is bracketed by two HIP events on its launch stream (0 = off; at most 512 samples are
  * kept between reads).  Replaces the reference's cudaEvent pair around each launch

@@ -61,6 +61,11 @@ class Result(C.Structure):
                 ("n", C.c_uint64), ("kernel_ms", C.c_float), ("wall_ms", C.c_float)]
 
 
+class CallStats(C.Structure):   # mc_call_stats: where the last synchronous call's time went
+    _fields_ = [(k, C.c_float) for k in ("setup_ms", "table_upload_ms", "launch_ms", "kernel_ms", "readback_ms", "closing_ms", "wall_ms",
+                                         "context_create_ms")] + [("first_call", C.c_int)]
+
+
 class Greeks(C.Structure):
     _fields_ = [("price", Result), ("delta", Result), ("vega", Result)]
 
@@ -76,7 +81,7 @@ CVA = {"f32": CvaF32, "f64": CvaF64}
 # every symbol include/mc_mi355x.h declares (the drop-in surface), then the test hooks of include/mc_mi355x_test.h;
 # tests/test_abi.py checks that the .so exports each of them and that each is declared in exactly one of the two headers
 EXPORTS = ["mc_last_error", "mc_device_count", "mc_device_pci_bus_id", "mc_context_create", "mc_context_destroy", "mc_context_device",
-           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_last_launch", "mc_context_profile", "mc_context_profile_read",
+           "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_last_launch", "mc_context_last_call_stats", "mc_context_describe", "mc_context_profile", "mc_context_profile_read",
            "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing",
            "mc_context_order", "mc_context_idle", "mc_context_arm_direct", "mc_context_publish", "mc_context_set_generator",
            "mc_context_set_normals", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range",
@@ -109,6 +114,8 @@ def _declare(L: C.CDLL) -> C.CDLL:
     L.mc_context_stream.restype = C.c_void_p
     L.mc_context_info.argtypes = [ctx, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.mc_context_last_launch.argtypes = [ctx, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.mc_context_last_call_stats.argtypes = [ctx, C.POINTER(CallStats)]
+    L.mc_context_describe.argtypes = [ctx, C.c_char_p, C.c_int]
     L.mc_context_set_antithetic.argtypes = [ctx, C.c_int]
     L.mc_context_set_control_variate.argtypes = [ctx, C.c_int]
     L.mc_context_set_finish.argtypes = [ctx, C.c_int]

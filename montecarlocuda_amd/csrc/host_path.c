@@ -297,6 +297,18 @@ static OptionValue simulate(chunk_fn fn, const void *ctx, long long paths, doubl
     g_normals_f32 = getenv("MC_F64_NORMALS") && !strcmp(getenv("MC_F64_NORMALS"), "f32");
     g_npb = g_normals_f32 ? 4 : NPB;
 #endif
+    {   /* MC_VERBOSE >= 2: what this call resolved its environment to, once per process (INTEGRATION.md section 1 holds the table) */
+        static int told;
+        const char *vb = getenv("MC_VERBOSE");
+        if (!told && vb && atoi(vb) >= 2) {
+            told = 1;
+            const char *isa = getenv("MC_HOST_ISA");
+            fprintf(stderr, "CPU twin config (libmchost): MC_HOST_THREADS -> %d threads (cgroup CPU limit %d, 0 = none) MC_HOST_ISA=%s MC_HOST_SCALAR=%d "
+                    "MC_ANTITHETIC=%d MC_CONTROL_VARIATE=%d MC_F64_NORMALS=%s seed=0x%llx\n",
+                    mc_host_threads(), cgroup_cpu_limit(), isa ? isa : "(widest the CPU has)", getenv("MC_HOST_SCALAR") != NULL, g_antithetic, g_control,
+                    g_normals_f32 ? "f32" : "native", (unsigned long long)seed);
+        }
+    }
 #ifdef _OPENMP
     omp_set_num_threads(mc_host_threads());
 #endif

@@ -67,6 +67,49 @@ static void die(const char *what)
     exit(1);
 }
 
+/* ---- configuration: every environment variable this library reads, resolved ONCE at the first call (MC_SEED alone is read by
+ * every call) and printed on request (MC_VERBOSE=2).  INTEGRATION.md section 1 holds the table. ---- */
+typedef struct {
+    int verbose;           /* MC_VERBOSE: 1 = one line per call with the stage breakdown, 2 = also the resolved configuration */
+    int device;            /* MC_DEVICE */
+    const char *devices;   /* MC_DEVICES: NULL / "" = single device */
+    int antithetic;        /* MC_ANTITHETIC */
+    int control;           /* MC_CONTROL_VARIATE */
+    int xorwow, grid;      /* MC_RNG = xorwow | xorwow_grid */
+} Config;
+
+static const Config *config(void)
+{
+    static Config c;
+    static int resolved;
+    if (resolved)
+        return &c;
+    const char *v;
+    c.verbose = (v = getenv("MC_VERBOSE")) ? (atoi(v) > 0 ? atoi(v) : 1) : 0;   /* set at all = 1, as before; a number selects the level */
+    c.device = (v = getenv("MC_DEVICE")) ? atoi(v) : 0;
+    c.devices = (v = getenv("MC_DEVICES")) && v[0] ? v : NULL;
+    c.antithetic = (v = getenv("MC_ANTITHETIC")) && atoi(v);
+    c.control = (v = getenv("MC_CONTROL_VARIATE")) && atoi(v);
+    v = getenv("MC_RNG");
+    c.xorwow = v && !strcmp(v, "xorwow");
+    c.grid = v && !strcmp(v, "xorwow_grid");
+    if (c.grid && c.devices) {
+        fprintf(stderr, "Error: MC_RNG=xorwow_grid reproduces a single-GPU launch of the reference; unset MC_DEVICES\n");
+        exit(1);
+    }
+    resolved = 1;
+    if (c.verbose >= 2)
+        fprintf(stderr, "legacy symbols config (%s, N=%d): MC_DEVICE=%d MC_DEVICES=%s MC_RNG=%s MC_ANTITHETIC=%d MC_CONTROL_VARIATE=%d MC_SEED=%s MC_VERBOSE=%d\n",
+#ifdef MC_SINGLE_PRECISION
+                "libmcgpu_f32",
+#else
+                "libmcgpu_f64",
+#endif
+                N, c.device, c.devices ? c.devices : "(unset: one device)", c.grid ? "xorwow_grid" : (c.xorwow ? "xorwow" : "philox (default)"), c.antithetic,
+                c.control, getenv("MC_SEED") ? getenv("MC_SEED") : "(unset: MC_DEFAULT_SEED)", c.verbose);
+    return &c;
+}
+
 static void drop_multi(void)
 {
     if (g_multi)
@@ -87,8 +130,8 @@ static void *multi_symbol(void *lib, const char *name)
 /* NULL unless MC_DEVICES is set */
 static mc_multi *multi(void)
 {
-    const char *list = getenv("MC_DEVICES");
-    if (g_multi || !list || !list[0])
+    const char *list = config()->devices;
+    if (g_multi || !list)
         return g_multi;
     char path[4096] = "libmc_multi.so";
     Dl_info here;
@@ -135,13 +178,13 @@ static mc_multi *multi(void)
     }
     if (create(n ? devices : NULL, n, 0, &g_multi) != MC_OK)
         die("creating the multi-device handle (MC_DEVICES)");
-    if (getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC")))
+    if (config()->antithetic)
         set_anti(g_multi, 1);
-    if (getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE")))
+    if (config()->control)
         set_cv(g_multi, 1);
-    if (getenv("MC_RNG") && !strcmp(getenv("MC_RNG"), "xorwow"))
+    if (config()->xorwow)
         set_rng(g_multi, MC_RNG_XORWOW, 0);
-    if (!getenv("MC_VERBOSE"))
+    if (!config()->verbose)
         set_timing(g_multi, 0);
     atexit(drop_multi);
     return g_multi;
@@ -156,16 +199,15 @@ static void drop_context(void)
 static mc_context *context(void)
 {
     if (!g_ctx) {
-        const char *dev = getenv("MC_DEVICE");
-        if (mc_context_create(dev ? atoi(dev) : 0, 0, &g_ctx) != MC_OK)
+        if (mc_context_create(config()->device, 0, &g_ctx) != MC_OK)
             die("creating the device context");
-        if (getenv("MC_ANTITHETIC") && atoi(getenv("MC_ANTITHETIC")))
+        if (config()->antithetic)
             mc_context_set_antithetic(g_ctx, 1);
-        if (getenv("MC_CONTROL_VARIATE") && atoi(getenv("MC_CONTROL_VARIATE")))
+        if (config()->control)
             mc_context_set_control_variate(g_ctx, 1);
-        if (getenv("MC_RNG") && !strcmp(getenv("MC_RNG"), "xorwow"))
+        if (config()->xorwow)
             mc_context_set_generator(g_ctx, MC_RNG_XORWOW, 0);
-        if (!getenv("MC_VERBOSE"))   /* nobody reads kernel_ms: take the short way back (result polled from pinned memory) */
+        if (!config()->verbose)   /* nobody reads kernel_ms: take the short way back (result polled from pinned memory) */
             mc_context_set_timing(g_ctx, 0);
         atexit(drop_context);
     }
@@ -175,14 +217,7 @@ static mc_context *context(void)
 /* MC_RNG=xorwow_grid: the calls go through mc_*_run_grid_* with the caller's (numBlocks, numThreads) */
 static int grid_mode(void)
 {
-    const char *r = getenv("MC_RNG");
-    if (!r || strcmp(r, "xorwow_grid"))
-        return 0;
-    if (getenv("MC_DEVICES")) {
-        fprintf(stderr, "Error: MC_RNG=xorwow_grid reproduces a single-GPU launch of the reference; unset MC_DEVICES\n");
-        exit(1);
-    }
-    return 1;
+    return config()->grid;
 }
 
 /* the seed of the next call: the *_ex entry points set it for their own call, everything else reads MC_SEED */
@@ -211,9 +246,20 @@ static OptionValue finish(const mc_result *r, const char *what)
     OptionValue v;
     v.Expected = (mc_real)r->expected;
     v.Confidence = (mc_real)r->confidence;
-    if (getenv("MC_VERBOSE"))
+    if (config()->verbose) {
+        /* the reference prints its stages from inside every call (RNG set-up :317-323, allocations :326-341, kernel :380-386, copy
+         * :404-409, closing :415-427); the same breakdown for this call, and what the first call of the process paid before it */
         printf("%s: %llu paths, kernel %.3f ms, call %.3f ms, value %.9g +- %.3g\n", what, (unsigned long long)r->n,
                r->kernel_ms, r->wall_ms, r->expected, r->confidence);
+        mc_call_stats k;
+        if (!g_multi && g_ctx && mc_context_last_call_stats(g_ctx, &k) == MC_OK) {
+            printf("%s stages (ms): set-up %.3f | tables %.3f | launch %.3f | kernel %.3f | read-back %.3f | closing %.3f | = call %.3f", what,
+                   k.setup_ms, k.table_upload_ms, k.launch_ms, k.kernel_ms, k.readback_ms, k.closing_ms, k.wall_ms);
+            if (k.first_call)
+                printf("   [first call of this context: creating it (HIP runtime, stream, buffers) took %.1f ms before that]", k.context_create_ms);
+            printf("\n");
+        }
+    }
     return v;
 }
 

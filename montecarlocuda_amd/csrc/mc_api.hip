@@ -106,7 +106,26 @@ struct mc_context {
     uint64_t launches = 0;
     std::vector<hipEvent_t> prof_start, prof_stop;
     int prof_used = 0;
+    // stage breakdown of the synchronous calls (mc_context_last_call_stats): host-clock accumulators of the call in progress
+    mc_call_stats stats = {};
+    double acc_setup_ms = 0, acc_table_ms = 0;
+    std::chrono::steady_clock::time_point call_t0;   // start of a synchronous call whose first part ran before run_sync (staged launch geometry)
+    bool call_t0_valid = false;
+    bool stats_timed_call = false;   // a timed synchronous call is being enqueued: set-up work that completes on the device re-records ev0
+    float create_ms = 0;
+    uint64_t sync_calls = 0;
 };
+
+// Host-clock time of a stage of the call in progress, added to one of the context's accumulators (run_sync reads them).
+struct StageTimer {
+    double *acc;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit StageTimer(double *a) : acc(a) {}
+    ~StageTimer() { *acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+// Set-up that ran on the device (XORWOW states, jump matrices): waited for HERE, so that it is charged to set-up and not to the
+// kernel stage, and the call's opening event is recorded again behind it.
+static int setup_settle(mc_context *c, hipStream_t st);
 
 static constexpr int PROFILE_RING = 512;
 
@@ -197,8 +216,6 @@ static int context_allocate(mc_context *c)
         c->fused = strcmp(e, "kernel") != 0;
     if (const char *e = getenv("MC_F64_NORMALS"))   // "f32": the reference's dp arithmetic (mc_context_set_normals)
         c->normals_f32 = strcmp(e, "f32") == 0;
-    if (const char *e = getenv("MC_GRID_FORM"))     // launch-geometry mode: "staged" / "fused" force a form (default: fused where compiled)
-        c->grid_form = strcmp(e, "staged") == 0 ? MC_GRID_FORM_STAGED : (strcmp(e, "fused") == 0 ? MC_GRID_FORM_FUSED : MC_GRID_FORM_AUTO);
     return MC_OK;
 }
 
@@ -209,6 +226,7 @@ extern "C" int mc_context_create(int device, int blocks, mc_context **out)
     if (!out)
         return fail(MC_ERR_INVALID, "mc_context_create: out is NULL");
     *out = nullptr;
+    const auto create0 = std::chrono::steady_clock::now();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(MC_ERR_NO_DEVICE, "no HIP device visible (the HIP engine has no CPU fallback)");
@@ -233,7 +251,45 @@ extern "C" int mc_context_create(int device, int blocks, mc_context **out)
         mc_context_destroy(c);  // frees whatever was allocated before the failure (keeps the error text)
         return rc;
     }
+    c->create_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - create0).count();
+    if (const char *v = getenv("MC_VERBOSE"))   // 2: the resolved configuration, once per context, on stderr
+        if (atoi(v) >= 2) {
+            char buf[1024];
+            mc_context_describe(c, buf, (int)sizeof buf);
+            fprintf(stderr, "%s\n", buf);
+        }
     *out = c;
+    return MC_OK;
+}
+
+static int setup_settle(mc_context *c, hipStream_t st)
+{
+    HIPCHK(hipStreamSynchronize(st));
+    if (c->stats_timed_call && st == c->stream)
+        HIPCHK(hipEventRecord(c->ev0, c->stream));
+    return MC_OK;
+}
+
+extern "C" int mc_context_last_call_stats(const mc_context *c, mc_call_stats *out)
+{
+    if (!c || !out)
+        return fail(MC_ERR_INVALID, "mc_context_last_call_stats: NULL argument");
+    *out = c->stats;
+    return MC_OK;
+}
+
+// The resolved configuration of a context as one line of text (what MC_VERBOSE=2 prints at creation).
+extern "C" int mc_context_describe(const mc_context *c, char *buf, int len)
+{
+    if (!c || !buf || len <= 0)
+        return fail(MC_ERR_INVALID, "mc_context_describe: bad argument");
+    snprintf(buf, (size_t)len,
+             "mc_context config: device=%d \"%s\" CUs=%d clock_mhz=%d blocks=%d finish=%s f64_normals=%s rng=%s antithetic=%d control_variate=%d timing=%d "
+             "grid_form=%s basket_static_max=f32:%d,f64:%d basket_tiled_min=%d basket_mfma=%d grid_sub=%d(0=auto) vanilla_units_per_lane=%d created_in_ms=%.1f",
+             c->device, c->name, c->compute_units, c->clock_mhz, c->blocks, c->fused ? "fused" : "kernel", c->normals_f32 ? "f32" : "native",
+             c->rng == MC_RNG_XORWOW ? "xorwow" : "philox", (int)c->antithetic, (int)c->control, (int)c->timing,
+             c->grid_form == MC_GRID_FORM_STAGED ? "staged" : (c->grid_form == MC_GRID_FORM_FUSED ? "fused" : "auto"), basket_static_max<float>(),
+             basket_static_max<double>(), basket_tiled_min(), (int)basket_mfma(), env_int("MC_GRID_SUB", 0, 0, 32), vanilla_units_per_lane(), c->create_ms);
     return MC_OK;
 }
 
@@ -695,13 +751,14 @@ static int xorwow_fill(mc_context *c, uint64_t seed, uint64_t base, uint32_t lan
 static int xorwow_ready(mc_context *c, uint64_t seed, hipStream_t st)
 {
     const uint32_t lanes = (uint32_t)c->blocks * GROUP;
+    if (c->d_xorwow && c->xorwow_valid && c->xorwow_seed == seed && c->xorwow_state_base == c->xorwow_base)
+        return MC_OK;
+    StageTimer stage(&c->acc_setup_ms);   // the reference's randomSetup (dp/MonteCarloKernel.cu:285-290, "RNG done" :317-323) -- here once per seed
     if (!c->d_xorwow)
         HIPCHK(hipMalloc(&c->d_xorwow, sizeof(uint32_t) * 6 * (size_t)lanes));
-    if (!c->xorwow_valid || c->xorwow_seed != seed || c->xorwow_state_base != c->xorwow_base) {
-        if (int rc = xorwow_fill(c, seed, c->xorwow_base, lanes, c->d_xorwow, st)) return rc;
-        c->xorwow_valid = true, c->xorwow_seed = seed, c->xorwow_state_base = c->xorwow_base;
-    }
-    return MC_OK;
+    if (int rc = xorwow_fill(c, seed, c->xorwow_base, lanes, c->d_xorwow, st)) return rc;
+    c->xorwow_valid = true, c->xorwow_seed = seed, c->xorwow_state_base = c->xorwow_base;
+    return c->stats_timed_call ? setup_settle(c, st) : MC_OK;
 }
 
 static int xorwow_one_segment(const std::vector<Segment> &segs)
@@ -778,6 +835,7 @@ static constexpr uint64_t MAX_DUMP_PATHS = 1ull << 26;
 static int upload_table(mc_context *c, hipStream_t st, const std::vector<char> &key, const void *data, size_t bytes)
 {
     if (key != c->table_key) {
+        StageTimer stage(&c->acc_table_ms);
         if (bytes > c->table_bytes) {
             HIPCHK(hipStreamSynchronize(st));
             if (c->table_stream && c->table_stream != st) HIPCHK(hipStreamSynchronize(c->table_stream));
@@ -1733,11 +1791,20 @@ extern "C" int mc_cva_greeks_run_f64(mc_context *c, const mc_cva_f64 *v, uint64_
 template <class Enq>
 static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, Enq enqueue)
 {
-    const auto wall0 = std::chrono::steady_clock::now();
+    using clock = std::chrono::steady_clock;
+    const auto ms_between = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    // a caller that did part of the call's work before coming here (the staged launch-geometry form) has set call_t0
+    const auto wall0 = c->call_t0_valid ? c->call_t0 : clock::now();
+    c->call_t0_valid = false;
     HIPCHK(hipSetDevice(c->device));
     c->armed = false;   // mc_context_arm_direct applies to the next mc_*_launch_* only: a synchronous call in between cancels it
     float ms = 0;
     const double *h = c->h_triple;
+    clock::time_point t_enqueued;
+    struct Scope {   // whatever way out: the stage accumulators and flags belong to ONE call
+        mc_context *c;
+        ~Scope() { c->acc_setup_ms = c->acc_table_ms = 0, c->stats_timed_call = false; }
+    } scope{c};
     if (!c->timing && c->fused) {
         volatile double *flag = c->h_direct + 2;
         *flag = DIRECT_SENTINEL;
@@ -1746,6 +1813,7 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         const int rc = enqueue(c->stream, c->d_triple);
         c->direct_target = nullptr;
         if (rc) return rc;
+        t_enqueued = clock::now();
         // poll from user space for the first 50 ms (the calls that care about 20 us are shorter than that), then hand the
         // core back and wait in the runtime (also the way out when a kernel failed and never writes)
         bool seen = false;
@@ -1754,7 +1822,7 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
                 seen = true;
                 break;
             }
-            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - wall0 > std::chrono::milliseconds(50))
+            if ((spin & 255u) == 255u && clock::now() - wall0 > std::chrono::milliseconds(50))
                 break;
             __builtin_ia32_pause();
         }
@@ -1769,12 +1837,16 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         // triple, whose n word would pass the check below whenever n is unchanged
         HIPCHK(hipMemsetAsync(c->d_triple, 0xFF, 3 * sizeof(double), c->stream));
         if (c->timing) HIPCHK(hipEventRecord(c->ev0, c->stream));
+        c->stats_timed_call = c->timing;   // set-up that completes on the device inside enqueue re-records ev0 behind itself
         if (int rc = enqueue(c->stream, c->d_triple)) return rc;
+        c->stats_timed_call = false;
         if (c->timing) HIPCHK(hipEventRecord(c->ev1, c->stream));
+        t_enqueued = clock::now();
         HIPCHK(hipMemcpyAsync(c->h_triple, c->d_triple, 3 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->timing) HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     }
+    const auto t_result = clock::now();
     if (!(h[2] == (double)n))   // also catches the poison (NaN) of a reduction that never closed
         return fail(MC_ERR_HIP, "device returned n=%g, expected %llu: the call's final reduction did not complete", h[2],
                     (unsigned long long)n);
@@ -1786,7 +1858,20 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
         return fail(MC_ERR_HIP, "device returned n=%llu, expected %llu", (unsigned long long)out->n,
                     (unsigned long long)n);
     mc_closing(out->sum, out->sum2, out->n, discount, &out->expected, &out->confidence);
-    out->wall_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    const auto t_closed = clock::now();
+    out->wall_ms = (float)ms_between(wall0, t_closed);
+    // the stage breakdown (mc_context_last_call_stats): consecutive host-clock intervals, the device's kernel time taken out of the wait
+    mc_call_stats &k = c->stats;
+    const double before = ms_between(wall0, t_enqueued), wait = ms_between(t_enqueued, t_result);
+    k.setup_ms = (float)c->acc_setup_ms;
+    k.table_upload_ms = (float)c->acc_table_ms;
+    k.launch_ms = (float)std::max(0.0, before - c->acc_setup_ms - c->acc_table_ms);
+    k.kernel_ms = ms;
+    k.readback_ms = (float)std::max(0.0, wait - (double)ms);
+    k.closing_ms = (float)ms_between(t_result, t_closed);
+    k.wall_ms = out->wall_ms;
+    k.context_create_ms = c->create_ms;
+    k.first_call = c->sync_calls++ == 0;
     return MC_OK;
 }
 
@@ -1936,6 +2021,8 @@ static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, uin
             *states = g.d;
             return MC_OK;
         }
+    // a miss: set-up work of the call (the reference pays its randomSetup on EVERY call, dp/MonteCarloKernel.cu:315-323)
+    StageTimer stage(&c->acc_setup_ms);
     if (int rc = xorwow_jump_ready(c)) return rc;
     if (c->grid_cache.size() >= GRID_CACHE) {   // evict the least recently used geometry (no kernel may still read it)
         HIPCHK(hipStreamSynchronize(c->stream));
@@ -1943,8 +2030,9 @@ static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, uin
         for (size_t i = 1; i < c->grid_cache.size(); ++i)
             if (c->grid_cache[i].last_used < c->grid_cache[lru].last_used)
                 lru = i;
-        HIPCHK(hipFree(c->grid_cache[lru].d));
-        c->grid_cache.erase(c->grid_cache.begin() + (long)lru);
+        uint32_t *victim = c->grid_cache[lru].d;
+        c->grid_cache.erase(c->grid_cache.begin() + (long)lru);   // out of the cache BEFORE it is freed: a failing hipFree leaves no dangling entry
+        HIPCHK(hipFree(victim));
     }
     uint32_t *d = nullptr;
     HIPCHK(hipMalloc(&d, sizeof(uint32_t) * 6 * (size_t)lanes));
@@ -1955,7 +2043,9 @@ static int grid_states_ready(mc_context *c, int num_blocks, int num_threads, uin
     }
     c->grid_cache.push_back({num_blocks, num_threads, sub, step, d, ++c->grid_clock});
     *states = d;
-    return MC_OK;
+    // the states are complete before the pricing kernel is enqueued, and a timed call's opening event is recorded again behind
+    // them: kernel_ms is the pricing kernel's, the set-up is reported as set-up (it used to sit inside ev0..ev1)
+    return setup_settle(c, c->stream);
 }
 
 extern "C" int mc_context_set_grid_form(mc_context *c, int form)
@@ -1974,6 +2064,7 @@ static int grid_run_staged(mc_context *c, int num_blocks, int num_threads, uint6
                            uint32_t per_unit, size_t padded, double discount, Real *h_values, mc_result *out, Enq enqueue)
 {
     const uint64_t n = (uint64_t)num_blocks * paths_per_block;
+    c->call_t0 = std::chrono::steady_clock::now(), c->call_t0_valid = !h_values;   // the normals pass below is part of the call's wall time
     HIPCHK(hipSetDevice(c->device));
     if (int rc = ensure_ext(c, padded * sizeof(Real))) return rc;
     const uint32_t *states = nullptr;

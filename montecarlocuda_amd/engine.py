@@ -142,6 +142,19 @@ class Engine:
         return {"name": name.value.decode(), "compute_units": cus.value, "clock_mhz": mhz.value,
                 "blocks": self.blocks}
 
+    def last_call_stats(self):
+        """Stage breakdown (ms) of this context's last synchronous call: mc_context_last_call_stats."""
+        from ._lib import CallStats
+        k = CallStats()
+        check(lib().mc_context_last_call_stats(self._ctx, C.byref(k)))
+        return {f: getattr(k, f) for f, _ in CallStats._fields_}
+
+    def describe(self):
+        """The context's resolved configuration as one line (what MC_VERBOSE=2 prints at creation)."""
+        buf = C.create_string_buffer(1024)
+        check(lib().mc_context_describe(self._ctx, buf, 1024))
+        return buf.value.decode()
+
     def last_launch(self):
         """(workgroups, lanes per workgroup) of the most recent simulation launch of this context."""
         g, t = C.c_int(), C.c_int()

@@ -162,3 +162,36 @@ def test_legacy_library_does_not_pull_in_rccl(mc):
     for X in ("f32", "f64"):
         needed = subprocess.check_output(["readelf", "-d", mc._lib.LEGACY[X]], text=True)
         assert "librccl" not in needed and "libmc_multi" not in needed and "libmc_mi355x.so" in needed
+
+
+def test_every_environment_variable_the_libraries_read_is_in_the_table():
+    """INTEGRATION.md section 1 holds ONE table of the knobs: every name the product sources pass to getenv() or to
+    the env_int() helper must have a row there, and the table must not list names nobody reads.  The test-only switch of
+    libmc_multi is compiled in under -DMC_MULTI_TEST_HOOKS only and named below the table, not in it."""
+    import glob
+    import re
+    csrc = os.path.join(ROOT, "montecarlocuda_amd", "csrc")
+    read = {}
+    for path in sorted(glob.glob(os.path.join(csrc, "*.[ch]*")) + glob.glob(os.path.join(ROOT, "drivers", "*.[ch]"))):
+        if path.endswith((".so", ".o", ".inc")):
+            continue
+        text = open(path, errors="replace").read()
+        for name in re.findall(r'(?:getenv|env_int)\("(MC_[A-Z0-9_]+)"', text):
+            read.setdefault(name, set()).add(os.path.basename(path))
+    assert len(read) >= 20, read
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    rows = set()
+    for line in doc.splitlines():
+        if line.startswith("| `MC_"):
+            rows |= set(re.findall(r"`(MC_[A-Z0-9_]+)`", line.split("|")[1]))
+    test_only = {"MC_MULTI_ALLOW_REPEATED_DEVICES"}
+    missing = sorted(set(read) - rows - test_only)
+    assert not missing, f"read by the sources but not in INTEGRATION.md's table: { {m: sorted(read[m]) for m in missing} }"
+    stale = sorted(rows - set(read))
+    assert not stale, f"in the table but read by nobody: {stale}"
+    # the test-only switch: named in the text, guarded by the macro in the source, absent from the shipped binary's strings
+    assert "MC_MULTI_ALLOW_REPEATED_DEVICES" in doc and read["MC_MULTI_ALLOW_REPEATED_DEVICES"] == {"mc_multi.cpp"}
+    src = open(os.path.join(csrc, "mc_multi.cpp")).read()
+    guard = src.index("#ifdef MC_MULTI_TEST_HOOKS")
+    assert guard < src.index('getenv("MC_MULTI_ALLOW_REPEATED_DEVICES")') < src.index("#endif", guard)
+    assert b"MC_MULTI_ALLOW_REPEATED_DEVICES" not in open(os.path.join(csrc, "libmc_multi.so"), "rb").read()
