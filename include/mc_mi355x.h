@@ -194,7 +194,9 @@ int mc_basket_control_mean_f64(const mc_basket_f64 *opt, double *mean);
  *   table_upload_ms  constant tables built on the host and uploaded when the inputs changed (CVA per-date rows, tiled basket matrix)
  *   launch_ms        the rest of the host time before the wait: folding the inputs, the launch calls themselves -- on the first
  *                    launch of a kernel in the process this includes loading its code object (~10 ms)
- *   kernel_ms        device time of the call's kernels (HIP events; 0 with timing off -- the kernel is then inside readback_ms)
+ *   kernel_ms        device time of the call's kernels (HIP events; 0 with timing off -- the kernel is then inside readback_ms), capped at
+ *                    the host's wait: on the first launch of a kernel the events (and mc_result.kernel_ms) also span the code-object
+ *                    load, which the host spent inside the launch call and which is counted in launch_ms
  *   readback_ms      from the last launch call to the triple on the host, minus kernel_ms: launch latency, copy / poll
  *   closing_ms       price and confidence interval on the host
  *   context_create_ms  what mc_context_create took for this context (once; NOT part of wall_ms): HIP runtime start-up on the first

@@ -1866,8 +1866,10 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
     k.setup_ms = (float)c->acc_setup_ms;
     k.table_upload_ms = (float)c->acc_table_ms;
     k.launch_ms = (float)std::max(0.0, before - c->acc_setup_ms - c->acc_table_ms);
-    k.kernel_ms = ms;
-    k.readback_ms = (float)std::max(0.0, wait - (double)ms);
+    // the events' figure, capped at the host's wait: the opening event is stamped when the idle device reaches it, so on the FIRST launch
+    // of a kernel it also spans the code-object load the host spent inside the launch call (already counted in launch_ms)
+    k.kernel_ms = (float)std::min((double)ms, wait);
+    k.readback_ms = (float)std::max(0.0, wait - (double)k.kernel_ms);
     k.closing_ms = (float)ms_between(t_result, t_closed);
     k.wall_ms = out->wall_ms;
     k.context_create_ms = c->create_ms;

@@ -32,14 +32,15 @@ def test_parts_add_up_to_the_call(eng, X):
     first = eng.vanilla(VAN, 10 ** 8, precision=X)
     k = eng.last_call_stats()
     assert k["first_call"] == 1 and k["context_create_ms"] > 0.1          # creating the context is reported, apart from the call
-    assert k["wall_ms"] == pytest.approx(first.wall_ms, rel=1e-6) and k["kernel_ms"] == pytest.approx(first.kernel_ms, rel=1e-6)
+    # the first launch of a kernel loads its code object inside the launch call: counted as launch, not (again) as kernel
+    assert k["wall_ms"] == pytest.approx(first.wall_ms, rel=1e-6) and k["kernel_ms"] <= first.kernel_ms * (1 + 1e-6)
     assert _sum(k) == pytest.approx(k["wall_ms"], rel=0.05), k
     for _ in range(3):
         e = eng.vanilla(VAN, 10 ** 8, precision=X)
         k = eng.last_call_stats()
         assert k["first_call"] == 0 and k["setup_ms"] == 0 and k["table_upload_ms"] == 0
         assert _sum(k) == pytest.approx(k["wall_ms"], rel=0.05), k
-        assert k["kernel_ms"] > 0.8 * k["wall_ms"] and k["kernel_ms"] == pytest.approx(e.kernel_ms, rel=1e-6)      # a 1e8-path call is its kernel
+        assert k["kernel_ms"] > 0.8 * k["wall_ms"] and k["kernel_ms"] == pytest.approx(e.kernel_ms, rel=0.02)      # a 1e8-path call is its kernel
         assert k["launch_ms"] < 0.05 and k["closing_ms"] < 0.01
     # timing off: no events -- the kernel's time is inside the wait (read-back), the parts still add up
     eng.set_timing(False)
