@@ -75,7 +75,7 @@ typedef struct {
     const char *devices;   /* MC_DEVICES: NULL / "" = single device */
     int antithetic;        /* MC_ANTITHETIC */
     int control;           /* MC_CONTROL_VARIATE */
-    int xorwow, grid;      /* MC_RNG = xorwow | xorwow_grid */
+    int xorwow;            /* MC_RNG = xorwow: the generator of the context (xorwow_grid is a property of each CALL: grid_mode()) */
 } Config;
 
 static const Config *config(void)
@@ -90,13 +90,7 @@ static const Config *config(void)
     c.devices = (v = getenv("MC_DEVICES")) && v[0] ? v : NULL;
     c.antithetic = (v = getenv("MC_ANTITHETIC")) && atoi(v);
     c.control = (v = getenv("MC_CONTROL_VARIATE")) && atoi(v);
-    v = getenv("MC_RNG");
-    c.xorwow = v && !strcmp(v, "xorwow");
-    c.grid = v && !strcmp(v, "xorwow_grid");
-    if (c.grid && c.devices) {
-        fprintf(stderr, "Error: MC_RNG=xorwow_grid reproduces a single-GPU launch of the reference; unset MC_DEVICES\n");
-        exit(1);
-    }
+    c.xorwow = (v = getenv("MC_RNG")) && !strcmp(v, "xorwow");
     resolved = 1;
     if (c.verbose >= 2)
         fprintf(stderr, "legacy symbols config (%s, N=%d): MC_DEVICE=%d MC_DEVICES=%s MC_RNG=%s MC_ANTITHETIC=%d MC_CONTROL_VARIATE=%d MC_SEED=%s MC_VERBOSE=%d\n",
@@ -105,7 +99,7 @@ static const Config *config(void)
 #else
                 "libmcgpu_f64",
 #endif
-                N, c.device, c.devices ? c.devices : "(unset: one device)", c.grid ? "xorwow_grid" : (c.xorwow ? "xorwow" : "philox (default)"), c.antithetic,
+                N, c.device, c.devices ? c.devices : "(unset: one device)", getenv("MC_RNG") ? getenv("MC_RNG") : "(unset: philox)", c.antithetic,
                 c.control, getenv("MC_SEED") ? getenv("MC_SEED") : "(unset: MC_DEFAULT_SEED)", c.verbose);
     return &c;
 }
@@ -217,7 +211,14 @@ static mc_context *context(void)
 /* MC_RNG=xorwow_grid: the calls go through mc_*_run_grid_* with the caller's (numBlocks, numThreads) */
 static int grid_mode(void)
 {
-    return config()->grid;
+    const char *r = getenv("MC_RNG");   /* read by every call, like MC_SEED: a process may price both ways */
+    if (!r || strcmp(r, "xorwow_grid"))
+        return 0;
+    if (config()->devices) {
+        fprintf(stderr, "Error: MC_RNG=xorwow_grid reproduces a single-GPU launch of the reference; unset MC_DEVICES\n");
+        exit(1);
+    }
+    return 1;
 }
 
 /* the seed of the next call: the *_ex entry points set it for their own call, everything else reads MC_SEED */
