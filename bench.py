@@ -794,12 +794,20 @@ def main():
         strong = strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, args.backend, barrier,
                                       args.strong_reps, args.strong_preheat_ms, full=args.detail == "full")
 
-    # who took part: one entry per rank -- local device index, its PCI bus id (hipDeviceGetPCIBusId through the C ABI), host
-    me = {"rank": rank, "device": local, "pci": mc.pci_bus_id(local), "host": os.uname().nodename, "pid": os.getpid()}
+    # who took part: one entry per rank -- local device index, its PCI bus id (hipDeviceGetPCIBusId through the C ABI), host.
+    # Exchanged as fixed-size byte tensors through dist.all_gather (the same call on RCCL and on gloo, also with ONE rank, so the
+    # one-GPU boxes exercise the exact code an 8-GPU node runs; all_gather_object would pickle and stage through the device)
+    me = {"rank": rank, "device": local, "pci": mc.pci_bus_id(local), "host": os.uname().nodename[:64], "pid": os.getpid()}
     roster = [me]
-    if grouped and world > 1:
-        roster = [None] * world
-        dist.all_gather_object(roster, me)
+    if grouped:
+        where = "cuda" if args.backend == "nccl" else "cpu"
+        raw = json.dumps(me).encode()[:255]
+        mine = torch.zeros(256, dtype=torch.uint8, device=where)
+        mine[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8, device=where)
+        every = [torch.zeros(256, dtype=torch.uint8, device=where) for _ in range(world)]
+        dist.all_gather(every, mine)
+        roster = [json.loads(bytes(t.cpu().tolist()).rstrip(b"\0").decode()) for t in every]
+        assert [m_["rank"] for m_ in roster] == list(range(world)), roster
 
     if rank == 0:
         tot = triples[W:].sum(dim=0).cpu().tolist()           # every step's triple is already all-reduced

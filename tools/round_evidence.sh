@@ -1,17 +1,19 @@
 #!/bin/bash
 # The round's evidence set on one MI355X box, every step writing under gpurun_out/ (copy what is to be judged into profiles/):
-#   gpurun --timeout 1200 -- bash tools/round_evidence.sh r04
+#   gpurun --timeout 1200 -- bash tools/round_evidence.sh r05
 # default bench line, two driver-style runs, all ten workloads, rocprofv3 kernel stats of the default command and of the
 # single-stream run (where every launch is alone on the device: the per-kernel duration), launch contention probe, smoke.
-TAG=${1:-r04}
+TAG=${1:-r05}
 O=gpurun_out
 export TMPDIR=/tmp
 set -e -o pipefail
 mkdir -p $O
 step() { echo "== $1 $(date +%T)"; }
-step "bench default";       python3 bench.py > $O/${TAG}_bench_default.log 2>&1
-step "driver style 1";      python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_style_1.log 2>&1
-step "driver style 2";      python3 bench.py --steps 20 --warmup 5 > $O/${TAG}_bench_driver_style_2.log 2>&1
+# every bench run: the ONE stdout line (<= 4 KB) into the .log, the full record next to it (--detail-file)
+step "bench default";       python3 bench.py --detail-file $O/${TAG}_bench_detail_default.json > $O/${TAG}_bench_default.log 2>&1
+step "bench detail full";   python3 bench.py --detail full --detail-file $O/${TAG}_bench_detail_full.json > $O/${TAG}_bench_full.log 2>&1
+step "driver style 1";      ( time python3 bench.py --steps 20 --warmup 5 --detail-file $O/${TAG}_bench_detail_driver_style_1.json ) > $O/${TAG}_bench_driver_style_1.log 2>&1
+step "driver style 2";      ( time python3 bench.py --steps 20 --warmup 5 --detail-file $O/${TAG}_bench_detail_driver_style_2.json ) > $O/${TAG}_bench_driver_style_2.log 2>&1
 step "all workloads";       bash tools/bench_all.sh > $O/${TAG}_bench_all_workloads.log 2>&1
 step "rocprofv3 default";   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 bench.py --cpu-seconds 0 --strong-reps 0 --c-multi-seconds 0 > $O/${TAG}_rocprofv3_bench_default.log 2>&1
 step "rocprofv3 streams 1"; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_streams1 -- python3 bench.py --streams 1 --cpu-seconds 0 --strong-reps 0 --c-multi-seconds 0 > $O/${TAG}_rocprofv3_bench_streams1.log 2>&1
@@ -21,4 +23,4 @@ rm -rf $O/prof_default $O/prof_streams1
 step "launch contention";   [ -x tools/c/launch_contention ] && tools/c/launch_contention > $O/${TAG}_launch_contention.log 2>&1
 step "smoke";               python3 -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1
 step done
-tail -1 $O/${TAG}_bench_default.log | cut -c1-400
+grep "^{" $O/${TAG}_bench_default.log | cut -c1-600
