@@ -71,7 +71,7 @@ int mc_multi_set_reduce(mc_multi *m, int mode);
  * call-number word for MC_MULTI_LINGER_US (default 5000) after its last job and then sleeps: calls shorter than that which
  * follow each other pay no wake-up, an idle handle uses no core, and a handle called more rarely than every 5 ms is served by
  * the calling thread -- a sleeping thread's job is run by the caller AT ONCE (no wake-up on the critical path; the sleepers are
- * woken after the fan-out, and only when calls come within the linger time of each other), the job of a spinning thread that
+ * woken after the fan-out, and only when calls shorter than the linger time come within the linger time of each other), the job of a spinning thread that
  * has not taken it 15 us after the hand-off (its core was taken away) likewise.  What no take-over can bound: a thread that loses
  * its core INSIDE the job it has claimed (or a runtime call that blocks) -- counted as `slow_claimed`.
  * What the threads buy, measured with timing OFF (mc_multi_set_timing(m, 0): pinned-slot read-back, what the legacy symbols

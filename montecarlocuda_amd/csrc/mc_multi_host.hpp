@@ -150,7 +150,7 @@ public:
                std::chrono::nanoseconds steal_after = std::chrono::microseconds(15), int cpus = cpus_allowed())
         : linger_(linger), steal_after_(steal_after), yield_(cpus < n + 1), workers_((size_t)n)
     {
-        last_end_ = std::chrono::steady_clock::now() - std::chrono::hours(1);
+        last_end_ = last_start_ = std::chrono::steady_clock::now() - std::chrono::hours(1);
         for (int g = 0; g < n; ++g) {
             workers_[(size_t)g].reset(new Worker);
             Worker *w = workers_[(size_t)g].get();
@@ -194,9 +194,12 @@ public:
         ++stats_.calls;
         go_.store(seq, std::memory_order_seq_cst);             // ONE word for the whole crew: every worker sees the call at once
         const auto handed = clock::now();
-        // Calls in quick succession (this one began within `linger` of the last one's end) are worth spinning for: parked
-        // workers are woken up -- AFTER the fan-out, off its critical path.  A lone call after a long pause leaves them asleep.
-        const bool busy = handed - last_end_ <= linger_;
+        // Calls in quick succession (this one began within `linger` of the last one's end, and the last one was itself shorter than
+        // `linger`: a spinning worker would have lived to see this call) are worth spinning for: parked workers are woken up --
+        // AFTER the fan-out, off its critical path.  A lone call after a long pause leaves them asleep, and so does a sequence of
+        // calls that each outlast the linger time (C4 x 10: 34 ms per device) -- they would only spin 5 ms and park again.
+        const bool busy = handed - last_end_ <= linger_ && last_duration_ <= linger_;
+        last_start_ = handed;
         const auto on_caller = [&](Worker &w, size_t g, int64_t why) {
             w.seen_ns = why;
             w.rc = fn_(ctx_, (int)g);
@@ -253,7 +256,11 @@ public:
     }
     // The caller's side of "a call has ended" (run_sharded: the estimate is closed): the next call's distance from here decides
     // whether parked workers are worth waking.
-    void call_ended() { last_end_ = std::chrono::steady_clock::now(); }
+    void call_ended()
+    {
+        last_end_ = std::chrono::steady_clock::now();
+        last_duration_ = last_end_ - last_start_;
+    }
 
 private:
     struct alignas(128) Worker {
@@ -320,7 +327,8 @@ private:
     std::chrono::nanoseconds steal_after_;
     bool yield_;
     Stats stats_;
-    std::chrono::steady_clock::time_point last_end_;
+    std::chrono::steady_clock::time_point last_end_, last_start_;
+    std::chrono::nanoseconds last_duration_{0};
     std::vector<std::unique_ptr<Worker>> workers_;
     std::atomic<bool> quit_{false};
     JobFn fn_ = nullptr;

@@ -203,6 +203,16 @@ int main()
         for (int g = 0; g < 4; ++g) by_workers = by_workers && seen[g] >= 0;
         EXPECT(by_workers && crew.stats().by_worker == 8, "the third call finds them spinning: the jobs run on the workers again");
         EXPECT(ctx.calls.load() == 16 && crew.stats().calls == 4 && crew.stats().stolen == 0, "16 jobs, each exactly once; none counted as a late take-over");
+        // calls that each outlast the linger time, back to back: the workers sleep through all of them (waking them would buy 100 ms of
+        // spinning and another sleep per call), the caller serves every job
+        std::this_thread::sleep_for(std::chrono::milliseconds(250));
+        const uint64_t wake0 = crew.stats().wakeups, served0 = crew.stats().served_parked;
+        for (int i = 0; i < 3; ++i) {
+            crew.run_all(job, &ctx, rc, clk::now(), at, seen);
+            std::this_thread::sleep_for(std::chrono::milliseconds(150));      // the "kernel": longer than the linger time
+            crew.call_ended();
+        }
+        EXPECT(crew.stats().wakeups == wake0 && crew.stats().served_parked == served0 + 12, "three back-to-back calls of 150 ms each: nobody is woken, 12 jobs served by the caller");
     }
     // ---- late workers: the caller claims their jobs (every job still runs exactly once) -------------------------------------
     {
