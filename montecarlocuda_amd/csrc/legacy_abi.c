@@ -16,16 +16,15 @@
  * Behaviour changed: the device context is created on first use and kept for the
  * life of the process (the reference allocates, seeds and frees on every call, :296-363);
  * numThreads is accepted and ignored (it only shaped the reference's reduction, :163);
- * nothing is printed on success (set MC_VERBOSE=1 for one line per call).
- * Environment: MC_DEVICE (default 0), MC_SEED (default MC_DEFAULT_SEED), MC_VERBOSE,
- * MC_DEVICES="0,1,2,3" or "all" (every call is sharded over these GPUs of the node and closed by one RCCL
- * all-reduce of the triple: include/mc_multi.h; libmc_multi.so -- and with it RCCL -- is loaded only then),
- * MC_RNG=xorwow (the reference's generator instead of Philox: mc_context_set_generator),
- * MC_RNG=xorwow_grid (the reference's generator AND its launch geometry: numBlocks and numThreads then shape the sample
- * as they do in the reference -- one XORWOW state per thread seeded blockIdx + gridDim, thread t pricing paths
- * t, t + numThreads, ... of its block; mc_*_run_grid_*, include/mc_mi355x.h; one GPU, MC_SEED is not used),
- * MC_ANTITHETIC=1 (antithetic-variates estimator instead of the reference's plain one),
- * MC_CONTROL_VARIATE=1 (dev_basketOpt only: geometric-basket control variate).
+ * nothing is printed on success.
+ * Environment (the one table: INTEGRATION.md section 1; `config()` below resolves them once, at the first call, and MC_VERBOSE=2
+ * prints the result): MC_DEVICE, MC_DEVICES (several GPUs: every call sharded and closed by one RCCL all-reduce of the triple,
+ * include/mc_multi.h; libmc_multi.so -- and with it RCCL -- is loaded only then), MC_RNG=xorwow (the reference's generator),
+ * MC_ANTITHETIC, MC_CONTROL_VARIATE, MC_VERBOSE (1: one line per call plus the stage breakdown of mc_call_stats -- the reference
+ * prints its stages from inside every call, dp/MonteCarloKernel.cu:317-323,380-386,404-409,415-427).  Read by EVERY call: MC_SEED and
+ * MC_RNG=xorwow_grid (the reference's generator AND its launch geometry: numBlocks and numThreads then shape the sample as they do
+ * in the reference -- one XORWOW state per thread seeded blockIdx + gridDim, thread t pricing paths t, t + numThreads, ... of its
+ * block; mc_*_run_grid_*; one GPU, MC_SEED is not used).
  */
 #define _GNU_SOURCE   /* dladdr */
 #include <dlfcn.h>
