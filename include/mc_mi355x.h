@@ -192,15 +192,16 @@ int mc_basket_control_mean_f64(const mc_basket_f64 *opt, double *mean);
  *                    randomSetup, paid there on EVERY call), launch-geometry states of a new (numBlocks, numThreads), buffer growth;
  *                    waited for on the device, so that it is not inside kernel_ms
  *   table_upload_ms  constant tables built on the host and uploaded when the inputs changed (CVA per-date rows, tiled basket matrix)
- *   launch_ms        the rest of the host time before the wait: folding the inputs, the launch calls themselves -- on the first
- *                    launch of a kernel in the process this includes loading its code object (~10 ms)
+ *   launch_ms        the rest of the host time before the wait: folding the inputs, the launch calls themselves (the library's code
+ *                    object is loaded by mc_context_create, not by the first launch: HIP would otherwise spend 7-10 ms inside it)
  *   kernel_ms        device time of the call's kernels (HIP events; 0 with timing off -- the kernel is then inside readback_ms), capped at
- *                    the host's wait: on the first launch of a kernel the events (and mc_result.kernel_ms) also span the code-object
- *                    load, which the host spent inside the launch call and which is counted in launch_ms
+ *                    the host's wait (the opening event is stamped at once on an idle device, so whatever the host does inside
+ *                    the launch call -- before round 5's preload: the code-object load -- would otherwise be counted twice)
  *   readback_ms      from the last launch call to the triple on the host, minus kernel_ms: launch latency, copy / poll
  *   closing_ms       price and confidence interval on the host
- *   context_create_ms  what mc_context_create took for this context (once; NOT part of wall_ms): HIP runtime start-up on the first
- *                    context of a process, stream, buffers.  first_call = 1 on the context's first synchronous call. */
+ *   context_create_ms  what mc_context_create took for this context (once; NOT part of wall_ms): HIP runtime start-up and the load
+ *                    of the code object on the first context of a process (~240 ms on a fresh box, ~5 ms for a second context),
+ *                    stream, buffers.  first_call = 1 on the context's first synchronous call. */
 typedef struct {
     float setup_ms, table_upload_ms, launch_ms, kernel_ms, readback_ms, closing_ms, wall_ms, context_create_ms;
     int first_call;

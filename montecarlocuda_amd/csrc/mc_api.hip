@@ -126,6 +126,10 @@ struct StageTimer {
 // Set-up that ran on the device (XORWOW states, jump matrices): waited for HERE, so that it is charged to set-up and not to the
 // kernel stage, and the call's opening event is recorded again behind it.
 static int setup_settle(mc_context *c, hipStream_t st);
+// Defined at the end of this file.  It must not name a kernel TEMPLATE: naming one instantiates it where it is named, the order of
+// instantiation is the order of the kernels in the code object, and the PMC profiles are stamped with the code object's bytes
+// (a first version queried vanilla_f32_kernel's attributes and moved the stamp without changing one instruction).
+static hipError_t preload_code_object();
 
 static constexpr int PROFILE_RING = 512;
 
@@ -250,6 +254,14 @@ extern "C" int mc_context_create(int device, int blocks, mc_context **out)
     if (int rc = context_allocate(c)) {
         mc_context_destroy(c);  // frees whatever was allocated before the failure (keeps the error text)
         return rc;
+    }
+    // Load the device code object NOW: HIP defers it to the first launch of any kernel of the library (7-10 ms inside that launch
+    // call: profiles/r05_multi_soak_300k_calls.log "first call of kernel 0"), so that the context's first pricing call costs what
+    // every later one costs and the one-time work is all in mc_context_create (context_create_ms of mc_call_stats).
+    if (const hipError_t e = preload_code_object(); e != hipSuccess) {
+        mc_context_destroy(c);
+        return fail(MC_ERR_HIP, "the device code object does not load on device %d (%s): this library is built for gfx950 only", device,
+                    hipGetErrorString(e));
     }
     c->create_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - create0).count();
     if (const char *v = getenv("MC_VERBOSE"))   // 2: the resolved configuration, once per context, on stderr
@@ -2418,3 +2430,11 @@ MC_DEFINE_FROM_NORMALS(f32, float)
 MC_DEFINE_GRID(f32, float)
 MC_DEFINE_FROM_NORMALS(f64, double)
 MC_DEFINE_GRID(f64, double)
+
+// A query of one kernel's attributes makes the runtime load the library's whole code object for the current device.  The kernel
+// named is a plain (non-template) one that xorwow_fill above already launches: naming it again instantiates nothing and moves nothing.
+static hipError_t preload_code_object()
+{
+    hipFuncAttributes attr;
+    return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&xorwow_init_kernel));
+}
