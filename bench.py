@@ -563,6 +563,9 @@ def main():
                     help="steps whose triples share one all-reduce (bucketed collective: 24 B x bucket); 1 = one per step")
     args = ap.parse_args()
 
+    # the host driver of these boxes supports dmabuf IPC only: without this RCCL's communicator set-up between processes fails with
+    # "hipIpcGetMemHandle: invalid argument" (it is exported on the boxes already; kept for any environment built by hand)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     import montecarlocuda_amd as mc
