@@ -1807,6 +1807,8 @@ static int run_sync(mc_context *c, uint64_t n, double discount, mc_result *out, 
     const auto ms_between = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     // a caller that did part of the call's work before coming here (the staged launch-geometry form) has set call_t0
     const auto wall0 = c->call_t0_valid ? c->call_t0 : clock::now();
+    if (!c->call_t0_valid)   // what earlier calls of other kinds (per-path dumps, Greeks, test hooks) left in the accumulators is not this call's
+        c->acc_setup_ms = c->acc_table_ms = 0;
     c->call_t0_valid = false;
     HIPCHK(hipSetDevice(c->device));
     c->armed = false;   // mc_context_arm_direct applies to the next mc_*_launch_* only: a synchronous call in between cancels it
@@ -2079,6 +2081,7 @@ static int grid_run_staged(mc_context *c, int num_blocks, int num_threads, uint6
 {
     const uint64_t n = (uint64_t)num_blocks * paths_per_block;
     c->call_t0 = std::chrono::steady_clock::now(), c->call_t0_valid = !h_values;   // the normals pass below is part of the call's wall time
+    c->acc_setup_ms = c->acc_table_ms = 0;
     HIPCHK(hipSetDevice(c->device));
     if (int rc = ensure_ext(c, padded * sizeof(Real))) return rc;
     const uint32_t *states = nullptr;
