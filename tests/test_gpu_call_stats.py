@@ -120,3 +120,20 @@ def test_legacy_symbols_print_the_stages_under_MC_VERBOSE(X):
                            env=dict(os.environ, MC_VERBOSE="2", MC_DEVICES="0,0", MC_MULTI_REDUCE="host"))
     assert three.returncode == 0, three.stdout + three.stderr
     assert "mc_multi config: devices=[0,0] reduce=host" in three.stderr and "linger_us=5000" in three.stderr
+
+
+def test_staged_launch_geometry_form_counts_its_normals_pass(eng):
+    """The staged form of the launch-geometry mode (normals through HBM, then the engine's kernels; kept as the checker and for shapes
+    without a fused kernel) does part of its work before the pricing launch: the call's wall time starts at ITS entry, the parts
+    still add up, and what per-path dumps or other calls did before is not charged to it."""
+    eng.set_grid_form("staged")
+    eng.vanilla_paths(VAN, 1000, precision="f64")          # a call of another kind first (allocates the dump buffer)
+    a = eng.run_grid("vanilla", VAN, 64, 128, 4000, "f64")
+    k1 = eng.last_call_stats()
+    b = eng.run_grid("vanilla", VAN, 64, 128, 4000, "f64")
+    k2 = eng.last_call_stats()
+    assert a.expected == b.expected and k1["setup_ms"] > 0.2 and k2["setup_ms"] == 0
+    for k in (k1, k2):
+        assert _sum(k) == pytest.approx(k["wall_ms"], rel=0.05), k
+    assert k2["wall_ms"] == pytest.approx(b.wall_ms, rel=1e-6) and k2["launch_ms"] > k2["kernel_ms"] * 0.05      # the normals pass is host-visible time
+    eng.set_grid_form("auto")
