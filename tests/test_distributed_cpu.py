@@ -67,3 +67,30 @@ def test_two_rank_sharded_estimate_equals_single_rank(po, X):
     assert n == TOTAL
     assert s == pytest.approx(whole["sum"], rel=1e-13) and s2 == pytest.approx(whole["sum2"], rel=1e-13)
     assert e == pytest.approx(whole["expected"], rel=1e-13) and ci == pytest.approx(whole["confidence"], rel=1e-12)
+
+
+def test_eight_rank_sharded_estimate_equals_single_rank(po):
+    """The node's own world size (8 ranks, gloo on the CPU): contiguous disjoint shards of an odd total that cover it, one reduced
+    estimate on every rank, equal to the single-process estimate over the whole range -- the bookkeeping of the 8-GPU run, which no
+    box here can execute on devices."""
+    X, world = "f64", 8
+    ctx = tmp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, X, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    nxt = 0
+    for rank, (first, count), *_ in got:
+        assert first == nxt and count in (TOTAL // 8, TOTAL // 8 + 1)
+        nxt = first + count
+    assert nxt == TOTAL and [g[0] for g in got] == list(range(8))
+    assert all(g[2:] == got[0][2:] for g in got)
+    _, whole = po.dev_vanilla(X, VAN, SEED, 0, TOTAL, want_paths=False)
+    e, ci, s, s2, n = got[0][2:]
+    assert n == TOTAL and s == pytest.approx(whole["sum"], rel=1e-13) and s2 == pytest.approx(whole["sum2"], rel=1e-13)
+    assert e == pytest.approx(whole["expected"], rel=1e-13) and ci == pytest.approx(whole["confidence"], rel=1e-12)
