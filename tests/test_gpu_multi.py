@@ -36,15 +36,17 @@ def test_c_multi_device_path_matches_single_device(tmp_path):
         assert "all rccl" in out.stdout
 
 
-def test_grouped_allreduce_call_sequence_with_three_ranks_through_a_test_double(tmp_path):
+@pytest.mark.parametrize("ranks", [3, 8])
+def test_grouped_allreduce_call_sequence_through_a_test_double(tmp_path, ranks):
     """The G > 1 control flow of run_sharded's collective branch -- G calls of ncclAllReduce inside one group, rank g's own send /
     receive buffers, stream and communicator, the publish of device 0's reduced triple, the cross-check against the host sum --
-    executed with THREE ranks on the one GPU.  Real RCCL refuses a repeated device, so a test double of its six entry points
-    (tests/cpp/rccl_mock.hip: event-ordered sum of the ranks' buffers in rank order) is preloaded in front of librccl.so and
-    MC_MULTI_ALLOW_REPEATED_DEVICES=1 lifts the library's own duplicate check -- in a TEST BUILD of the library only
-    (`make libmc_multi_testhooks`: -DMC_MULTI_TEST_HOOKS, built here into a temporary directory that goes in front on
-    LD_LIBRARY_PATH; the shipped libmc_multi.so has no such switch, see the next test).  This proves the call sequence and the
-    indexing, NOT RCCL or xGMI: the multi-rank collective itself stays unexercised on one-GPU boxes."""
+    executed with THREE and with EIGHT ranks (the node's own size: eight launcher threads, nine pinned slots) on the one GPU.
+    Real RCCL refuses a repeated device, so a test double of its six entry points (tests/cpp/rccl_mock.hip: event-ordered sum of the
+    ranks' buffers in rank order) is preloaded in front of librccl.so and MC_MULTI_ALLOW_REPEATED_DEVICES=1 lifts the library's own
+    duplicate check -- in a TEST BUILD of the library only (`make libmc_multi_testhooks`: -DMC_MULTI_TEST_HOOKS, built here into a
+    temporary directory that goes in front on LD_LIBRARY_PATH; the shipped libmc_multi.so has no such switch, see the next test).
+    This proves the call sequence and the indexing, NOT RCCL or xGMI: the multi-rank collective itself stays unexercised on
+    one-GPU boxes."""
     mock = tmp_path / "librccl_mock.so"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC",
                            os.path.join(ROOT, "tests", "cpp", "rccl_mock.hip"), "-o", str(mock)])
@@ -53,16 +55,18 @@ def test_grouped_allreduce_call_sequence_with_three_ranks_through_a_test_double(
     hooks.mkdir()
     subprocess.check_call(["make", "-C", CSRC, "libmc_multi_testhooks", f"TESTHOOKS_OUT={hooks / 'libmc_multi.so'}"], stdout=subprocess.DEVNULL)
     env = dict(os.environ, LD_PRELOAD=str(mock), MC_MULTI_ALLOW_REPEATED_DEVICES="1", RCCL_MOCK_VERBOSE="1", MC_MULTI_LINGER_US="2000",
-               LD_LIBRARY_PATH=f"{hooks}:{os.environ.get('LD_LIBRARY_PATH', '')}")
+               MULTI_CHECK_RANKS=str(ranks), LD_LIBRARY_PATH=f"{hooks}:{os.environ.get('LD_LIBRARY_PATH', '')}")
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=900, env=env)
     print(out.stdout[-6000:])
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "all checks passed" in out.stdout and "MISMATCH" not in out.stdout
-    assert "{0,0,0} mock collective" in out.stdout and "grouped all-reduce through the preloaded test double" in out.stdout
-    assert "communicator set of 3 ranks" in out.stderr          # the double, not RCCL, served the three-rank handle
+    rep = "{" + ",".join(["0"] * ranks) + "}"
+    assert f"{rep} mock collective" in out.stdout and "grouped all-reduce through the preloaded test double" in out.stdout
+    assert f"communicator set of {ranks} ranks" in out.stderr          # the double, not RCCL, served the repeated-device handle
+    assert f"launcher threads: {rep} default {ranks}," in out.stdout    # one launcher thread per rank (the boxes grant 16 CPUs)
     groups = re.findall(r"rccl_mock: (\d+) grouped all-reduces of (\d+) calls in all", out.stderr)
-    # hundreds of grouped calls, and more all-reduce calls than groups: groups of three went through (the {0} handle's are of one)
-    assert groups and max(int(g) for g, _ in groups) > 100 and max(int(c) - int(g) for g, c in groups) > 200, out.stderr[-2000:]
+    # hundreds of grouped calls, and more all-reduce calls than groups: groups of `ranks` went through (the {0} handle's are of one)
+    assert groups and max(int(g) for g, _ in groups) > 100 and max(int(c) - int(g) for g, c in groups) > 100 * (ranks - 1), out.stderr[-2000:]
 
 
 def test_shipped_library_has_no_repeated_devices_switch(tmp_path):
