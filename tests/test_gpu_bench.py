@@ -218,3 +218,22 @@ def test_bench_two_ranks_rccl_one_rank_per_device(tmp_path):
     assert rows["C4"]["paths_per_gpu"] == 5 * 10 ** 8 and rows["C4"]["paths_priced"] == 10 ** 9 and 9.70 < rows["C4"]["value"] < 9.74
     assert rows["C5"]["paths_priced"] == 10 ** 7 and 0.1895 < rows["C5"]["value"] < 0.1905
     assert line["value"] > 2e11          # two devices, weak scaling: no less than one device's worth
+
+
+def test_bench_four_ranks_share_the_gpu(tmp_path):
+    """Four ranks on the one GPU (gloo; the box admits six processes on the card): the roster has four entries, every path of the
+    strong rows is priced exactly once over mc_shard_range(total, rank, 4), the weak headline counts four shards per step."""
+    tmp = tmp_path / "d.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(_port()), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--steps", "20", "--warmup", "2",
+           "--regions", "2", "--cpu-seconds", "0", "--fp64-steps", "0", "--strong-reps", "2", "--strong-preheat-ms", "20", "--detail-file", str(tmp)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = _json_line(out.stdout)
+    d = _detail(line, tmp)
+    assert line["n_gpus"] == 4 and line["world_size"] == 4 and [r["rank"] for r in line["ranks"]] == [0, 1, 2, 3]
+    assert line["paths_priced"] == 2 * 20 * 4 * 10 ** 8 and line["config"]["global_paths_per_step"] == 4 * 10 ** 8
+    assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]
+    rows = {x["config"]: x for x in d["strong"]["rows"]}
+    assert rows["C4"]["paths_per_gpu"] == 25 * 10 ** 7 and rows["C4"]["paths_priced"] == 10 ** 9 and 9.70 < rows["C4"]["value"] < 9.74
+    assert rows["C5"]["paths_per_gpu"] == 25 * 10 ** 5 and rows["C5"]["paths_priced"] == 10 ** 7 and 0.1895 < rows["C5"]["value"] < 0.1905
