@@ -130,6 +130,76 @@ int main(int argc, char **argv)
     // third set: a filler that keeps the vector pipes FULL between the calls (8 independent FMA chains per lane, 8 waves per SIMD)
     const Mode full_set[] = {{"off", 0, 0, 64, 0}, {"valu_full_yield", 4096, 2, 256, 1}, {"off", 0, 0, 64, 0}};
     const bool third = argc > 1 && !strcmp(argv[1], "full");
+    // fourth set ("pulse"): no resident kernel at all -- during the gap the host launches a SHORT burst of the pricing kernel itself
+    // (65 536 paths = one wave-trip on every SIMD, ~50 us at full intensity) every `period` us: does a few per cent of duty hold the state?
+    if (argc > 1 && !strcmp(argv[1], "pulse")) {
+        const uint64_t n = 1250000ull;
+        auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        printf("%-22s %8s %12s %10s %10s %10s\n", "mode", "gap ms", "kernel med", "min", "max", "pulses/gap");
+        for (int period_us : {0, 2000, 1000, 500, 250, 0}) {
+            for (uint64_t pulse_paths : {65536ull, 262144ull}) {
+                if (period_us == 0 && pulse_paths != 65536ull) continue;
+                if (preheat(c, d_triple, 300)) return 1;
+                for (double gap : {0.0, 5.0, 20.0, 100.0}) {
+                    std::vector<double> k;
+                    double pulses = 0;
+                    for (int i = 0; i < 10; ++i) {
+                        const double g0 = now_ms();
+                        int np = 0;
+                        while (now_ms() - g0 < gap) {
+                            if (period_us) {
+                                MC(mc_cva_launch_f64(c, &CVA, MC_DEFAULT_SEED, (1ull << 41) + (uint64_t)np * pulse_paths, pulse_paths, d_triple, mc_context_stream(c)));
+                                ++np;
+                                usleep((useconds_t)period_us);
+                            } else {
+                                usleep((useconds_t)(gap * 1e3));
+                            }
+                        }
+                        pulses += np;
+                        mc_result r;
+                        MC(mc_cva_run_f64(c, &CVA, MC_DEFAULT_SEED, (uint64_t)i * n, n, &r));
+                        k.push_back(r.kernel_ms * 1e3);
+                    }
+                    char name[64];
+                    snprintf(name, sizeof name, period_us ? "pulse %llu / %d us" : "off", (unsigned long long)pulse_paths, period_us);
+                    printf("%-22s %8.1f %12.1f %10.1f %10.1f %10.1f\n", name, gap, med(k), *std::min_element(k.begin(), k.end()),
+                           *std::max_element(k.begin(), k.end()), pulses / 10);
+                    fflush(stdout);
+                }
+                usleep(300000);
+                smi(period_us ? "after a pulsed sweep (idle now)" : "off");
+            }
+        }
+        // what the pulses cost: board power in the middle of 1.5 s of pulsing (rocm-smi as a child process), and of the kernel back to back
+        for (int period_us : {0, 1000, 500, 250, -1}) {
+            const double t0p = now_ms();
+            bool told = false;
+            int np = 0;
+            while (now_ms() - t0p < 1500) {
+                if (period_us != 0) {
+                    MC(mc_cva_launch_f64(c, &CVA, MC_DEFAULT_SEED, (1ull << 42) + (uint64_t)np * 262144ull, period_us < 0 ? 10000000ull : 262144ull, d_triple,
+                                         mc_context_stream(c)));
+                    ++np;
+                    if (period_us > 0) usleep((useconds_t)period_us);
+                    else HIP(hipStreamSynchronize((hipStream_t)mc_context_stream(c)));
+                } else {
+                    usleep(1000);
+                }
+                if (!told && now_ms() - t0p > 750) {
+                    char tag[96];
+                    snprintf(tag, sizeof tag, period_us < 0 ? "1e7-path launches back to back (full load)" : period_us ? "262144-path pulse every %d us sleep" : "idle", period_us);
+                    smi(tag);
+                    told = true;
+                }
+            }
+            HIP(hipStreamSynchronize((hipStream_t)mc_context_stream(c)));
+            printf("   ... %d launches in 1.5 s\n", np);
+        }
+        hipStreamDestroy(side);
+        hipFree(d_triple), hipFree(d_sink), hipHostFree(stop);
+        mc_context_destroy(c);
+        return 0;
+    }
     const std::vector<Mode> modes = third ? std::vector<Mode>(full_set, full_set + 3)
                                   : second ? std::vector<Mode>(heavy_set, heavy_set + 4) : std::vector<Mode>(first_set, first_set + 6);
     const uint64_t n = 1250000ull;
