@@ -63,7 +63,8 @@ def test_grouped_allreduce_call_sequence_through_a_test_double(tmp_path, ranks):
     rep = "{" + ",".join(["0"] * ranks) + "}"
     assert f"{rep} mock collective" in out.stdout and "grouped all-reduce through the preloaded test double" in out.stdout
     assert f"communicator set of {ranks} ranks" in out.stderr          # the double, not RCCL, served the repeated-device handle
-    assert f"launcher threads: {rep} default {ranks}," in out.stdout    # one launcher thread per rank (the boxes grant 16 CPUs)
+    # one launcher thread per rank (the boxes grant 16 CPUs) -- or none at all, by design, on a grant of fewer CPUs than ranks + 1
+    assert f"launcher threads: {rep} default {ranks}," in out.stdout or (f"launcher threads: {rep} default 0," in out.stdout and "fewer CPUs" in out.stdout)
     groups = re.findall(r"rccl_mock: (\d+) grouped all-reduces of (\d+) calls in all", out.stderr)
     # hundreds of grouped calls, and more all-reduce calls than groups: groups of `ranks` went through (the {0} handle's are of one)
     assert groups and max(int(g) for g, _ in groups) > 100 and max(int(c) - int(g) for g, c in groups) > 100 * (ranks - 1), out.stderr[-2000:]
