@@ -82,6 +82,35 @@ __global__ void keep_warm_kernel(const volatile int *stop, long long ticks, int 
         *sink = x;
 }
 
+// A stand-in for the pricing load that can be told to leave: fp64 FMAs, 32 x 32 -> 64 multiplies and fp32 transcendentals in about
+// the kernels' proportions, on every SIMD, until `ticks` of the 100 MHz clock have passed OR a word in DEVICE memory no longer holds
+// the value the launcher saw (the owner's stream writes it right before its own kernel: hipStreamWriteValue32).
+__global__ __launch_bounds__(256) void pulse_kernel(const uint32_t *word, uint32_t seen, long long ticks, double *sink)
+{
+    const long long t0 = wall_clock64();
+    double a = 1.0 + threadIdx.x * 1e-6, b = 0.5, c = 0.25, d = 2.0;
+    uint64_t x = 0x9E3779B97F4A7C15ull + threadIdx.x + blockIdx.x * 256u;
+    float f = 1.0f + threadIdx.x * 1e-3f;
+    for (;;) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            a = __builtin_fma(a, 0.9999999, b);
+            b = __builtin_fma(b, 1.0000001, -c);
+            c = __builtin_fma(c, 0.9999998, d * 1e-9);
+            d = __builtin_fma(d, 1.0000002, -a * 1e-9);
+            x = (uint64_t)(uint32_t)x * 0xD2511F53ull + (x >> 32);
+            x = (uint64_t)(uint32_t)x * 0xCD9E8D57ull + (x >> 32);
+            f = __builtin_amdgcn_exp2f(f * 0.001f) + __builtin_amdgcn_logf(f + 2.0f);
+        }
+        if (wall_clock64() - t0 >= ticks)
+            break;
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seen)
+            break;
+    }
+    if (a + b + c + d + (double)x + f == 12345.678)
+        *sink = a;
+}
+
 static int preheat(mc_context *c, double *d_triple, double ms)
 {
     const double t0 = now_ms();
@@ -132,6 +161,73 @@ int main(int argc, char **argv)
     const bool third = argc > 1 && !strcmp(argv[1], "full");
     // fourth set ("pulse"): no resident kernel at all -- during the gap the host launches a SHORT burst of the pricing kernel itself
     // (65 536 paths = one wave-trip on every SIMD, ~50 us at full intensity) every `period` us: does a few per cent of duty hold the state?
+    // fifth set ("pulse2"): the same pulsing with the custom kernel above instead of the CVA kernel -- does a stand-in hold the state, and
+    // does the owner's stream-ordered write make it leave?  Bursts of `burst_us` every `period_us`; the real call first writes the word.
+    if (argc > 1 && !strcmp(argv[1], "pulse2")) {
+        const uint64_t n = 1250000ull;
+        auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        uint32_t *d_word = nullptr;
+        double *d_sink2 = nullptr;
+        HIP(hipMalloc(&d_word, 4));
+        HIP(hipMalloc(&d_sink2, 8));
+        HIP(hipMemset(d_word, 0, 4));
+        hipStream_t own = (hipStream_t)mc_context_stream(c);
+        uint32_t gen = 0;
+        printf("%-26s %8s %12s %10s %10s %10s %12s\n", "mode", "gap ms", "kernel med", "min", "max", "pulses/gap", "wall med us");
+        struct P { int period_us, burst_us; };
+        for (P p : {P{0, 0}, P{500, 200}, P{250, 200}, P{500, 400}, P{1000, 400}, P{0, 0}}) {
+            if (preheat(c, d_triple, 300)) return 1;
+            for (double gap : {0.0, 5.0, 20.0, 100.0}) {
+                std::vector<double> k, w;
+                double pulses = 0;
+                for (int i = 0; i < 10; ++i) {
+                    const double g0 = now_ms();
+                    int np = 0;
+                    while (now_ms() - g0 < gap) {
+                        if (p.period_us) {
+                            hipLaunchKernelGGL(pulse_kernel, dim3(2048), dim3(256), 0, side, d_word, gen, (long long)p.burst_us * 100, d_sink2);
+                            ++np;
+                            usleep((useconds_t)p.period_us);
+                        } else {
+                            usleep((useconds_t)(gap * 1e3));
+                        }
+                    }
+                    pulses += np;
+                    // the real call: a pulse may be in flight (it was launched up to `period` ago and lasts `burst`): tell it to leave
+                    const double tc = now_ms();
+                    ++gen;
+                    HIP(hipStreamWriteValue32(own, d_word, gen, 0));
+                    mc_result r;
+                    MC(mc_cva_run_f64(c, &CVA, MC_DEFAULT_SEED, (uint64_t)i * n, n, &r));
+                    w.push_back((now_ms() - tc) * 1e3);
+                    k.push_back(r.kernel_ms * 1e3);
+                }
+                char name[64];
+                snprintf(name, sizeof name, p.period_us ? "custom burst %d / %d us" : "off", p.burst_us, p.period_us);
+                printf("%-26s %8.1f %12.1f %10.1f %10.1f %10.1f %12.1f\n", name, gap, med(k), *std::min_element(k.begin(), k.end()),
+                       *std::max_element(k.begin(), k.end()), pulses / 10, med(w));
+                fflush(stdout);
+            }
+            if (p.period_us) {     // board power while pulsing
+                const double t0p = now_ms();
+                bool told = false;
+                while (now_ms() - t0p < 1500) {
+                    hipLaunchKernelGGL(pulse_kernel, dim3(2048), dim3(256), 0, side, d_word, gen, (long long)p.burst_us * 100, d_sink2);
+                    usleep((useconds_t)p.period_us);
+                    if (!told && now_ms() - t0p > 750) {
+                        char tag[64];
+                        snprintf(tag, sizeof tag, "custom burst %d / %d us", p.burst_us, p.period_us);
+                        smi(tag);
+                        told = true;
+                    }
+                }
+                HIP(hipStreamSynchronize(side));
+            }
+        }
+        hipStreamDestroy(side);
+        mc_context_destroy(c);
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "pulse")) {
         const uint64_t n = 1250000ull;
         auto med = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
