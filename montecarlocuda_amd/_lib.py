@@ -84,7 +84,7 @@ EXPORTS = ["mc_last_error", "mc_device_count", "mc_device_pci_bus_id", "mc_conte
            "mc_context_blocks", "mc_context_stream", "mc_context_info", "mc_context_last_launch", "mc_context_last_call_stats", "mc_context_describe", "mc_context_profile", "mc_context_profile_read",
            "mc_context_set_antithetic", "mc_context_set_control_variate", "mc_context_set_finish", "mc_context_set_timing",
            "mc_context_order", "mc_context_idle", "mc_context_arm_direct", "mc_context_publish", "mc_context_set_generator",
-           "mc_context_set_normals", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range",
+           "mc_context_set_normals", "mc_context_set_cva_date_lanes", "mc_basket_control_mean_f32", "mc_basket_control_mean_f64", "mc_closing", "mc_shard_range",
            "mc_chol_f32", "mc_chol_f64", "mc_factor_from_cov_f32", "mc_factor_from_cov_f64"]
 TEST_EXPORTS = ["mc_xorwow_words", "mc_grid_normals", "mc_context_set_grid_form"]
 for _x in ("f32", "f64"):
@@ -126,6 +126,7 @@ def _declare(L: C.CDLL) -> C.CDLL:
     L.mc_context_publish.argtypes = [ctx, C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(C.c_double))]
     L.mc_context_set_generator.argtypes = [ctx, C.c_int, C.c_uint64]
     L.mc_context_set_normals.argtypes = [ctx, C.c_int]
+    L.mc_context_set_cva_date_lanes.argtypes = [ctx, C.c_int]
     L.mc_grid_normals.argtypes = [ctx, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_float)]
     L.mc_context_set_grid_form.argtypes = [ctx, C.c_int]
     L.mc_xorwow_words.argtypes = [ctx, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]

@@ -99,6 +99,8 @@ struct mc_context {
     void *d_ext = nullptr;        // the context's buffer for them, grown on demand
     size_t d_ext_bytes = 0;
     bool antithetic = false;      // estimator: plain (reference) or antithetic variates
+    // CVA: lanes per path (mc_launch_shape.hpp: cva_plan).  0 = by call size, 1 = cva_kernel only, 2 ... 64 = cva_dates_kernel for the whole call
+    int cva_date_lanes = 0;
     bool control = false;         // baskets: geometric-basket control variate
     // sampled device timing of the simulation kernels (mc_context_profile)
     int last_grid = 0, last_group = 0;   // shape of the most recent simulation launch (mc_context_last_launch)
@@ -220,6 +222,7 @@ static int context_allocate(mc_context *c)
         c->fused = strcmp(e, "kernel") != 0;
     if (const char *e = getenv("MC_F64_NORMALS"))   // "f32": the reference's dp arithmetic (mc_context_set_normals)
         c->normals_f32 = strcmp(e, "f32") == 0;
+    c->cva_date_lanes = env_int("MC_CVA_DATE_LANES", 0, 0, 64);   // mc_context_set_cva_date_lanes
     return MC_OK;
 }
 
@@ -297,11 +300,13 @@ extern "C" int mc_context_describe(const mc_context *c, char *buf, int len)
         return fail(MC_ERR_INVALID, "mc_context_describe: bad argument");
     snprintf(buf, (size_t)len,
              "mc_context config: device=%d \"%s\" CUs=%d clock_mhz=%d blocks=%d finish=%s f64_normals=%s rng=%s antithetic=%d control_variate=%d timing=%d "
-             "grid_form=%s basket_static_max=f32:%d,f64:%d basket_tiled_min=%d basket_mfma=%d grid_sub=%d(0=auto) vanilla_units_per_lane=%d created_in_ms=%.1f",
+             "grid_form=%s basket_static_max=f32:%d,f64:%d basket_tiled_min=%d basket_mfma=%d grid_sub=%d(0=auto) vanilla_units_per_lane=%d cva_date_lanes=%d(0=auto) "
+             "created_in_ms=%.1f",
              c->device, c->name, c->compute_units, c->clock_mhz, c->blocks, c->fused ? "fused" : "kernel", c->normals_f32 ? "f32" : "native",
              c->rng == MC_RNG_XORWOW ? "xorwow" : "philox", (int)c->antithetic, (int)c->control, (int)c->timing,
              c->grid_form == MC_GRID_FORM_STAGED ? "staged" : (c->grid_form == MC_GRID_FORM_FUSED ? "fused" : "auto"), basket_static_max<float>(),
-             basket_static_max<double>(), basket_tiled_min(), (int)basket_mfma(), env_int("MC_GRID_SUB", 0, 0, 32), vanilla_units_per_lane(), c->create_ms);
+             basket_static_max<double>(), basket_tiled_min(), (int)basket_mfma(), env_int("MC_GRID_SUB", 0, 0, 32), vanilla_units_per_lane(), c->cva_date_lanes,
+             c->create_ms);
     return MC_OK;
 }
 
@@ -370,6 +375,14 @@ extern "C" int mc_context_set_normals(mc_context *c, int mode)
     if (!c || (mode != MC_NORMALS_NATIVE && mode != MC_NORMALS_F32))
         return fail(MC_ERR_INVALID, "mc_context_set_normals: bad argument");
     c->normals_f32 = mode == MC_NORMALS_F32;
+    return MC_OK;
+}
+
+extern "C" int mc_context_set_cva_date_lanes(mc_context *c, int lanes)
+{
+    if (!c || lanes < 0 || lanes > 64 || (lanes & (lanes - 1)) != 0)
+        return fail(MC_ERR_INVALID, "mc_context_set_cva_date_lanes: lanes must be 0 (by call size), 1, 2, 4, ... 64");
+    c->cva_date_lanes = lanes;
     return MC_OK;
 }
 
@@ -1648,6 +1661,14 @@ static int cva_table_ready(mc_context *c, const typename CvaIn<Real>::type *v, h
     return MC_OK;
 }
 
+// workgroups of the date-parallel part of a launch over `count` paths at 2^log2_lanes lanes per path: one lane-group per path
+// until the grid reaches the CVA cap (12 per CU), grid-stride beyond
+static int grid_for_cva_dates(int blocks, uint32_t count, int log2_lanes)
+{
+    const uint64_t need = (((uint64_t)count << log2_lanes) + GROUP - 1) / GROUP, cap = (uint64_t)blocks * GRID_SCALE_CVA / 2;
+    return (int)(need < cap ? (need ? need : 1) : cap);
+}
+
 template <class Real>
 static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint64_t seed, uint64_t first, uint64_t n,
                        double *d_triple, hipStream_t st, Real *out)
@@ -1655,22 +1676,64 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     if (int rc = begin_call(c, st)) return rc;
     CvaArgs<Real> args;
     if (int rc = cva_table_ready<Real>(c, v, st, args)) return rc;
-    std::vector<Segment> segs;
-    if (int rc = plan_segments(first, n, segs)) return rc;
-    const int scale = (c->rng == MC_RNG_XORWOW && !c->ext) ? 2 : GRID_SCALE_CVA;
+    const bool xorwow = c->rng == MC_RNG_XORWOW && !c->ext;
+    // The cut between one lane per path and the date-parallel form (mc_launch_shape.hpp: cva_plan).  The date-parallel form
+    // needs a generator a path can be entered in the middle of (XORWOW is one sequence per lane) and the per-date table in
+    // LDS.  A call with BOTH parts is one launch of cva_split_kernel: compiled for the plain estimator on the counter-based
+    // generators, one segment each (the external array is indexed from the call's first path), and a table small enough not
+    // to cost the one-lane-per-path workgroups their residency (24 KB: 4 workgroups per CU beside the fp64 math tables)
+    const int n_dates = args.n_bs + args.last_intrinsic;
+    const size_t table_lds = (size_t)n_dates * sizeof(CvaStep<Real>);
+    // (calls on an external array -- the from-normals hooks, the staged launch-geometry form -- are compared bit for bit with
+    // one-lane-per-path kernels: they go date-parallel only when the setting forces it)
+    const int lanes_setting = (c->ext && c->cva_date_lanes == 0) ? 1 : c->cva_date_lanes;
+    CvaPlan plan = cva_plan(lanes_setting, n, n_dates, c->compute_units, !xorwow && table_lds <= 48 * 1024);
+    std::vector<Segment> segs, tail_segs;
+    if (plan.main_paths && plan.tail_paths) {
+        bool split = !c->antithetic && !c->ext && table_lds <= 24 * 1024;
+        if (split) {
+            if (int rc = plan_segments(first, plan.main_paths, segs)) return rc;
+            if (int rc = plan_segments(first + plan.main_paths, plan.tail_paths, tail_segs)) return rc;
+            split = segs.size() == 1 && tail_segs.size() == 1;
+        }
+        if (!split)
+            plan = CvaPlan{n, 0, 0}, segs.clear(), tail_segs.clear();
+    }
+    const bool fused_split = plan.main_paths && plan.tail_paths;
+    if (!fused_split) {
+        if (plan.main_paths)
+            if (int rc = plan_segments(first, plan.main_paths, segs)) return rc;
+        if (plan.tail_paths)
+            if (int rc = plan_segments(first, plan.tail_paths, tail_segs)) return rc;
+    }
+    const int scale = xorwow ? 2 : GRID_SCALE_CVA;
     int total = 0, slot = 0;
     for (const Segment &s : segs)
         total += grid_for(c->blocks, s.count, scale);
+    for (const Segment &s : tail_segs)
+        total += grid_for_cva_dates(c->blocks, s.count, plan.log2_lanes);
     Tail t = make_tail(c, total, 1.0, 1.0, n, d_triple);
     uint64_t done = 0;
     ProfileScope prof(c);
-    if (c->ext && (segs.size() > 1 || first != 0))
+    if (c->ext && (segs.size() + tail_segs.size() > 1 || first != 0))
         return fail(MC_ERR_INVALID, "external normals: one segment starting at path 0");
-    if (c->rng == MC_RNG_XORWOW && !c->ext) {
+    if (xorwow) {
         if (sizeof(Real) == 8 && c->normals_f32)
             return fail(MC_ERR_UNSUPPORTED, "fp32 normals in the fp64 kernels are implemented for the Philox generator");
         if (int rc = xorwow_one_segment(segs)) return rc;
         if (int rc = xorwow_ready(c, seed, st)) return rc;
+    }
+    if (fused_split) {
+        const Work w = context_work(c, seed, segs[0], 0, 0), wt = context_work(c, seed, tail_segs[0], 0, 0);
+        const int g_tail = grid_for_cva_dates(c->blocks, tail_segs[0].count, plan.log2_lanes);
+        Real *dst = out, *dst_tail = out ? out + segs[0].count : (Real *)nullptr;
+        constexpr unsigned ALLOW = GEN_PHILOX | (sizeof(Real) == 8 ? GEN_F32N : 0);
+        if (int rc = with_gen<ALLOW>(gen_of(c, w, sizeof(Real)), [&](auto tag) {
+                launch_sim_lds(prof, cva_split_kernel<Real, CVA_DATES_CH, typename decltype(tag)::type>, total, table_lds, st, t, args, w, wt,
+                               (uint32_t)g_tail, (uint32_t)plan.log2_lanes, dst, dst_tail);
+            }))
+            return rc;
+        return finish_call(c, t, total, st);
     }
     for (const Segment &s : segs) {
         const Work w = context_work(c, seed, s, 0, 0);
@@ -1680,6 +1743,20 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         constexpr unsigned ALLOW = GEN_PHILOX | GEN_XORWOW | GEN_EXTERNAL | (sizeof(Real) == 8 ? GEN_F32N : 0);
         if (int rc = with_anti_gen<ALLOW>(c->antithetic, gen_of(c, w, sizeof(Real)), [&](auto a, auto tag) {
                 launch_sim(prof, cva_kernel<Real, decltype(a)::value, typename decltype(tag)::type>, g, st, t, args, w, dst);
+            }))
+            return rc;
+        slot += g;
+        done += s.count;
+    }
+    for (const Segment &s : tail_segs) {
+        const Work w = context_work(c, seed, s, 0, 0);
+        const int g = grid_for_cva_dates(c->blocks, s.count, plan.log2_lanes);
+        t.slot_base = t.ticket_base = (uint32_t)slot;
+        Real *dst = out ? out + done : (Real *)nullptr;
+        constexpr unsigned ALLOW = GEN_PHILOX | GEN_EXTERNAL | (sizeof(Real) == 8 ? GEN_F32N : 0);
+        if (int rc = with_anti_gen<ALLOW>(c->antithetic, gen_of(c, w, sizeof(Real)), [&](auto a, auto tag) {
+                launch_sim_lds(prof, cva_dates_kernel<Real, CVA_DATES_CH, decltype(a)::value, typename decltype(tag)::type>, g, table_lds, st, t,
+                               args, w, (uint32_t)plan.log2_lanes, dst);
             }))
             return rc;
         slot += g;

@@ -1149,9 +1149,8 @@ __device__ __forceinline__ float bs_exposure(float ln2_spot, float W, const CvaS
 // fp32, TWO consecutive dates of one path in the halves of every packed op (the form above packs d1, d2 of one
 // date): the same operations per date, but the spot's exponent, A, the selects' subtractions and the dp-weighted
 // accumulation now issue packed as well.  `row` = 12 floats {g, e1, e2, xk, disc, dp} x {date, next date}.
-__device__ __forceinline__ f2 bs_exposure_dates(f2 ln2_spot, f2 W, const float *row)
+__device__ __forceinline__ f2 bs_exposure_dates(f2 ln2_spot, f2 W, f2 g, f2 e1, f2 e2, f2 disc)
 {
-    const f2 g = {row[0], row[1]}, e1 = {row[2], row[3]}, e2 = {row[4], row[5]}, disc = {row[8], row[9]};
     const f2 spot = {__builtin_amdgcn_exp2f(ln2_spot.x), __builtin_amdgcn_exp2f(ln2_spot.y)};
     const f2 d1 = __builtin_elementwise_fma(W, g, e1), d2 = __builtin_elementwise_fma(W, g, e2);
     const f2 a = __builtin_elementwise_fma(d1 * (f2){-0.72134752044448170f, -0.72134752044448170f}, d1, ln2_spot);
@@ -1176,6 +1175,10 @@ __device__ __forceinline__ f2 bs_exposure_dates(f2 ln2_spot, f2 W, const float *
     const f2 v1 = __builtin_elementwise_fma(half, spot, -t1), v2 = __builtin_elementwise_fma(half, disc, -t2);
     const f2 w1 = {flip_by_sign(v1.x, d1.x), flip_by_sign(v1.y, d1.y)}, w2 = {flip_by_sign(v2.x, d2.x), flip_by_sign(v2.y, d2.y)};
     return __builtin_elementwise_fma(half, spot - disc, w1 - w2);
+}
+__device__ __forceinline__ f2 bs_exposure_dates(f2 ln2_spot, f2 W, const float *row)
+{
+    return bs_exposure_dates(ln2_spot, W, (f2){row[0], row[1]}, (f2){row[2], row[3]}, (f2){row[4], row[5]}, (f2){row[8], row[9]});
 }
 
 // a * b + c with c read from its SGPR pair by the three-operand instruction (c must be wave-uniform)
@@ -1227,6 +1230,7 @@ __device__ __forceinline__ double bs_exposure(double ln_spot, double W, const Cv
 // fp64: two consecutive dates of a path together, so that their four Hastings reciprocals share one v_rcp_f64 (a
 // 16-cycle instruction: -3.7 % kernel time for sharing in pairs, a further -1.3 % for four).  Same operations per date
 // as bs_exposure except for that shared reciprocal and 1/sqrt(2 pi) folded into the Hastings coefficients.
+template <bool SGPR_ROWS = true>
 __device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaStep<double> &sa, double ln_b, double W_b,
                                              const CvaStep<double> &sb, double &ee_a, double &ee_b)
 {
@@ -1236,9 +1240,16 @@ __device__ __forceinline__ void bs_exposure2(double ln_a, double W_a, const CvaS
     // fma: 6 of the ~124 instructions per date).  Spelled out instead: g into a vector pair once (it serves d1 and d2),
     // the addends read straight from their SGPRs by the three-operand form -- same fma, same bits, 3 instructions per
     // date instead of 6 (-3.1 % instructions, -2.4 % time: profiles/r02_ab_cva_scalar_addend.log).
-    const double g_a = scalar_to_vgpr(sa.g), g_b = scalar_to_vgpr(sb.g);
-    const double d1a = fma_scalar_addend(W_a, g_a, sa.e1), d2a = fma_scalar_addend(W_a, g_a, sa.e2);
-    const double d1b = fma_scalar_addend(W_b, g_b, sb.e1), d2b = fma_scalar_addend(W_b, g_b, sb.e2);
+    // (SGPR_ROWS = false: the date differs between lanes -- cva_dates_kernel -- and the rows are ordinary vector operands)
+    double d1a, d2a, d1b, d2b;
+    if constexpr (SGPR_ROWS) {
+        const double g_a = scalar_to_vgpr(sa.g), g_b = scalar_to_vgpr(sb.g);
+        d1a = fma_scalar_addend(W_a, g_a, sa.e1), d2a = fma_scalar_addend(W_a, g_a, sa.e2);
+        d1b = fma_scalar_addend(W_b, g_b, sb.e1), d2b = fma_scalar_addend(W_b, g_b, sb.e2);
+    } else {
+        d1a = __builtin_fma(W_a, sa.g, sa.e1), d2a = __builtin_fma(W_a, sa.g, sa.e2);
+        d1b = __builtin_fma(W_b, sb.g, sb.e1), d2b = __builtin_fma(W_b, sb.g, sb.e2);
+    }
     // A = C exp(.) with C = 1/sqrt(2 pi) folded into the Hastings coefficients (hastings_poly_phi): one multiply less per date
     const double A_a = exp_f64(fmax(__builtin_fma(-0.5 * d1a, d1a, ln_a), -800.0));  // d1 runs away as tau -> 0
     const double A_b = exp_f64(fmax(__builtin_fma(-0.5 * d1b, d1b, ln_b), -800.0));
@@ -1351,13 +1362,14 @@ __device__ __forceinline__ double cva_path(Gen &gen, const CvaArgs<double> &o, c
     return acc * (ANTI ? o.lgd * 0.5 : o.lgd);
 }
 
-template <class Real, bool ANTI, class Gen = GenPhilox>
-__global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real *__restrict__ out)
+// one lane per path, grid-stride over the segment's paths: workgroup `block` of `n_blocks` (the whole grid for cva_kernel, the
+// main part of it for cva_split_kernel)
+template <class Real, bool ANTI, class Gen>
+__device__ __forceinline__ void cva_paths_role(const CvaArgs<Real> &o, const Work &w, Real *__restrict__ out, uint32_t block, uint32_t n_blocks,
+                                               double &acc_s, double &acc_q)
 {
-    stage_tables<Real>();
-    const uint32_t stride = gridDim.x * GROUP;
-    const uint32_t gtid = blockIdx.x * GROUP + threadIdx.x;
-    double acc_s = 0.0, acc_q = 0.0;
+    const uint32_t stride = n_blocks * GROUP;
+    const uint32_t gtid = block * GROUP + threadIdx.x;
     Gen gen(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
         const Real p = cva_path<ANTI>(gen, o, w, w.unit_lo + i);
@@ -1366,9 +1378,203 @@ __global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument
         if (out)  // wave-uniform: per-path dump for the parity tests
             out[i] = p;
     }
+}
+
+template <class Real, bool ANTI, class Gen = GenPhilox>
+__global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real *__restrict__ out)
+{
+    stage_tables<Real>();
+    double acc_s = 0.0, acc_q = 0.0;
+    cva_paths_role<Real, ANTI, Gen>(o, w, out, blockIdx.x, gridDim.x, acc_s, acc_q);
     group_sum2(acc_s, acc_q);
     finish_group(acc_s, acc_q);
 }
+
+// =========================================================================================
+// CVA, parallel in the DATE axis.  Reference loop: dp/MonteCarloKernel.cu:241-262 -- one thread walks all N_GRID dates of
+// its path.  With the reformulation above the lane's only state is W_j = z_1 + ... + z_j and everything else is a table
+// row of the date, so the walk is a prefix sum followed by independent work: here a path's dates are shared by
+// L = 2^log2_lanes ADJACENT lanes (L = 2 ... 64).  Per round of CH * L dates, lane `sub` of the path owns the CH dates
+// [r0 + sub CH, r0 + (sub + 1) CH):
+//   1. it draws ITS dates' normals -- the generator is counter-based (block = date / NPB): nothing is handed over --
+//      and keeps them in registers (CH of them);
+//   2. one scan over the L lanes (ds_bpermute: the LDS crossbar, no memory) turns the chunk sums into every lane's W offset;
+//   3. it prices its CH dates with the same per-date operations as cva_kernel, the table row read per LANE from an LDS copy
+//      of the table (the date is no longer wave-uniform, so the scalar loads of cva_kernel are not available);
+// and after the last round one butterfly over the L lanes forms the path's sum_j dp_j ee_j BEFORE it is squared.  The
+// values differ from cva_kernel's only by the association of two sums (W, and the sum over dates): 1e-16-level in fp64.
+// What it is for (mc_api.hip: cva_enqueue picks L): a unit of work is 1/L of a path, so
+//   * the LAST PARTIAL WAVE-TRIP of a large call (cva_kernel's time is a staircase in steps of 64 lanes x 1024 SIMDs = 65 536
+//     paths: 1.25e6 paths -- C5's shard of 8 -- pay 20 trips for 19.07) is priced by date-parallel workgroups of the SAME launch
+//     (cva_split_kernel below);
+//   * a SMALL call (the reference driver's own 131 072 paths, dp/cvaOpt.cu:12-15: two waves per SIMD) fills the chip
+//     (cva_dates_kernel).
+// Generators: the counter-based ones and the external array (XORWOW is one sequence per lane: a path cannot be entered in
+// the middle).  Grid-stride over path slots; a wave's lanes all run the same number of trips (lanes beyond the range price
+// a valid path and contribute nothing), because the scans need every lane.
+// =========================================================================================
+__device__ __forceinline__ float lane_fetch(float v, uint32_t src_lane)   // v of lane `src_lane` (mod 64)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __builtin_bit_cast(int, v)));
+}
+__device__ __forceinline__ double lane_fetch(double v, uint32_t src_lane)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// exposures of two consecutive dates of one path, table rows in vector registers; same operations per date as the pair
+// forms of cva_path (fp32: the two dates in the halves of every packed instruction; fp64: one shared reciprocal)
+__device__ __forceinline__ void exposure_pair_rows(float bx, float W_a, float W_b, const CvaStep<float> &sa, const CvaStep<float> &sb,
+                                                   float &ee_a, float &ee_b)
+{
+    const f2 Wp = {W_a, W_b};
+    const f2 ee = bs_exposure_dates(pk_fma(Wp, (f2){bx, bx}, (f2){sa.xk, sb.xk}), Wp, (f2){sa.g, sb.g}, (f2){sa.e1, sb.e1}, (f2){sa.e2, sb.e2},
+                                    (f2){sa.disc, sb.disc});
+    ee_a = ee.x, ee_b = ee.y;
+}
+__device__ __forceinline__ void exposure_pair_rows(double bx, double W_a, double W_b, const CvaStep<double> &sa, const CvaStep<double> &sb,
+                                                   double &ee_a, double &ee_b)
+{
+    bs_exposure2<false>(__builtin_fma(W_a, bx, sa.xk), W_a, sa, __builtin_fma(W_b, bx, sb.xk), W_b, sb, ee_a, ee_b);
+}
+template <class Real>
+__device__ __forceinline__ Real intrinsic_exposure(Real bx, Real W, Real xk, Real strike)
+{
+    const Real iv = exp_model(fma_r(W, bx, xk)) - strike;
+    return iv > 0 ? iv : (Real)0;
+}
+
+// workgroup `block` of `n_blocks` date-parallel workgroups; lds_raw: room for the per-date table (n_dates rows)
+template <class Real, int CH, bool ANTI, class Gen>
+__device__ __forceinline__ void cva_dates_role(const CvaArgs<Real> &o, const Work &w, const uint32_t log2_lanes, Real *__restrict__ out, uint32_t block,
+                                               uint32_t n_blocks, unsigned char *lds_raw, double &acc_s, double &acc_q)
+{
+    constexpr int NPB = Gen::template npb<Real>();
+    static_assert(CH % NPB == 0 && CH % 2 == 0, "a lane's chunk is whole generator blocks and whole date pairs");
+    CvaStep<Real> *rows = reinterpret_cast<CvaStep<Real> *>(lds_raw);
+    const int n_dates = o.n_bs + o.last_intrinsic;
+    {   // the per-date table, once per workgroup (n_dates * 6 reals; the host checked that it fits)
+        const Real *src = reinterpret_cast<const Real *>(o.steps);
+        Real *dst = reinterpret_cast<Real *>(lds_raw);
+        for (int k = threadIdx.x; k < 6 * n_dates; k += GROUP)
+            dst[k] = src[k];
+    }
+    __syncthreads();
+    const uint32_t L = 1u << log2_lanes, lane = threadIdx.x & 63u, sub = lane & (L - 1u);
+    const uint32_t slots = (uint32_t)GROUP >> log2_lanes;                  // paths a workgroup holds at a time
+    const uint32_t stride = n_blocks * slots;
+    const uint32_t slot = block * slots + (threadIdx.x >> log2_lanes);
+    Gen gen(w);
+    for (uint32_t i = slot, i0 = __builtin_amdgcn_readfirstlane(slot); i0 < w.n_units; i += stride, i0 += stride) {   // i0: the wave's first slot
+        const bool live = i < w.n_units;
+        const uint32_t unit = w.unit_lo + (live ? i : i0);
+        Real W_done = 0, acc = 0;   // W_done: the path's W at the end of the previous round
+        for (int r0 = 0; r0 < n_dates; r0 += CH << log2_lanes) {
+            const int j0 = r0 + (int)sub * CH;   // this lane's first date (0-based) of the round
+            Real z[CH];
+#pragma unroll
+            for (int t = 0; t < CH; ++t)
+                z[t] = 0;
+            if (j0 < n_dates) {
+#pragma unroll
+                for (int q = 0; q < CH / NPB; ++q) {
+                    Real zz[NPB];
+                    gen.normals(w, unit, (uint32_t)(j0 / NPB + q), 3u /*MC_DOMAIN_CVA*/, zz);
+#pragma unroll
+                    for (int t = 0; t < NPB; ++t)
+                        z[q * NPB + t] = (j0 + q * NPB + t < n_dates) ? zz[t] : (Real)0;
+                }
+            }
+            Real incl = z[0];
+#pragma unroll
+            for (int t = 1; t < CH; ++t)
+                incl += z[t];
+            for (uint32_t d = 1; d < L; d <<= 1) {   // inclusive scan of the chunk sums over the path's L lanes
+                const Real below = lane_fetch(incl, lane - d);
+                if (sub >= d)
+                    incl += below;
+            }
+            const Real before = lane_fetch(incl, lane - 1u);
+            Real Wl = sub ? W_done + before : W_done;                 // W at the end of the date before this lane's chunk
+            W_done += lane_fetch(incl, lane | (L - 1u));
+#pragma unroll
+            for (int t = 0; t < CH; t += 2) {
+                const int ja = j0 + t, jb = ja + 1;
+                const CvaStep<Real> sa = rows[ja < n_dates ? ja : n_dates - 1], sb = rows[jb < n_dates ? jb : n_dates - 1];
+                const Real W_a = Wl + z[t], W_b = W_a + z[t + 1];
+                Wl = W_b;
+                Real ee_a, ee_b;
+                exposure_pair_rows(o.bx, W_a, W_b, sa, sb, ee_a, ee_b);
+                if (ANTI) {
+                    Real em_a, em_b;
+                    exposure_pair_rows(o.bx, -W_a, -W_b, sa, sb, em_a, em_b);
+                    ee_a += em_a, ee_b += em_b;
+                }
+                ee_a = ja < o.n_bs ? ee_a : (Real)0;   // beyond the closed-form dates: the intrinsic-value date below, or nothing
+                ee_b = jb < o.n_bs ? ee_b : (Real)0;
+                if (o.last_intrinsic && (ja == o.n_bs || jb == o.n_bs)) {   // one lane of one wave of the path
+                    const bool first = ja == o.n_bs;
+                    const Real Wi = first ? W_a : W_b, xk = first ? sa.xk : sb.xk;
+                    Real iv = intrinsic_exposure(o.bx, Wi, xk, o.strike);
+                    if (ANTI)
+                        iv += intrinsic_exposure(o.bx, -Wi, xk, o.strike);
+                    ee_a = first ? iv : ee_a;   // (selects: a reference picked at run time would put both in scratch)
+                    ee_b = first ? ee_b : iv;
+                }
+                acc = fma_r(sa.dp, ee_a, acc);
+                acc = fma_r(sb.dp, ee_b, acc);
+            }
+        }
+        for (uint32_t d = 1; d < L; d <<= 1)   // the path's sum over its lanes (every lane ends up with a total; lane sub = 0's is used)
+            acc += lane_fetch(acc, lane ^ d);
+        const Real p = acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);
+        if (live && sub == 0) {
+            acc_s += (double)p;
+            acc_q = __builtin_fma((double)p, (double)p, acc_q);
+            if (out)
+                out[i] = p;
+        }
+    }
+}
+
+template <class Real, int CH, bool ANTI, class Gen = GenPhilox>
+__global__ __launch_bounds__(GROUP) void cva_dates_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w,
+                                                          const uint32_t log2_lanes, Real *__restrict__ out)
+{
+    stage_tables<Real>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double acc_s = 0.0, acc_q = 0.0;
+    cva_dates_role<Real, CH, ANTI, Gen>(o, w, log2_lanes, out, blockIdx.x, gridDim.x, lds_raw, acc_s, acc_q);
+    group_sum2(acc_s, acc_q);
+    finish_group(acc_s, acc_q);
+}
+
+// ONE launch for a call that ends in a partial wave-trip: the first `tail_groups` workgroups price the call's last `wt.n_units`
+// paths date-parallel, the others the leading whole trips one lane per path.  (Two launches would have to run side by side:
+// on one stream the queue's barrier bit serialises them -- gfx950 ignores hipExtAnyOrderLaunch, profiles/r06_any_order_probe.log
+// -- and a second stream forked from and joined to the first costs 21-26 us per call whatever the remainder's size,
+// half of the trip it saves: profiles/r06_shard_clock_split_two_streams.log.)  The date-parallel workgroups come FIRST in
+// the grid: they are dispatched with the first round of the others and are long gone when the last full trip ends.  The
+// kernel's registers are the date-parallel role's (fp64: 4 waves per SIMD instead of cva_kernel's 6, which costs cva_kernel's
+// loop nothing measurable: profiles/r06_occupancy_probe.log).
+template <class Real, int CH, class Gen = GenPhilox>
+__global__ __launch_bounds__(GROUP) void cva_split_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w,
+                                                          const Work wt, const uint32_t tail_groups, const uint32_t log2_lanes,
+                                                          Real *__restrict__ out, Real *__restrict__ out_tail)
+{
+    stage_tables<Real>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double acc_s = 0.0, acc_q = 0.0;
+    if (blockIdx.x < tail_groups)   // workgroup-uniform
+        cva_dates_role<Real, CH, false, Gen>(o, wt, log2_lanes, out_tail, blockIdx.x, tail_groups, lds_raw, acc_s, acc_q);
+    else
+        cva_paths_role<Real, false, Gen>(o, w, out, blockIdx.x - tail_groups, gridDim.x - tail_groups, acc_s, acc_q);
+    group_sum2(acc_s, acc_q);
+    finish_group(acc_s, acc_q);
+}
+
 
 // =========================================================================================
 // Pathwise Greeks of the basket call (the reference prices only).  Per path, in the reference's own

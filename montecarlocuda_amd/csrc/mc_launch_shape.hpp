@@ -102,6 +102,66 @@ static int basket_tiled_min()
     return limit;
 }
 
+// CVA: how a call of n paths over n_dates dates is cut between one lane per path (cva_kernel; the date walk serial, as in the
+// reference) and the date-parallel form (2^log2_lanes adjacent lanes per path, CVA_DATES_CH dates per lane and round; mc_kernels.hpp).
+//   main_paths   leading paths, one lane each
+//   tail_paths   trailing paths, date-parallel (both > 0: one launch of cva_split_kernel; main_paths == 0: cva_dates_kernel)
+// The one-lane-per-path kernel's time is a staircase in steps of one WAVE-TRIP = 64 lanes x 4 SIMDs x CUs paths (65 536 on
+// MI355X): a launch pays for whole trips -- 1 250 000 paths (C5's shard of 8: 19.07 trips) cost what 1 310 720 do, 990.9 us against
+// 944.8 for 19 trips -- and a wave alone on its SIMD needs 104 us for its path whatever the call's size.  Measured with
+// tools/c/shard_clock (profiles/r06_shard_clock_AD_fused_split.log), 256 dates fp64:
+//   * a call of 2.5 ... 64 trips that ends in a partial trip of at most 60 % hands that remainder to the date-parallel
+//     workgroups of the same launch, with enough lanes per path to put about two of their waves on every SIMD
+//     (1 250 000 paths: 953.0 us; the gain shrinks to nothing as the remainder approaches a full trip: 0.31 of a trip -21.6 us,
+//     0.45 -15.2, 0.53 -8.0; beyond 64 trips a trip is under 1.6 % of the call);
+//   * a call below 2.5 trips runs date-parallel as a whole, with lanes for ~4 waves per SIMD: 4096 paths 104.1 -> 15.0 us
+//     (64 lanes), 32 768: 105.3 -> 41.9 (8), 65 536: 104.7 -> 67.6 (4), 131 072 -- the reference driver's own call,
+//     dp/cvaOpt.cu:12-15 -- 127.6 -> 119.2 (4); from 196 608 paths on one lane per path is as fast or faster (the date-parallel
+//     form pays per-lane table rows and Philox counters: +6 % at 2 lanes, +11 % at 8, +26...33 % from 16 on at 1e6 paths);
+//   * everything else keeps one lane per path.
+// `forced_lanes`: 0 = this rule, 1 = one lane per path always, 2 ... 64 = the whole call date-parallel with that many lanes
+// (mc_context_set_cva_date_lanes / MC_CVA_DATE_LANES; the tests sweep it).  A path cannot use more lanes than it has
+// chunks of CVA_DATES_CH dates.
+constexpr int CVA_DATES_CH = 8;
+struct CvaPlan { uint64_t main_paths, tail_paths; int log2_lanes; };
+static int cva_max_log2_lanes(int n_dates)
+{
+    int l = 0;
+    while (l < 6 && (CVA_DATES_CH << l) < n_dates)
+        ++l;
+    return l;
+}
+static CvaPlan cva_plan(int forced_lanes, uint64_t n, int n_dates, int compute_units, bool dates_kernel_possible)
+{
+    constexpr int tail_max_pct = 60, small_trips_x4 = 10 /* 2.5 trips */, small_fill = 4, split_max_trips = 64;
+    const int max_l = cva_max_log2_lanes(n_dates);
+    CvaPlan p = {n, 0, 0};
+    if (!dates_kernel_possible || max_l == 0 || forced_lanes == 1 || n == 0)
+        return p;
+    const auto log2_ceil = [](uint64_t x) { int l = 0; while ((1ull << l) < x) ++l; return l; };
+    if (forced_lanes >= 2) {
+        int l = 0;
+        while ((2 << l) <= forced_lanes) ++l;
+        p.main_paths = 0, p.tail_paths = n, p.log2_lanes = l < max_l ? l : max_l;
+        return p;
+    }
+    const uint64_t trip = 64ull * 4ull * (uint64_t)(compute_units > 0 ? compute_units : 256);
+    if (4 * n < (uint64_t)small_trips_x4 * trip) {   // small call: all of it date-parallel, ~small_fill waves per SIMD
+        int l = log2_ceil(((uint64_t)small_fill * trip + n - 1) / n);
+        l = l > max_l ? max_l : l;
+        if (l > 0)
+            p.main_paths = 0, p.tail_paths = n, p.log2_lanes = l;
+        return p;
+    }
+    const uint64_t r = n % trip;
+    if (r == 0 || 100 * r > (uint64_t)tail_max_pct * trip || n > (uint64_t)split_max_trips * trip)
+        return p;
+    int l = log2_ceil((2 * trip + r - 1) / r);
+    l = l < 1 ? 1 : (l > max_l ? max_l : l);
+    p.main_paths = n - r, p.tail_paths = r, p.log2_lanes = l;
+    return p;
+}
+
 // How many pieces the fused kernels cut every reference thread's stream into (mc_grid.hpp "sub-streams"): enough to put
 // ~8 waves on every SIMD (the reference's 512 x 128 launch alone is ONE), as long as a piece keeps >= 16 paths; a power
 // of two up to 32.  MC_GRID_SUB forces a count (1 = the reference's own layout).

@@ -219,6 +219,10 @@ class Engine:
         """'philox' (default; counter-based) or 'xorwow' (the reference's generator, one sequence per lane)."""
         check(lib().mc_context_set_generator(self._ctx, {"philox": 0, "xorwow": 1}[name], subsequence_base))
 
+    def set_cva_date_lanes(self, lanes: int):
+        """CVA: adjacent lanes sharing one path's dates (0 = by call size, 1 = never, 2 ... 64 = the whole call date-parallel)."""
+        check(lib().mc_context_set_cva_date_lanes(self._ctx, int(lanes)))
+
     def set_normals(self, mode: str):
         """fp64 kernels: 'native' (default; true fp64 normals) or 'f32' (the reference's dp arithmetic: a float normal
         widened to double, four per Philox block)."""

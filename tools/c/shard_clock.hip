@@ -52,7 +52,7 @@ static int preheat(mc_context *c, double *d_triple, double ms)
 
 int main(int argc, char **argv)
 {
-    const char *which = argc > 1 ? argv[1] : "ABC";
+    const char *which = argc > 1 ? argv[1] : "ABCD";
     mc_context *c;
     MC(mc_context_create(0, 0, &c));
     double *d_triple = nullptr;
@@ -92,18 +92,42 @@ int main(int argc, char **argv)
 
     if (strchr(which, 'A')) {
         printf("\nA. hot sweep (300 ms pre-heat, then 30 back-to-back launches per size; stream-event brackets, so each figure\n"
-               "   includes the ~2 us launch boundary).  65 536 paths = one wave-trip on each of the 1024 SIMDs.\n");
-        printf("%10s %12s %10s %10s %10s %14s %16s\n", "paths", "trips/SIMD", "median us", "min us", "max us", "ns per path", "us per trip/SIMD");
+               "   includes the ~2 us launch boundary).  65 536 paths = one wave-trip on each of the 1024 SIMDs.\n"
+               "   lanes = 1: cva_kernel alone (one lane per path); auto: the last partial trip on cva_dates_kernel beside it\n");
+        printf("%10s %12s | %10s %10s %10s | %10s %10s %10s | %8s\n", "paths", "trips/SIMD", "1: med us", "min", "max", "auto: med", "min", "max", "auto/1");
         if (preheat(c, d_triple, 300)) return 1;
         const uint64_t sizes[] = {1000000, 1048576, 1100000, 1114112, 1150000, 1179648, 1200000, 1245184, 1250000, 1280000, 1310720,
                                   1340000, 1376256, 1400000, 1441792, 1450000, 2500000, 5000000, 10000000};
-        std::vector<double> us;
+        std::vector<double> us, us2;
         for (uint64_t n : sizes) {
+            MC(mc_context_set_cva_date_lanes(c, 1));
             if (timed_burst(n, n > 2000000 ? 12 : 30, us)) return 1;
-            const double m = med(us);
-            printf("%10llu %12.3f %10.1f %10.1f %10.1f %14.4f %16.2f\n", (unsigned long long)n, n / 65536.0, m, mn(us), mx(us), m * 1e3 / n,
-                   m / (n / 65536.0));
+            MC(mc_context_set_cva_date_lanes(c, 0));
+            if (timed_burst(n, n > 2000000 ? 12 : 30, us2)) return 1;
+            printf("%10llu %12.3f | %10.1f %10.1f %10.1f | %10.1f %10.1f %10.1f | %8.4f\n", (unsigned long long)n, n / 65536.0, med(us), mn(us), mx(us),
+                   med(us2), mn(us2), mx(us2), med(us2) / med(us));
         }
+    }
+    if (strchr(which, 'D')) {
+        printf("\nD. small calls, hot (pre-heat, 40 back-to-back launches each): the whole call on cva_dates_kernel with L lanes per path\n"
+               "   against cva_kernel (L = 1); 131 072 paths is the reference driver's own call (dp/cvaOpt.cu:12-15)\n");
+        printf("%10s %8s", "paths", "auto us");
+        for (int l = 1; l <= 64; l *= 2) printf(" %8s%-2d", "L=", l);
+        printf("\n");
+        if (preheat(c, d_triple, 300)) return 1;
+        std::vector<double> us;
+        for (uint64_t n : {4096ull, 16384ull, 32768ull, 65536ull, 98304ull, 131072ull, 196608ull, 262144ull, 393216ull, 524288ull, 786432ull, 1048576ull}) {
+            MC(mc_context_set_cva_date_lanes(c, 0));
+            if (timed_burst(n, 40, us)) return 1;
+            printf("%10llu %8.1f", (unsigned long long)n, med(us));
+            for (int l = 1; l <= 64; l *= 2) {
+                MC(mc_context_set_cva_date_lanes(c, l));
+                if (timed_burst(n, 40, us)) return 1;
+                printf(" %10.1f", med(us));
+            }
+            printf("\n");
+        }
+        MC(mc_context_set_cva_date_lanes(c, 0));
     }
     if (strchr(which, 'B')) {
         printf("\nB. the same launch as synchronous calls (mc_cva_run_f64, timing on: kernel_ms from events) separated by host sleeps;\n"
