@@ -26,7 +26,8 @@ over RCCL the barrier that closes a region is the all-reduce of its last bucket 
 all-reduce is a barrier; --closing barrier adds a separate dist.barrier()).
 
 OUTPUT.  stdout carries ONE line: a JSON object of at most 4096 bytes -- the contract fields, `config`, `roofline`,
-`cpu_baseline`, `fp64`, `region_ms_per_step`, `strong_summary` and, at N > 1, the roster of ranks (`ranks`) -- built by
+`cpu_baseline`, `fp64`, `configs` (BASELINE configs[1..4] with their roofline fractions and the reference's CPU path), `strong_summary` and,
+at N > 1, the roster of ranks (`ranks`) -- built by
 compact_line() from the full record.  The full record (every strong row, every line of the C library's child process,
 host-side timings, the prose that explains each field) goes to --detail-file (default bench_detail.json next to this
 script; the line names it as `detail`), never to stdout or stderr.  (Round 4's line had grown to 32 KB and the driver
@@ -150,7 +151,9 @@ def kernel_name(prod, X, inputs):
         if n <= 8:
             return f"mc::basket_kernel<f64, {n}>"
         return f"mc::basket_tiled_kernel<f64, {n if n <= 16 else pad}>" if n <= 32 else "mc::basket_dyn_kernel<f64>"
-    return f"mc::cva_kernel<{X}>"
+    # (a call that ends in a partial wave-trip of at most 60 % runs as cva_split_kernel: the same one-lane-per-path loop plus
+    # date-parallel workgroups for the remainder -- 1.25e6 paths = 19 trips + 4816 paths; csrc/mc_launch_shape.hpp: cva_plan)
+    return f"mc::cva_kernel<{X}> (as cva_split_kernel when the call ends in a partial wave-trip)"
 
 
 PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}   # MI355X vector peaks (MI355X_MICROARCH.md; fp64 vector = half)
@@ -197,6 +200,246 @@ def cpus_granted():
         return None if q == "max" else -(-int(q) // int(p))
     except (OSError, ValueError):
         return None
+
+
+class SclkSampler:
+    """Shader clock of the card at PCI address `pci` while the block runs, from amdgpu's hwmon file (montecarlocuda_amd/sclk.py),
+    sampled every millisecond by a side thread: .mhz = median of the second half of the samples (the first half may still
+    be the ramp), None when the file does not exist."""
+
+    def __init__(self, pci):
+        from montecarlocuda_amd import sclk
+        self._read = (lambda: sclk.read_mhz(0, pci)) if sclk.source(0, pci) else None
+        self.mhz, self.samples = None, 0
+
+    def __enter__(self):
+        import threading
+        self._stop, self._v = threading.Event(), []
+        if self._read:
+            def run():
+                while not self._stop.is_set():
+                    self._v.append(self._read())
+                    time.sleep(0.001)
+            self._th = threading.Thread(target=run, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self._read:
+            self._th.join()
+            v = sorted(x for x in self._v[len(self._v) // 2:] if x)
+            self.samples = len(v)
+            self.mhz = v[len(v) // 2] if v else None
+
+
+def sustained_clock(torch, engines, streams, launch, pci, ms=150.0):
+    """Shader clock while `launch(i, engine, stream)` runs back to back on the given context/stream pairs for `ms` milliseconds."""
+    with SclkSampler(pci) as sm:
+        t0, i = time.perf_counter(), 0
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for _ in range(16):
+                launch(i, engines[i % len(engines)], streams[i % len(streams)])
+                i += 1
+            torch.cuda.synchronize()
+    return sm.mhz
+
+
+def issue_ceiling(workload, paths, kernel_s, step_s, stamp, traffic_stale, committed, sclk_mhz=None):
+    """SURVEY 8d's second fraction: the VALU issue CEILING of one launch of `workload` over `paths` paths, from the kernel's own
+    instruction stream -- the opcode histogram of its hot loop (ISA listing) x the ARCHITECTURAL issue cost of each opcode
+    (tools/issue_model.py -> profiles/issue_model.json: 4 cycles for a full-rate wave64 instruction on a 16-lane SIMD, 8 / 16 for the
+    fp32 / fp64 transcendentals, 2 for the simple 32-bit ops tools/ubench measured at 2.3), cross-checked against the hardware's
+    instruction counters.  Priced at the chip's peak 2.4 GHz (issue_frac: a time no launch can beat at any clock) and at the
+    clock the card actually held while this kernel ran back to back (issue_frac_at_measured_clock: what the kernel leaves on the
+    table at the clock DVFS gives it).  Returns (fields for the roofline dict, or None when the committed model does not
+    describe this build)."""
+    try:
+        model = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json"))).get(workload, {})
+    except (OSError, ValueError):
+        model = {}
+    if not model:
+        return None
+    if not (kernel_s and not traffic_stale and model.get("launch_stamp") == stamp["stamp"] and
+            (model.get("cross_check_ok") or model.get("rescaled_to_counters"))):
+        return {"issue_model_withheld": "profiles/issue_model.json does not describe this build (stamp) or failed its cross-check against the "
+                                        "hardware counters: re-run tools/collect_pmc_all.sh and tools/issue_model.py"}
+    waves_trips = paths / 64.0
+    ceil_s = model["min_cycles_per_path"] * waves_trips / model["simds"] / model["clock_hz"]
+    typ_s = model["typical_cycles_per_path"] * waves_trips / model["simds"] / model["clock_hz"]
+    out = {"issue_frac": ceil_s / kernel_s,
+           "issue_model": {
+               "ceiling_us": ceil_s * 1e6, "kernel_us": kernel_s * 1e6, "frac_effective": (ceil_s / step_s) if step_s else None,
+               "typical_us": typ_s * 1e6, "typical_frac": typ_s / kernel_s,
+               "valu_insts_per_path": model["valu_per_path"], "min_cycles_per_path": model["min_cycles_per_path"],
+               "simds": model["simds"], "clock_hz": model["clock_hz"], "source": model.get("source"),
+               "cross_check": {"pmc_vs_histogram_valu": model.get("pmc_vs_model"), "ok_within_1pct": bool(model.get("cross_check_ok")),
+                               "rescaled_to_counters": bool(model.get("rescaled_to_counters"))},
+               "valu_busy_long_launch": (committed or {}).get("valu_busy_long_launch"), "valu_busy_source": (committed or {}).get("valu_busy_source"),
+               "note": "ceiling = sum over the hot loop's VALU instructions of the ARCHITECTURAL issue cost of the opcode x wave-trips / "
+                       "(1024 SIMDs x 2.4 GHz): a lower bound on the launch time at any clock; typical_us prices the same histogram at "
+                       "the costs tools/ubench measured in mixed streams (4.1 / 8.1 / 16.2 cycles) -- an estimate, not a bound"}}
+    if sclk_mhz:
+        out["sclk_mhz"] = sclk_mhz
+        out["issue_frac_at_measured_clock"] = out["issue_frac"] * model["clock_hz"] / (sclk_mhz * 1e6)
+        out["issue_model"]["ceiling_us_at_measured_clock"] = ceil_s * 1e6 * model["clock_hz"] / (sclk_mhz * 1e6)
+    return out
+
+
+def cva_analytic(c):
+    """E[CVA] of the reference's estimator in closed form: under the risk-neutral measure E[C(S_t, T - t)] = C_0 e^{r t}, so
+    CVA = LGD * C_0 * sum_j dPD_j e^{r t_j} over the dates with a non-negative residual maturity."""
+    from statistics import NormalDist
+    s0, k, r, v, t = c["s"], c["k"], c["r"], c["v"], c["t"]
+    d1 = (math.log(s0 / k) + (r + 0.5 * v * v) * t) / (v * math.sqrt(t))
+    c0 = s0 * NormalDist().cdf(d1) - k * math.exp(-r * t) * NormalDist().cdf(d1 - v * math.sqrt(t))
+    n, lam = c["n_grid"], c["defint"]
+    dt, ttm, tot = t / n, t, 0.0
+    for j in range(1, n + 1):
+        ttm -= dt
+        if ttm < 0:
+            break
+        tot += (math.exp(-lam * dt * (j - 1)) - math.exp(-lam * dt * j)) * math.exp(r * dt * j)
+    return c["lgd"] * c0 * tot
+
+
+def configs_block(mc, torch, engines, launch_streams, pci, headline, strong, stamp, cpu_seconds=2.0):
+    """BASELINE.json configs[1..4], each on this ONE GPU with its roofline fractions and the reference's CPU path beside it:
+      C2  vanilla, 1e8 paths fp32 (the headline: copied from it) + what ONE synchronous call of it costs (single_call: the reference
+          driver times exactly that, dp/vanillaOpt.cu:77-83 -- a lone launch plus the call's fixed cost, without the second stream
+          that hides ramp and tail in the stepped region)
+      C3  basket, 4 assets, 1e8 paths fp32: stepped over the two context/stream pairs like the headline; price against the SAME
+          basket in fp64 (1e9 paths)
+      C4  basket, 16 assets, 1e9 paths fp64 on one GPU: T(1) of the strong block; price against the 1e10-path run (C4x10)
+      C5  CVA, 256 dates x 1e7 paths fp64: T(1) of the strong block; price against the closed form (cva_analytic)
+    kernel_us = the config's kernel alone (HIP events bound to the dispatch, launches one at a time); frac = algorithmic flop
+    / kernel_us / the vector peak of the dtype; issue_frac(_at_measured_clock): issue_ceiling().  cpu = the compiled reference's
+    own host_basketOpt / host_cvaEquityOption (oracle/_ref, gcc -O2, ONE thread: the reference is single-threaded) on a bounded
+    sample; for the baskets the sp object -- the dp object's multiStockValue omits the volatility, its time is
+    reported beside it as cpu_dp."""
+    import numpy as np
+    W = workloads(mc)
+    seed = mc.MC_DEFAULT_SEED
+    rows = {(r["config"]): r for r in (strong or {}).get("rows", [])}
+    out = {}
+
+    def lone_kernel(eng, prod, X, struct, count, n, stream_handle):
+        eng.profile(1)
+        scratch = torch.zeros((n, 3), dtype=torch.float64, device="cuda")
+        for i in range(n):
+            eng.launch(prod, X, struct, seed, (1 << 52) + i * count, count, scratch[i].data_ptr(), stream_handle)
+        torch.cuda.synchronize()
+        k, ms = eng.profile_read()
+        eng.profile(0)
+        return (ms / k * 1e-3) if k else None
+
+    def entry(name, wl, paths_per_s, kernel_s, count, price, ci, target, versus, sclk):
+        prod, X, _, _, flop, desc = W[wl]
+        e = {"workload": desc, "paths": count, "paths_per_s": paths_per_s, "kernel_us": kernel_s * 1e6 if kernel_s else None,
+             "frac": (flop * count / kernel_s / 1e12 / PEAK_TFLOPS[X]) if kernel_s else None, "dtype": X,
+             "price": price, "confidence_95": ci, "err": abs(price - target) if target is not None else None, "vs": versus}
+        im = issue_ceiling(wl, count, kernel_s, None, stamp, False, None, sclk) or {}
+        for k in ("issue_frac", "issue_frac_at_measured_clock"):
+            if k in im:
+                e[k] = im[k]
+        if im.get("issue_model"):
+            e["ceiling_us"] = im["issue_model"]["ceiling_us"]
+        if sclk:
+            e["sclk_mhz"] = sclk
+        return e
+
+    # ---- C2: the headline's own numbers + one synchronous call ----
+    r = headline["roofline"]
+    c2 = {"workload": headline["config"]["workload"], "paths": headline["config"]["paths_per_gpu_per_step"], "paths_per_s": headline["value"],
+          "kernel_us": r.get("avg_kernel_us"), "frac": r.get("frac"), "dtype": "f32", "price": headline["price"],
+          "confidence_95": headline["confidence_95"], "err": headline.get("price_error_vs_black_scholes"), "vs": "Black-Scholes"}
+    for k in ("issue_frac", "issue_frac_at_measured_clock", "sclk_mhz"):
+        if r.get(k) is not None:
+            c2[k] = r[k]
+    eng = engines[0]
+    eng.set_timing(False)                      # what the legacy symbols run with: the last workgroup writes the pinned slot, the host polls
+    walls = []
+    for i in range(-5, 30):
+        t0 = time.perf_counter()
+        est = eng.vanilla(VAN, 10 ** 8, seed, (1 << 53) + i * 10 ** 8 if i >= 0 else 0, "f32")
+        if i >= 0:
+            walls.append(time.perf_counter() - t0)
+    eng.set_timing(True)
+    walls.sort()
+    c2["single_call"] = {"wall_us": walls[len(walls) // 2] * 1e6, "paths_per_s": 10 ** 8 / walls[len(walls) // 2], "calls": len(walls),
+                         "what": "ONE synchronous mc_vanilla_run_f32 of 1e8 paths, back to back, median (dev_vanillaOpt's path, timing off)"}
+    out["C2"] = c2
+
+    # ---- C3: stepped like the headline ----
+    prod, X, inputs, count, flop, desc = W["basket4_f32"]
+    inputs = inputs()
+    structs = [e_.prepared(prod, X, inputs) for e_ in engines]
+    launch3 = lambda i, e_, st: e_.launch(prod, X, structs[engines.index(e_)][0], seed, (1 << 51) + i * count, count, warm[i % 2].data_ptr(), st)   # noqa: E731
+    warm = torch.zeros((2, 3), dtype=torch.float64, device="cuda")
+    sclk3 = sustained_clock(torch, engines, launch_streams, launch3, pci, 150.0)
+    K3, R3 = 40, 3
+    tri = torch.zeros((R3 * K3, 3), dtype=torch.float64, device="cuda")
+    regs = []
+    for r_ in range(R3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(r_ * K3, (r_ + 1) * K3):
+            e_ = i % len(engines)
+            engines[e_].launch(prod, X, structs[e_][0], seed, i * count, count, tri[i].data_ptr(), launch_streams[e_])
+        torch.cuda.synchronize()
+        regs.append(time.perf_counter() - t0)
+    regs.sort()
+    tot = tri.sum(dim=0).cpu().tolist()
+    disc32 = math.exp(-float(np.float32(inputs["r"])) * float(np.float32(inputs["t"])))
+    p3, ci3 = mc.closing(tot[0], tot[1], int(tot[2]), disc32)
+    k3 = lone_kernel(engines[0], prod, X, structs[0][0], count, 20, launch_streams[0])
+    ref64 = engines[0].basket(basket_inputs(mc, 4, "f64"), 10 ** 9, seed, 0, "f64")
+    out["C3"] = entry("C3", "basket4_f32", count * K3 / regs[len(regs) // 2], k3, count, p3, ci3, ref64.expected, "the same basket in fp64, 1e9 paths", sclk3)
+    out["C3"]["vs_confidence_95"] = ref64.confidence
+    out["C3"]["steps"] = [K3, R3]
+
+    # ---- C4, C5: T(1) from the strong block, the kernel alone here ----
+    for name, wl, total, n_lone in (("C4", "basket16_f64", 10 ** 9, 3), ("C5", "cva256_f64", 10 ** 7, 8)):
+        prod, X, inputs, _, flop, desc = W[wl]
+        if callable(inputs):
+            inputs = inputs()
+        struct, keep = engines[0].prepared(prod, X, inputs)
+        launchN = lambda i, e_, st: e_.launch(prod, X, struct, seed, (1 << 51) + i * total, total, warm[0].data_ptr(), st)   # noqa: E731
+        sclk = sustained_clock(torch, engines[:1], launch_streams[:1], launchN, pci, 200.0)
+        kN = lone_kernel(engines[0], prod, X, struct, total, n_lone, launch_streams[0])
+        row = rows.get(name)
+        if row:
+            t1, price, ci = row["wall_ms_median"] * 1e-3, row["value"], row["confidence_95"]
+        else:       # the strong block was skipped: one timed call here
+            t0 = time.perf_counter()
+            est = getattr(engines[0], prod)(inputs, total, seed, 0, X)
+            t1, price, ci = time.perf_counter() - t0, est.expected, est.confidence
+        if name == "C4":
+            big = rows.get("C4x10")
+            target, versus = (big["value"], "the same basket, 1e10 paths (C4x10)") if big else (None, None)
+        else:
+            target, versus = cva_analytic(inputs), "closed form LGD C0 sum dPD_j e^(r t_j)"
+        out[name] = entry(name, wl, total / t1, kN, total, price, ci, target, versus, sclk)
+        out[name]["workload"] = desc.replace("1e9/8 paths per GPU", "1e9 paths, one GPU").replace("1e7/8 paths per GPU", "1e7 paths, one GPU")
+        if name == "C4" and rows.get("C4x10"):
+            out[name]["vs_confidence_95"] = rows["C4x10"]["confidence_95"]
+
+    # ---- the reference's CPU path beside each (bounded samples; rank 0, N = 1 only) ----
+    if cpu_seconds > 0:
+        if headline.get("cpu_baseline"):
+            out["C2"]["cpu"] = _pick(headline["cpu_baseline"], "value", "unit", "cores", "kind", "sample_short")
+        b4, b16 = basket_inputs(mc, 4, "f32"), basket_inputs(mc, 16, "f32")
+        for name, prodc, Xc, inp, also_dp in (("C3", "basket", "f32", b4, False), ("C4", "basket", "f32", b16, True), ("C5", "cva", "f64", CVA, False)):
+            c = cpu_baseline(prodc, Xc, inp, cpu_seconds)
+            e = _pick(c, "value", "unit", "cores", "kind", "sample_short")
+            e["object"] = f"oracle/_ref/libref_{Xc}_n{len(inp['s']) if prodc == 'basket' else 3}.so" if c["kind"] == "reference" else "oracle port"
+            if prodc == "basket":
+                e["note"] = "sp object: the dp host's basket omits v[i] (SURVEY 2.3 #1)"
+            if also_dp:
+                c2_ = cpu_baseline(prodc, "f64", basket_inputs(mc, 16, "f64"), max(1.0, cpu_seconds / 2))
+                e["cpu_dp"] = c2_["value"]
+            out[name]["cpu"] = e
+    return out
 
 
 def cpu_all_cores(seconds=2.0):
@@ -316,11 +559,39 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
             dist.all_reduce(t, op=dist.ReduceOp.MAX)            # a repeat ends when its slowest rank has the result
         return sorted(t.tolist()), host
 
+    def timed_local(prod, struct, first, count, n_reps):
+        """this rank's launch alone, first launch -> its own triple on this host (pinned slot), no collective: median seconds"""
+        ts = []
+        for r_ in range(-2, n_reps):
+            t0 = time.perf_counter()
+            slot = eng.arm_direct()
+            eng.launch(prod, "f64", struct, mc.MC_DEFAULT_SEED, first, count, scratch.data_ptr(), stream.cuda_stream)
+            eng.wait_slot(slot)
+            if r_ >= 0:
+                ts.append(time.perf_counter() - t0)
+        return float(np.median(ts))
+
+    def gather_floats(x):
+        where = "cuda" if backend == "nccl" else "cpu"
+        mine = torch.tensor([x], dtype=torch.float64, device=where)
+        every = [torch.zeros(1, dtype=torch.float64, device=where) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [float(t.item()) for t in every]
+
     for (name, prod, inputs, total, desc, normals, base), shard_of in runs:
         eng.set_normals(normals)
         struct, keep = eng.prepared(prod, "f64", inputs)
         first, count = mc.shard_range(total, rank, world) if shard_of == 1 else mc.shard_range(total, 0, shard_of)
         times, host = timed(prod, struct, first, count, reps, True)
+        decomposition = None
+        if world > 1 and shard_of == 1 and base and count:
+            # what the N-rank wall time is made of (the driver's efficiency T1 / (N TN) needs its own N = 1 line; this line explains
+            # itself): every rank's own shard WITHOUT the collective (device side), and T(1) of the whole config on rank 0 alone
+            shard_s = gather_floats(timed_local(prod, struct, first, count, reps))
+            barrier()
+            t1_s = timed_local(prod, struct, 0, total, min(reps, 5)) if rank == 0 else 0.0
+            barrier()
+            decomposition = (shard_s, t1_s)
         cold = None
         if base:
             cold_times, _ = timed(prod, struct, first, count, min(reps, 5), False)
@@ -336,6 +607,19 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
                    "value": price, "confidence_95": ci, "paths_priced": int(n_)}
             if cold is not None:
                 row["cold"] = {"wall_ms_median": cold * 1e3, "what": "0.5 s idle, 2 warm-up calls, median of 5"}
+            if decomposition:
+                shard_s, t1_s = decomposition
+                row["t_shard_ms"] = [min(shard_s) * 1e3, max(shard_s) * 1e3]
+                row["t_shard_ms_by_rank"] = [x * 1e3 for x in shard_s]
+                row["collective_ms"] = (med - max(shard_s)) * 1e3
+                if rank == 0 and t1_s > 0:
+                    row["t1_ms_rank0"] = t1_s * 1e3
+                    row["eff"] = t1_s / (world * med)
+                    row["eff_device_side"] = t1_s / (world * max(shard_s))
+                row["decomposition"] = ("t_shard_ms = [min, max] over ranks of each rank's own shard, launch -> its triple on its host, no collective; "
+                                        "collective_ms = wall_ms_median - the slowest shard: what the all-reduce and its hand-overs add; t1_ms_rank0 = the "
+                                        "whole config on rank 0 alone, same read-back; eff = t1 / (N wall), eff_device_side = t1 / (N slowest shard): the "
+                                        "difference is the collective's share")
             rows.append(row)
         else:
             row = {"config": name, "normals": normals, "shard_of": shard_of, "paths": count, "reps": reps, "preheat_ms": preheat_ms,
@@ -346,7 +630,24 @@ def strong_scaling_block(mc, torch, dist, eng, stream, rank, world, grouped, bac
                 row["cold"] = {"wall_ms_median": cold * 1e3, "device_side_efficiency": t_full_cold[name] / (shard_of * cold)}
             shard_rows.append(row)
     eng.set_normals("native")
-    return {"scaling": "strong", "n_gpus": world, "rows": rows, "shard_rows": shard_rows,
+    allreduce_us = None
+    if grouped:
+        # the collective alone: 24 bytes, what closes every strong call (pure latency).  Outside every timed region, after a
+        # barrier; each call timed on the host from issue to completion (RCCL: to the end of the stream's work)
+        t24 = torch.zeros(3, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        lat = []
+        barrier()
+        for i in range(-20, 200):
+            t0 = time.perf_counter()
+            dist.all_reduce(t24, op=dist.ReduceOp.SUM)
+            if backend == "nccl":
+                torch.cuda.current_stream().synchronize()
+            if i >= 0:
+                lat.append(time.perf_counter() - t0)
+        lat.sort()
+        allreduce_us = {"median": lat[len(lat) // 2] * 1e6, "p10": lat[len(lat) // 10] * 1e6, "p90": lat[len(lat) * 9 // 10] * 1e6, "calls": len(lat),
+                        "backend": backend, "what": "24-byte dist.all_reduce, issue -> complete on this rank's host (rank 0), back to back after a barrier"}
+    return {"scaling": "strong", "n_gpus": world, "rows": rows, "shard_rows": shard_rows, "allreduce_us": allreduce_us,
             "timing": "wall-clock, first launch -> all-reduced {sum, sum2, n} on the host, max over ranks; every row HOT: "
                       f"{preheat_ms:.0f} ms of this rank's own shard back to back, 2 warm-up calls, median of `reps`; base sizes also "
                       "COLD (0.5 s idle first)",
@@ -399,38 +700,83 @@ def _pick(d, *keys):
     return {k: d[k] for k in keys if d and k in d and d[k] is not None}
 
 
+SHARD8_COLS = ["t1_ms", "t_shard8_ms", "shard8_device_side_eff_1gpu", "shard8_device_side_eff_1gpu_cold"]
+
+
 def strong_summary(detail):
     """A few numbers per strong-scaling config out of the full record's rows.
-    N = 1: t1_ms = one call of the whole config on this GPU (wall, hot, median), t8_ms = shard 0 of 8 of it, eff8 / eff8_cold =
-    T(1) / (8 T(shard)) hot / cold -- the device side of the 8-GPU point, everything but the all-reduce between ranks; each as
-    [bench.py's torch path, the C library (drivers/multiBench, libmc_multi.so)].  `c_devices`: the C library over G > 1 of the
-    visible devices (real RCCL), [wall ms, efficiency vs its own G = 1, fan-out us].
-    N > 1: wall_ms = one call sharded over the N ranks, first launch -> all-reduced triple, max over ranks."""
+    N = 1: {"cols": SHARD8_COLS, "src": [bench.py's torch path, the C library (drivers/multiBench, libmc_multi.so)], config: [[a, b] per
+    column]}: t1_ms = one call of the whole config on this GPU (wall, hot, median); t_shard8_ms = shard 0 of 8 of it ON THIS ONE GPU;
+    shard8_device_side_eff_1gpu(_cold) = T(1) / (8 T(shard)) hot (cold) -- a ratio of two single-GPU timings: the device side of the
+    8-GPU point, everything but the collective between ranks; NOT a measured 8-GPU efficiency (round 5 called it eff8).
+    `c_devices` (when the C library drove G > 1 of the visible devices, real RCCL): {config: {G: [wall ms, efficiency vs its own
+    G = 1, fan-out us, collective us]}}.
+    N > 1: per config wall_ms (one call sharded over the N ranks, first launch -> all-reduced triple, max over ranks), the ranks'
+    own shard times t_shard_ms [min, max], collective_ms, t1_ms_rank0, eff and eff_device_side (strong_scaling_block), and
+    allreduce_us (the 24-byte collective alone)."""
     strong = detail.get("strong") or {}
     rows = {r["config"]: r for r in strong.get("rows", [])}
     if not rows:
         return None
     if detail.get("n_gpus", 1) > 1:
-        return {c: _pick(r, "wall_ms_median", "paths_per_gpu", "value") for c, r in rows.items()}
+        out = {c: _pick(r, "wall_ms_median", "paths_per_gpu", "value", "t_shard_ms", "collective_ms", "t1_ms_rank0", "eff", "eff_device_side")
+               for c, r in rows.items()}
+        if strong.get("allreduce_us"):
+            out["allreduce_us"] = _pick(strong["allreduce_us"], "median", "p10", "p90", "calls")
+        return out
     shard = {(r["config"], r["shard_of"]): r for r in strong.get("shard_rows", [])}
     crows_all = (detail.get("c_multi") or {}).get("rows", [])
     crows = {r.get("config"): r for r in crows_all if r.get("devices") == 1 and "shard_of" not in r and "config" in r}
     cshard = {(r.get("config"), r["shard_of"]): r for r in crows_all if "shard_of" in r}
-    out = {}
+    out = {"cols": SHARD8_COLS, "src": ["bench.py", "libmc_multi"]}
+    multi_all = {}
     for c, r in rows.items():
         s8, c1, c8 = shard.get((c, 8)), crows.get(c), cshard.get((c, 8))
-        e = {"t1_ms": [r["wall_ms_median"], c1["wall_ms_median"] if c1 else None]}
+        cols = [[r["wall_ms_median"], c1["wall_ms_median"] if c1 else None]]
         if s8 or c8:
-            e["t8_ms"] = [s8["wall_ms_median"] if s8 else None, c8["wall_ms_median"] if c8 else None]
-            e["eff8"] = [s8["device_side_efficiency"] if s8 else None, c8["device_side_efficiency"] if c8 else None]
+            cols.append([s8["wall_ms_median"] if s8 else None, c8["wall_ms_median"] if c8 else None])
+            cols.append([s8["device_side_efficiency"] if s8 else None, c8["device_side_efficiency"] if c8 else None])
             cold = [(x or {}).get("cold", {}).get("device_side_efficiency") for x in (s8, c8)]
             if any(v is not None for v in cold):
-                e["eff8_cold"] = cold
-        multi = {str(x["devices"]): [x["wall_ms_median"], x.get("strong_efficiency_vs_1"), x.get("fanout_us")]
+                cols.append(cold)
+        out[c] = cols
+        multi = {str(x["devices"]): [x["wall_ms_median"], x.get("strong_efficiency_vs_1"), x.get("fanout_us"), x.get("collective_us")]
                  for x in crows_all if x.get("config") == c and x.get("devices", 1) > 1 and "shard_of" not in x}
         if multi:
-            e["c_devices"] = multi
-        out[c] = e
+            multi_all[c] = multi
+    if multi_all:
+        out["c_devices"] = multi_all
+    return out
+
+
+def configs_summary(detail):
+    """BASELINE configs[1..4] in the compact line: per config paths_per_s, kernel_us (the kernel alone), frac (flop), issue_frac (ceiling
+    at 2.4 GHz / kernel), issue_frac_clk (= issue_frac_at_measured_clock, the ceiling at sclk_mhz), price, err against `vs`, and
+    cpu_baseline = the reference's CPU path timed on this host (paths/s, cores, kind); C2 also single_call = [wall us, paths/s] of ONE
+    synchronous call.  4 significant digits except the rates."""
+    cf = detail.get("configs")
+    if not cf:
+        return None
+    short = {"Black-Scholes": "BS", "the same basket in fp64, 1e9 paths": "fp64 1e9 paths", "the same basket, 1e10 paths (C4x10)": "C4x10",
+             "closed form LGD C0 sum dPD_j e^(r t_j)": "closed form"}
+    out = {}
+    for name, e in cf.items():
+        o = _pick(e, "paths_per_s", "kernel_us", "frac", "issue_frac")
+        if e.get("issue_frac_at_measured_clock") is not None:
+            o["issue_frac_clk"] = e["issue_frac_at_measured_clock"]
+        o.update(_pick(e, "sclk_mhz", "err"))
+        if e.get("vs"):
+            o["vs"] = short.get(e["vs"], e["vs"])
+        o = _sig(o, 4)
+        if e.get("price") is not None:
+            o["price"] = float(f"{e['price']:.7g}")
+        if e.get("paths_per_s"):
+            o["paths_per_s"] = float(f"{e['paths_per_s']:.5g}")
+        if e.get("cpu"):
+            o["cpu_baseline"] = {"value": float(f"{e['cpu'].get('value', 0):.4g}"), "cores": e["cpu"].get("cores"), "kind": e["cpu"].get("kind")}
+        if e.get("single_call"):
+            o["single_call"] = [float(f"{e['single_call']['wall_us']:.4g}"), float(f"{e['single_call']['paths_per_s']:.4g}")]
+        out[name] = o
     return out
 
 
@@ -444,15 +790,18 @@ def compact_line(detail, detail_name="bench_detail.json"):
     cfg = d.get("config", {})
     line["config"] = _pick(cfg, "workload", "paths_per_gpu_per_step", "global_paths_per_step", "parallelism", "rng", "seed", "grid",
                            "streams", "finish", "preheat_ms", "engine_settings", "detail")
+    if "parallelism" in line["config"]:
+        line["config"]["parallelism"] = str(line["config"]["parallelism"]).split(",")[0]      # "path-sharded xN" (the rest: detail file)
+    if "rng" in line["config"]:
+        line["config"]["rng"] = "Philox4x32-10, counter = path index"
     line.update(_pick(d, "timed_region_s", "regions"))
-    body = _pick(d, "ms_per_step_min", "ms_per_step_max", "region_ms_per_step", "price", "confidence_95", "paths_priced",
-                 "price_error_vs_black_scholes")
+    body = _pick(d, "ms_per_step_min", "ms_per_step_max", "price", "confidence_95", "paths_priced", "price_error_vs_black_scholes")
     r = d.get("roofline") or {}
-    roof = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "kernel", "flop_per_path", "avg_kernel_us",
-                 "kernel_samples", "issue_frac", "hbm_gbps", "launch_stamp", "grid_workgroups")
+    roof = _pick(r, "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "kernel", "avg_kernel_us",
+                 "issue_frac", "issue_frac_at_measured_clock", "sclk_mhz", "hbm_gbps", "grid_workgroups")
     roof.setdefault("traffic", None)
     if r.get("in_region"):
-        roof["in_region"] = _pick(r["in_region"], "avg_kernel_us", "kernel_samples", "concurrent_launches", "step_period_us")
+        roof["in_region"] = _pick(r["in_region"], "avg_kernel_us", "concurrent_launches", "step_period_us")
     if r.get("effective"):
         roof["effective"] = _pick(r["effective"], "achieved", "frac")
     if r.get("issue_model"):
@@ -464,27 +813,27 @@ def compact_line(detail, detail_name="bench_detail.json"):
         c = d["cpu_baseline"]
         body["cpu_baseline"] = _pick(c, "value", "unit", "cores", "kind", "host_cpus_granted", "value_at_O0")
         body["cpu_baseline"]["sample"] = c.get("sample_short") or str(c.get("sample", ""))[:80]
-    if d.get("cpu_all_cores"):
-        body["cpu_all_cores"] = _pick(d["cpu_all_cores"], "value", "unit", "cores")
     if d.get("fp64"):
         body["fp64"] = _pick(d["fp64"], "value", "unit", "steps", "ms_per_step", "price_error_vs_black_scholes")
+    cs = configs_summary(d)
+    if cs:
+        body["configs"] = cs
     ss = strong_summary(d)
     if ss:
         body["strong_summary"] = ss
     body.update(_pick(d, "world_size", "backend", "rccl_version", "ranks", "devices_visible", "device"))
-    line.update(_sig(body))
+    line.update(_sig(body, 5))
     line["detail"] = detail_name
     # never above the limit: shed the least important parts first, and say so
     dropped = []
 
     def size():
         return len(json.dumps(dict(line, dropped_for_size=dropped) if dropped else line))
-    for k in ("cpu_all_cores", "region_ms_per_step", "strong_summary.c_devices", "fp64", "strong_summary", "ranks"):
+    for k in ("strong_summary.c_devices", "fp64", "device", "strong_summary", "ranks", "configs"):
         if size() <= LINE_LIMIT:
             break
         if k == "strong_summary.c_devices":
-            hit = [e.pop("c_devices", None) for e in (line.get("strong_summary") or {}).values() if isinstance(e, dict)]
-            if any(h is not None for h in hit):
+            if (line.get("strong_summary") or {}).pop("c_devices", None) is not None:
                 dropped.append(k)
         elif line.pop(k, None) is not None:
             dropped.append(k)
@@ -506,7 +855,12 @@ def main():
                          "20-step region is 1 ms, one sample of it moves by +-4 %% between runs")
     ap.add_argument("--workload", default="vanilla_f32")
     ap.add_argument("--paths", type=int, default=0, help="paths per GPU per step (default: the workload's)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample length (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0,
+                    help="CPU baseline sample length of the headline workload (0 = skip every CPU baseline); the other configs' CPU paths "
+                         "run for 2 s each")
+    ap.add_argument("--configs", type=int, default=1,
+                    help="1 (default): N = 1 also measures BASELINE configs[2..4] (C3 basket n=4 fp32, C4 basket n=16 fp64 1e9 paths, C5 CVA "
+                         "256 x 1e7 fp64) with roofline fractions, price error and the reference's CPU path beside each; 0 = skip")
     ap.add_argument("--detail", default="brief", choices=["brief", "full"],
                     help="brief (default): strong rows C4, C5, their 10x sizes, C4 / C5 on fp32 normals, shard 0 of 8 -- the driver's run "
                          "stays under a minute.  full: also the 10x sizes on fp32 normals, shard 0 of 2 and of 4, the -O0 CPU build")
@@ -740,7 +1094,15 @@ def main():
     # The dominant kernel alone on the device (outside the timed region): with 2 streams the timed launches
     # overlap their neighbours, which stretches every per-kernel duration.
     exclusive = None
+    my_pci = mc.pci_bus_id(local)
+    sclk_headline = None
     if args.exclusive_launches > 0:
+        # the clock the card holds while this kernel runs back to back (amdgpu hwmon, sampled by a side thread): the exclusive
+        # launches below follow at once, in that state
+        clk_out = torch.zeros((len(engines), 3), dtype=torch.float64, device="cuda")
+        sclk_headline = sustained_clock(torch, engines, launch_streams,
+                                        lambda i, e_, st_: e_.launch(prod, X, structs[engines.index(e_)][0], seed, (1 << 52) + i * shard_count, shard_count,
+                                                                     clk_out[engines.index(e_)].data_ptr(), st_), my_pci, 150.0)
         n_ex = min(args.exclusive_launches, 512)
         solo = torch.zeros((n_ex, 3), dtype=torch.float64, device="cuda")
         eng.profile(1)
@@ -800,7 +1162,7 @@ def main():
     # who took part: one entry per rank -- local device index, its PCI bus id (hipDeviceGetPCIBusId through the C ABI), host.
     # Exchanged as fixed-size byte tensors through dist.all_gather (the same call on RCCL and on gloo, also with ONE rank, so the
     # one-GPU boxes exercise the exact code an 8-GPU node runs; all_gather_object would pickle and stage through the device)
-    me = {"rank": rank, "device": local, "pci": mc.pci_bus_id(local), "host": os.uname().nodename[:64], "pid": os.getpid()}
+    me = {"rank": rank, "device": local, "pci": my_pci, "host": os.uname().nodename[:64], "pid": os.getpid()}
     roster = [me]
     if grouped:
         where = "cuda" if args.backend == "nccl" else "cpu"
@@ -889,40 +1251,14 @@ def main():
                                        "paths_per_s_per_gpu": shard_count / step_s,
                                        "note": "flop of one GPU's step / step period (whole job, launch gaps and tails included)"}},
         }
-        # SURVEY 8d's second fraction: the VALU issue CEILING of the launch, from the kernel's own instruction stream --
-        # the opcode histogram of its hot loop (ISA listing) x the cheapest issue cost tools/ubench measured for each opcode,
-        # cross-checked against the hardware's instruction counters (tools/issue_model.py -> profiles/issue_model.json).
-        # A time no launch of this kernel can beat: issue_frac <= 1 by construction (round 3 charged every plain
-        # instruction its mixed-stream 4.1 cycles and reported 1.036 on the step period).
         if traffic_stale:
             out["roofline"]["traffic_stale_note"] = ("the device code object, the launch-shape rules (csrc/mc_launch_shape.hpp), HIPFLAGS or the "
                                                      "launched grid changed since profiles/pmc_traffic.json was collected (tools/collect_pmc_all.sh): "
                                                      "traffic is the old launches', issue_frac is withheld")
-        model = {}
-        try:
-            model = json.load(open(os.path.join(ROOT, "profiles", "issue_model.json"))).get(args.workload, {})
-        except (OSError, ValueError):
-            model = {}
-        if model and kernel_s and not traffic_stale and model.get("launch_stamp") == stamp["stamp"] and \
-                (model.get("cross_check_ok") or model.get("rescaled_to_counters")):
-            waves_trips = shard_count / 64.0
-            ceil_s = model["min_cycles_per_path"] * waves_trips / model["simds"] / model["clock_hz"]
-            typ_s = model["typical_cycles_per_path"] * waves_trips / model["simds"] / model["clock_hz"]
-            out["roofline"]["issue_frac"] = ceil_s / kernel_s
-            out["roofline"]["issue_model"] = {
-                "ceiling_us": ceil_s * 1e6, "kernel_us": kernel_s * 1e6, "frac_effective": ceil_s / step_s,
-                "typical_us": typ_s * 1e6, "typical_frac": typ_s / kernel_s,
-                "valu_insts_per_path": model["valu_per_path"], "min_cycles_per_path": model["min_cycles_per_path"],
-                "simds": model["simds"], "clock_hz": model["clock_hz"], "source": model.get("source"),
-                "cross_check": {"pmc_vs_histogram_valu": model.get("pmc_vs_model"), "ok_within_1pct": bool(model.get("cross_check_ok")),
-                                "rescaled_to_counters": bool(model.get("rescaled_to_counters"))},
-                "valu_busy_long_launch": committed.get("valu_busy_long_launch"), "valu_busy_source": committed.get("valu_busy_source"),
-                "note": "ceiling = sum over the hot loop's VALU instructions of the CHEAPEST issue cost measured for the opcode x wave-trips / "
-                        "(1024 SIMDs x 2.4 GHz): a lower bound on the launch time, so issue_frac <= 1; typical_us prices the same histogram at "
-                        "the costs of mixed streams (4.1 / 8.1 / 16.2 cycles) -- an estimate, not a bound"}
-        elif model:
-            out["roofline"]["issue_model_withheld"] = ("profiles/issue_model.json does not describe this build (stamp) or failed its cross-check "
-                                                       "against the hardware counters: re-run tools/collect_pmc_all.sh and tools/issue_model.py")
+        # SURVEY 8d's second fraction (issue_ceiling above): at the chip's peak clock and at the clock measured during this run
+        out["roofline"].update(issue_ceiling(args.workload, shard_count, kernel_s, step_s, stamp, traffic_stale, committed, sclk_headline) or {})
+        if sclk_headline and "sclk_mhz" not in out["roofline"]:
+            out["roofline"]["sclk_mhz"] = sclk_headline
         if prod == "vanilla":
             out["price_error_vs_black_scholes"] = abs(price - BS_EXACT)
         if fp64_side:
@@ -935,6 +1271,10 @@ def main():
                 extra = cpu_all_cores(1.5)
                 if extra:
                     out["cpu_all_cores"] = extra
+        if world == 1 and args.workload == "vanilla_f32" and args.configs:
+            # BASELINE.json names five configs: configs[0] is the CPU run (tests), the other four are measured here, one GPU
+            out["configs"] = configs_block(mc, torch, engines, launch_streams, my_pci, out, strong, stamp,
+                                           cpu_seconds=min(2.0, args.cpu_seconds) if args.cpu_seconds > 0 else 0.0)
         if world == 1 and args.c_multi_seconds > 0 and args.workload == "vanilla_f32":
             for e in engines:       # the child process gets the GPU to itself
                 e.close()

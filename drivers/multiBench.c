@@ -63,6 +63,8 @@ static int one_call(mc_multi *m, const Work *w, uint64_t first, uint64_t n, mc_r
 
 typedef struct {
     double med, min, fanout_us, fanout_us_max, preheat_ms;
+    double collective_us;          /* median over the timed calls: last device's own triple on the host -> all-reduced triple on the host (-1: not measured) */
+    double device_us_min, device_us_max;   /* last timed call: earliest / latest device delivery since call entry */
     int calls_preheat;
 } Timing;
 
@@ -82,17 +84,30 @@ static int time_row(mc_multi *m, const Work *w, uint64_t first, uint64_t n, int 
         out->calls_preheat++;
     }
     out->preheat_ms = hot ? (now_s() - p0) * 1e3 : 0.0;
-    double fan = 0, fan_max = 0;
+    double fan = 0, fan_max = 0, coll[MAX_REPS];
+    int n_coll = 0;
     for (int i = 0; i < reps; ++i) {
         const double t0 = now_s();
         CHECK(one_call(m, w, first, n, r));
         t[i] = now_s() - t0;
-        const double f = mc_multi_last_fanout_us(m);
+        const double f = mc_multi_last_fanout_us(m), c = mc_multi_last_collective_us(m);
         fan += f, fan_max = f > fan_max ? f : fan_max;
+        if (c >= 0)
+            coll[n_coll++] = c;
     }
     out->fanout_us_max = fan_max;
     qsort(t, (size_t)reps, sizeof t[0], cmp_double);
     out->med = t[reps / 2], out->min = t[0], out->fanout_us = fan / reps;
+    qsort(coll, (size_t)n_coll, sizeof coll[0], cmp_double);
+    out->collective_us = n_coll ? coll[n_coll / 2] : -1.0;
+    double dev[64];
+    const int G = mc_multi_last_device_us(m, 64, dev);
+    out->device_us_min = out->device_us_max = -1.0;
+    for (int g = 0; g < G && g < 64; ++g)
+        if (dev[g] >= 0) {
+            out->device_us_min = (out->device_us_min < 0 || dev[g] < out->device_us_min) ? dev[g] : out->device_us_min;
+            out->device_us_max = dev[g] > out->device_us_max ? dev[g] : out->device_us_max;
+        }
     return 0;
 }
 
@@ -159,7 +174,7 @@ int main(int argc, char **argv)
         printf("{\"devices\": %d, \"create_s\": %.3f, \"launcher_threads\": %d, \"what\": \"contexts + ncclCommInitAll + first call, once per handle\"}\n", G,
                create_s, mc_multi_launcher_threads(m));
         for (int k = 0; k < n_work; ++k) {
-            Timing hot, cd = {0, 0, 0, 0, 0, 0};
+            Timing hot, cd = {0};
             if (time_row(m, &work[k], 0, work[k].paths, reps, events, 1, preheat_ms, &hot, &r)) return 1;
             const mc_result res = r;
             const double rel = mc_multi_last_reduce_error(m);
@@ -172,9 +187,11 @@ int main(int argc, char **argv)
                 t1[k] = hot.med, t1_cold[k] = cd.med;
             printf("{\"devices\": %d, \"config\": \"%s\", \"workload\": \"%s\", \"normals\": \"%s\", \"paths\": %llu, \"reps\": %d, \"preheat_ms\": %.0f, \"wall_ms_median\": %.4f, "
                    "\"wall_ms_min\": %.4f, \"paths_per_s\": %.6g, \"strong_efficiency_vs_1\": %.4f, \"kernel_ms_slowest_device\": %.4f, "
-                   "\"fanout_us\": %.2f, \"fanout_us_max\": %.2f, \"value\": %.9g, \"confidence_95\": %.3g, \"rccl_vs_host_rel\": %.3g",
+                   "\"fanout_us\": %.2f, \"fanout_us_max\": %.2f, \"collective_us\": %.2f, \"device_delivery_us\": [%.1f, %.1f], \"value\": %.9g, "
+                   "\"confidence_95\": %.3g, \"rccl_vs_host_rel\": %.3g",
                    G, work[k].config, work[k].name, work[k].n32 ? "f32" : "f64", (unsigned long long)work[k].paths, reps, hot.preheat_ms, hot.med * 1e3,
-                   hot.min * 1e3, (double)work[k].paths / hot.med, t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0, kernel_ms, hot.fanout_us, hot.fanout_us_max, res.expected, res.confidence, rel);
+                   hot.min * 1e3, (double)work[k].paths / hot.med, t1[k] > 0 ? t1[k] / (G * hot.med) : 0.0, kernel_ms, hot.fanout_us, hot.fanout_us_max, hot.collective_us, hot.device_us_min, hot.device_us_max,
+                   res.expected, res.confidence, rel);
             if (do_cold)
                 printf(", \"cold\": {\"wall_ms_median\": %.4f, \"wall_ms_min\": %.4f, \"strong_efficiency_vs_1\": %.4f, \"what\": \"0.5 s idle, 2 warm-up calls, 5 calls\"}",
                        cd.med * 1e3, cd.min * 1e3, t1_cold[k] > 0 ? t1_cold[k] / (G * cd.med) : 0.0);
@@ -201,7 +218,7 @@ int main(int argc, char **argv)
             for (int k = 0; k < n_work; ++k) {
                 uint64_t lo = 0, cnt = 0;
                 mc_shard_range(work[k].paths, 0, G, &lo, &cnt);
-                Timing hot, cd = {0, 0, 0, 0, 0, 0};
+                Timing hot, cd = {0};
                 if (time_row(m, &work[k], lo, cnt, reps, events, 1, preheat_ms, &hot, &r)) return 1;
                 CHECK(mc_multi_set_timing(m, 1));
                 CHECK(one_call(m, &work[k], lo, cnt, &r));

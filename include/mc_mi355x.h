@@ -309,11 +309,22 @@ int mc_vanilla_greeks_lr_run_f64(mc_context *ctx, const mc_option_f64 *opt, uint
  * On the pricing kernels' stream and path indexing (reference formulas dp/MonteCarloKernel.cu:74-101), with
  * B = sum_a w_a S_a(T), I = [B > K]:  price,  delta[a] = dV/dS_a = I w_a S_a(T) / S_a,
  * vega[a] = dV/dv_a = I w_a S_a(T) (bt_a sqrt T - v_a T); discounted means with their own 95 % half-widths.
- * delta and vega are caller arrays of opt->n results.  Plain estimator; the path is re-simulated once per asset. */
+ * delta and vega are caller arrays of opt->n results.  Plain estimator; one pass over the paths per 8 assets (a lane keeps the
+ * (sum, sum2) pairs of the price and of eight assets' two derivatives in registers). */
 int mc_basket_greeks_run_f32(mc_context *ctx, const mc_basket_f32 *opt, uint64_t seed, uint64_t first_path,
                              uint64_t n_paths, mc_result *price, mc_result *delta, mc_result *vega);
 int mc_basket_greeks_run_f64(mc_context *ctx, const mc_basket_f64 *opt, uint64_t seed, uint64_t first_path,
                              uint64_t n_paths, mc_result *price, mc_result *delta, mc_result *vega);
+/* Likelihood-ratio forms of the same 1 + 2n numbers: the payoff times the score of the terminal prices' joint lognormal
+ * density.  With y = L^-T g (the path's normals whitened by the inverse factor, formed on the host):
+ *   delta[a] = payoff y_a / (S_a v_a sqrt T),
+ *   vega[a]  = payoff [ (y_a (L g)_a - 1) / v_a + (sqrt T d_a - v_a T) y_a / (v_a sqrt T) ]
+ * (one asset: the vanilla forms above).  Needs t > 0, every v[a] > 0 and a non-singular factor (every p[a][a] > 0 -- the
+ * reference driver's own 3 x 3 correlation is singular, SURVEY 2.3 #10, and is refused). */
+int mc_basket_greeks_lr_run_f32(mc_context *ctx, const mc_basket_f32 *opt, uint64_t seed, uint64_t first_path,
+                                uint64_t n_paths, mc_result *price, mc_result *delta, mc_result *vega);
+int mc_basket_greeks_lr_run_f64(mc_context *ctx, const mc_basket_f64 *opt, uint64_t seed, uint64_t first_path,
+                                uint64_t n_paths, mc_result *price, mc_result *delta, mc_result *vega);
 
 /* ---- CVA with its pathwise delta and vega -------------------------------------------------
  * On the CVA kernel's stream (reference loop dp/MonteCarloKernel.cu:241-262), not discounted, like the CVA itself (:466):
@@ -325,6 +336,15 @@ int mc_cva_greeks_run_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed,
                           uint64_t n_paths, mc_cva_greeks *out);
 int mc_cva_greeks_run_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed, uint64_t first_path,
                           uint64_t n_paths, mc_cva_greeks *out);
+/* Likelihood-ratio forms: only the first transition's density depends on S_0, every transition's on sigma, and the closed-form
+ * exposure depends on sigma explicitly (that part stays pathwise):
+ *   d CVA / d S_0   = E[ CVA_path z_1 ] / (S_0 sigma sqrt(dt))
+ *   d CVA / d sigma = E[ LGD sum_j dp_j S_j phi(d1_j) sqrt(tau_j) + CVA_path sum_j ((z_j^2 - 1) / sigma - z_j sqrt(dt)) ]
+ * Same stream, same CVA plane; the variance grows with the number of dates (the scores add up). */
+int mc_cva_greeks_lr_run_f32(mc_context *ctx, const mc_cva_f32 *cva, uint64_t seed, uint64_t first_path,
+                             uint64_t n_paths, mc_cva_greeks *out);
+int mc_cva_greeks_lr_run_f64(mc_context *ctx, const mc_cva_f64 *cva, uint64_t seed, uint64_t first_path,
+                             uint64_t n_paths, mc_cva_greeks *out);
 
 /* ---- per-path values, for parity tests ---------------------------------------------------
  * h_out: HOST pointer to n_paths values (undiscounted payoffs / per-path CVA).  Same kernels

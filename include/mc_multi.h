@@ -73,7 +73,12 @@ int mc_multi_set_reduce(mc_multi *m, int mode);
  * the calling thread -- a sleeping thread's job is run by the caller AT ONCE (no wake-up on the critical path; the sleepers are
  * woken after the fan-out, and only when calls shorter than the linger time come within the linger time of each other), the job of a spinning thread that
  * has not taken it 15 us after the hand-off (its core was taken away) likewise.  What no take-over can bound: a thread that loses
- * its core INSIDE the job it has claimed (or a runtime call that blocks) -- counted as `slow_claimed`.
+ * its core INSIDE the job it has claimed (or a runtime call that blocks) -- counted as `slow_claimed` (5 of 2.4 million jobs took
+ * more than 1 ms that way, the worst 7.66 ms, p99.9 of the whole fan-out 58 us: profiles/r05_multi_soak_300k_calls.log).  The
+ * WAIT for such a job is bounded all the same: when a launcher thread has not returned from a launch it claimed 20 s after the
+ * hand-off, mc_multi_*_run_* fails with MC_ERR_HIP naming the device instead of spinning for ever.  The handle is unusable
+ * from then on (every later call fails at once) and mc_multi_destroy leaks it on purpose -- the stuck thread may still come back
+ * and touch it; the option struct passed to the call that timed out must stay valid for as long as the process lives.
  * What the threads buy, measured with timing OFF (mc_multi_set_timing(m, 0): pinned-slot read-back, what the legacy symbols
  * use): eight launches enqueued in 8.8 us (median) instead of 22.2 serial; the tail is in profiles/r05_multi_soak_*.log
  * (p50 / p99 / p99.9 / max of every call's fan-out, and who was late in the slowest twenty).  With timing on, every call ends
@@ -87,6 +92,12 @@ int mc_multi_set_reduce(mc_multi *m, int mode);
  * configuration as one line (printed to stderr at creation under MC_VERBOSE=2).  One calling thread per handle. */
 int mc_multi_launcher_threads(const mc_multi *m);
 double mc_multi_last_fanout_us(const mc_multi *m);
+/* The collective as the calling thread saw it, last call, pinned-slot read-back (timing off) with MC_REDUCE_RCCL: microseconds from
+ * the moment the LAST device's own triple was visible on the host to the moment the all-reduced triple was -- the grouped
+ * ncclAllReduce plus the one-lane publish kernel behind it (-1: not measured: host reduction, copy read-back).
+ * mc_multi_last_device_us: per device, microseconds from call entry until its own triple was visible (returns the device count). */
+double mc_multi_last_collective_us(const mc_multi *m);
+int mc_multi_last_device_us(const mc_multi *m, int cap, double *delivered_us);
 int mc_multi_last_fanout_trace(const mc_multi *m, int cap, double *seen_us, double *enqueued_us);
 typedef struct {
     uint64_t calls, by_worker, served_parked, stolen, slow_claimed, wakeups;

@@ -91,7 +91,8 @@ for _x in ("f32", "f64"):
     for _p in ("vanilla", "basket", "cva"):
         EXPORTS += [f"mc_{_p}_launch_{_x}", f"mc_{_p}_run_{_x}", f"mc_{_p}_paths_{_x}"]
     EXPORTS += [f"mc_{_p}_run_grid_{_x}" for _p in ("vanilla", "basket", "cva")]       # the reference's launch geometry
-    EXPORTS += [f"mc_vanilla_greeks_run_{_x}", f"mc_vanilla_greeks_lr_run_{_x}", f"mc_basket_greeks_run_{_x}", f"mc_cva_greeks_run_{_x}"]
+    EXPORTS += [f"mc_vanilla_greeks_run_{_x}", f"mc_vanilla_greeks_lr_run_{_x}", f"mc_basket_greeks_run_{_x}", f"mc_cva_greeks_run_{_x}",
+                f"mc_basket_greeks_lr_run_{_x}", f"mc_cva_greeks_lr_run_{_x}"]
     TEST_EXPORTS.append(f"mc_normals_{_x}")
     TEST_EXPORTS += [f"mc_{_p}_from_normals_{_x}" for _p in ("vanilla", "basket", "cva")]
     TEST_EXPORTS += [f"mc_{_p}_paths_grid_{_x}" for _p in ("vanilla", "basket", "cva")]
@@ -158,6 +159,9 @@ def _declare(L: C.CDLL) -> C.CDLL:
         getattr(L, f"mc_basket_greeks_run_{X}").argtypes = [ctx, C.POINTER(BASKET[X]), u64, u64, u64, C.POINTER(Result), C.POINTER(Result),
                                                             C.POINTER(Result)]
         getattr(L, f"mc_cva_greeks_run_{X}").argtypes = [ctx, C.POINTER(CVA[X]), u64, u64, u64, C.POINTER(CvaGreeks)]
+        getattr(L, f"mc_basket_greeks_lr_run_{X}").argtypes = [ctx, C.POINTER(BASKET[X]), u64, u64, u64, C.POINTER(Result), C.POINTER(Result),
+                                                               C.POINTER(Result)]
+        getattr(L, f"mc_cva_greeks_lr_run_{X}").argtypes = [ctx, C.POINTER(CVA[X]), u64, u64, u64, C.POINTER(CvaGreeks)]
     return L
 
 

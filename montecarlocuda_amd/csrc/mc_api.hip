@@ -1768,7 +1768,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
 // ---------------------------------------------------------------------------------------
 // Greeks of the basket call and of the CVA: secondary kernels, plain estimator, synchronous
 // ---------------------------------------------------------------------------------------
-template <class Real>
+template <class Real, bool LR>
 static int basket_greeks_run(mc_context *c, const typename BasketIn<Real>::type *o, uint64_t seed, uint64_t first, uint64_t n,
                              mc_result *price, mc_result *delta, mc_result *vega)
 {
@@ -1786,8 +1786,37 @@ static int basket_greeks_run(mc_context *c, const typename BasketIn<Real>::type 
     const int na = o->n;
     const double sqrt_t = std::sqrt((double)o->t);
     // table: L[n*n] | d | mu | v | w | s | 1/s | v t      (the reference's unfolded constants, dp/MonteCarloKernel.cu:74-101)
-    std::vector<Real> host((size_t)na * na + 7 * (size_t)na, (Real)0);
+    //        | likelihood ratio only: M = L^-T [n*n] | 1 / (s v sqrt t) | 1 / v | (sqrt t d - v t) / (v sqrt t)
+    std::vector<Real> host((size_t)na * na + 7 * (size_t)na + (LR ? (size_t)na * na + 3 * (size_t)na : 0), (Real)0);
     Real *L = host.data(), *d = L + (size_t)na * na, *mu = d + na, *v = mu + na, *w = v + na, *s0 = w + na, *inv_s = s0 + na, *vt = inv_s + na;
+    if (LR) {
+        // The scores divide by sigma sqrt t and whiten with the inverse factor: y = L^-T g, i.e. M = L^-T (upper triangular), in
+        // fp64 from the caller's factor by back-substitution on the columns of L^-1, rounded once
+        if (!((double)o->t > 0))
+            return fail(MC_ERR_INVALID, "likelihood-ratio greeks: need t>0 (the scores divide by sigma sqrt t)");
+        std::vector<double> inv((size_t)na * na, 0.0);   // L^-1, lower triangular
+        for (int a = 0; a < na; ++a) {
+            const double laa = (double)o->p[a * na + a];
+            if (!((double)o->v[a] > 0) || !(laa > 0))
+                return fail(MC_ERR_INVALID, "likelihood-ratio greeks: need v[%d] > 0 and a non-singular factor (p[%d][%d] = %g): the joint density "
+                                            "of the terminal prices must exist", a, a, a, laa);
+            for (int b = 0; b <= a; ++b) {
+                double acc = a == b ? 1.0 : 0.0;
+                for (int k = b; k < a; ++k)
+                    acc -= (double)o->p[a * na + k] * inv[(size_t)k * na + b];
+                inv[(size_t)a * na + b] = acc / laa;
+            }
+        }
+        Real *M = vt + na, *inv_svt = M + (size_t)na * na, *inv_v = inv_svt + na, *mcoef = inv_v + na;
+        for (int a = 0; a < na; ++a) {
+            for (int b = a; b < na; ++b)
+                M[(size_t)a * na + b] = (Real)inv[(size_t)b * na + a];   // (L^-T)_ab = (L^-1)_ba
+            const double va = (double)o->v[a];
+            inv_svt[a] = (Real)(1.0 / ((double)o->s[a] * va * sqrt_t));
+            inv_v[a] = (Real)(1.0 / va);
+            mcoef[a] = (Real)((sqrt_t * (double)o->d[a] - va * (double)o->t) / (va * sqrt_t));
+        }
+    }
     for (int a = 0; a < na; ++a) {
         if (!finite_pos((double)o->s[a]))
             return fail(MC_ERR_INVALID, "basket greeks: need s[a] > 0 (delta is taken with respect to it)");
@@ -1809,7 +1838,7 @@ static int basket_greeks_run(mc_context *c, const typename BasketIn<Real>::type 
     std::vector<char> key(bytes + 2);
     memcpy(key.data(), host.data(), bytes);
     key[bytes] = (char)sizeof(Real);
-    key[bytes + 1] = 'G';
+    key[bytes + 1] = LR ? 'R' : 'G';
     if (int rc = begin_call(c, c->stream)) return rc;
     if (int rc = upload_table(c, c->stream, key, host.data(), bytes)) return rc;
     BasketGreeks<Real> k;
@@ -1819,28 +1848,40 @@ static int basket_greeks_run(mc_context *c, const typename BasketIn<Real>::type 
     k.sqrt_t = (Real)sqrt_t;
     constexpr int NPB = GenPhilox::npb<Real>();
     const size_t lds = (size_t)((na + NPB - 1) / NPB * NPB) * GROUP * sizeof(Real);
-    HIPCHK(hipFuncSetAttribute((const void *)basket_greeks_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute((const void *)basket_greeks_kernel<Real, LR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     std::vector<mc_result *> out(1 + 2 * (size_t)na);
     out[0] = price;
     for (int a = 0; a < na; ++a)
         out[1 + a] = delta + a, out[1 + na + a] = vega + a;
-    return planes_run(c, sizeof(Real), 1 + 2 * na, na, first, n, n, std::exp(-(double)o->r * (double)o->t), out.data(),
+    // one pass per BASKET_GREEKS_CHUNK assets: the grid's y index is the chunk
+    const int chunks = (na + BASKET_GREEKS_CHUNK - 1) / BASKET_GREEKS_CHUNK;
+    return planes_run(c, sizeof(Real), 1 + 2 * na, chunks, first, n, n, std::exp(-(double)o->r * (double)o->t), out.data(),
                       [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
-                          hipLaunchKernelGGL(basket_greeks_kernel<Real>, dim3(g, na), dim3(GROUP), lds, st, t, k, make_work(seed, s, 0, 0));
+                          hipLaunchKernelGGL((basket_greeks_kernel<Real, LR>), dim3(g, chunks), dim3(GROUP), lds, st, t, k, make_work(seed, s, 0, 0));
                       });
 }
 extern "C" int mc_basket_greeks_run_f32(mc_context *c, const mc_basket_f32 *o, uint64_t seed, uint64_t first, uint64_t n,
                                         mc_result *price, mc_result *delta, mc_result *vega)
 {
-    return basket_greeks_run<float>(c, o, seed, first, n, price, delta, vega);
+    return basket_greeks_run<float, false>(c, o, seed, first, n, price, delta, vega);
 }
 extern "C" int mc_basket_greeks_run_f64(mc_context *c, const mc_basket_f64 *o, uint64_t seed, uint64_t first, uint64_t n,
                                         mc_result *price, mc_result *delta, mc_result *vega)
 {
-    return basket_greeks_run<double>(c, o, seed, first, n, price, delta, vega);
+    return basket_greeks_run<double, false>(c, o, seed, first, n, price, delta, vega);
+}
+extern "C" int mc_basket_greeks_lr_run_f32(mc_context *c, const mc_basket_f32 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                           mc_result *price, mc_result *delta, mc_result *vega)
+{
+    return basket_greeks_run<float, true>(c, o, seed, first, n, price, delta, vega);
+}
+extern "C" int mc_basket_greeks_lr_run_f64(mc_context *c, const mc_basket_f64 *o, uint64_t seed, uint64_t first, uint64_t n,
+                                           mc_result *price, mc_result *delta, mc_result *vega)
+{
+    return basket_greeks_run<double, true>(c, o, seed, first, n, price, delta, vega);
 }
 
-template <class Real>
+template <class Real, bool LR>
 static int cva_greeks_run(mc_context *c, const typename CvaIn<Real>::type *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
 {
     if (int rc = check_common(c, v, first, n, out)) return rc;
@@ -1853,17 +1894,26 @@ static int cva_greeks_run(mc_context *c, const typename CvaIn<Real>::type *v, ui
     const Real inv_spot = (Real)(1.0 / (double)v->option.s);
     const Real dt = v->option.t / v->n_grid;   // the table's own dt (build_cva_table)
     const Real sqrt_dt = (Real)std::sqrt((double)dt);
+    const Real lr_delta = (Real)(1.0 / ((double)v->option.s * (double)v->option.v * std::sqrt((double)dt))), inv_sigma = (Real)(1.0 / (double)v->option.v);
     return planes_run(c, sizeof(Real), 3, 1, first, n, n, 1.0, r, [&](const Tail &t, const Segment &s, int g, hipStream_t st) {
-        cva_greeks_kernel<Real><<<g, GROUP, 0, st>>>(t, args, make_work(seed, s, 0, 0), inv_spot, sqrt_dt);
+        cva_greeks_kernel<Real, LR><<<g, GROUP, 0, st>>>(t, args, make_work(seed, s, 0, 0), inv_spot, sqrt_dt, lr_delta, inv_sigma);
     });
 }
 extern "C" int mc_cva_greeks_run_f32(mc_context *c, const mc_cva_f32 *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
 {
-    return cva_greeks_run<float>(c, v, seed, first, n, out);
+    return cva_greeks_run<float, false>(c, v, seed, first, n, out);
 }
 extern "C" int mc_cva_greeks_run_f64(mc_context *c, const mc_cva_f64 *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
 {
-    return cva_greeks_run<double>(c, v, seed, first, n, out);
+    return cva_greeks_run<double, false>(c, v, seed, first, n, out);
+}
+extern "C" int mc_cva_greeks_lr_run_f32(mc_context *c, const mc_cva_f32 *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
+{
+    return cva_greeks_run<float, true>(c, v, seed, first, n, out);
+}
+extern "C" int mc_cva_greeks_lr_run_f64(mc_context *c, const mc_cva_f64 *v, uint64_t seed, uint64_t first, uint64_t n, mc_cva_greeks *out)
+{
+    return cva_greeks_run<double, true>(c, v, seed, first, n, out);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -1577,15 +1577,25 @@ __global__ __launch_bounds__(GROUP) void cva_split_kernel(const Tail /* first ar
 
 
 // =========================================================================================
-// Pathwise Greeks of the basket call (the reference prices only).  Per path, in the reference's own
-// (unfolded) device formulas dp/MonteCarloKernel.cu:74-101 on the pricing kernels' normals:
+// Greeks of the basket call (the reference prices only).  Per path, in the reference's own (unfolded) device
+// formulas dp/MonteCarloKernel.cu:74-101 on the pricing kernels' normals:
 //     bt_a = sum_{b<=a} L_ab g_b + d_a,   s_a = S_a exp(mu_a + v_a bt_a sqrt T),   B = sum_a w_a s_a,   I = [B > K]
+// PATHWISE (LR = false):
 //     payoff = I (B - K),   d payoff / d S_a = I w_a s_a / S_a,   d payoff / d v_a = I w_a s_a (bt_a sqrt T - v_a T)
-// A secondary kernel: generic in n (normals in the lane's LDS column, constants through scalar loads), and the
-// grid's y index picks the asset whose two derivatives the workgroup accumulates -- the path is re-simulated once per
-// asset, which keeps the per-lane state at three (sum, sum2) pairs whatever n is.  Planes of the pair buffer:
+// LIKELIHOOD RATIO (LR = true): the payoff times the score of the terminal prices' joint lognormal density.  With
+// x = ln S(T) ~ N(m, Sigma), Sigma = T D L L' D, D = diag(v), the whitened vector y = L^-T g (y_a = sum_{b>=a} M_ab g_b,
+// M = L^-T on the host) gives Sigma^-1 (x - m) = D^-1 y / sqrt T and
+//     score_{S_a} = y_a / (S_a v_a sqrt T),
+//     score_{v_a} = (y_a (L g)_a - 1) / v_a + (sqrt T d_a - v_a T) y_a / (v_a sqrt T)
+// (one asset: z / (S sigma sqrt T) and (z^2 - 1) / sigma - z sqrt T, the vanilla kernel's).  No indicator is differentiated;
+// needs a non-singular factor (every L_aa > 0).
+// ONE PASS per BASKET_GREEKS_CHUNK assets: a lane keeps the (sum, sum2) pairs of the price and of the two derivatives of the
+// A = 8 assets of its workgroup's chunk (grid y index) in registers -- 2 + 4 A doubles -- so a basket of n assets is simulated
+// ceil(n / 8) times instead of n times (round 5: one pass per asset; n = 16: profiles/r06_basket_greeks_one_pass.log).  Generic
+// in n (normals in the lane's LDS column, constants through scalar loads).  Planes of the pair buffer:
 // 0 = price (published by y = 0 only), 1 + a = delta_a, 1 + n + a = vega_a.
-// Constant table (Real): L[n*n] row-major | d[n] | mu[n] | v[n] | w[n] | s[n] | inv_s[n] | vt[n] (= v_a T).
+// Constant table (Real): L[n*n] row-major | d[n] | mu[n] | v[n] | w[n] | s[n] | inv_s[n] | vt[n] (= v_a T)
+//                        | LR only: M[n*n] | inv_svt[n] (= 1 / (S_a v_a sqrt T)) | inv_v[n] | mcoef[n] (= (sqrt T d_a - v_a T) / (v_a sqrt T)).
 // =========================================================================================
 template <class Real>
 struct BasketGreeks {
@@ -1593,23 +1603,32 @@ struct BasketGreeks {
     int n;
     Real strike, sqrt_t;
 };
+#ifndef MC_BASKET_GREEKS_CHUNK
+#define MC_BASKET_GREEKS_CHUNK 8   // -DMC_BASKET_GREEKS_CHUNK=1 rebuilds round 5's one pass per asset (the A/B of profiles/r06_basket_greeks_one_pass.log)
+#endif
+constexpr int BASKET_GREEKS_CHUNK = MC_BASKET_GREEKS_CHUNK;
 
 __device__ __forceinline__ float exp_nat(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 __device__ __forceinline__ double exp_nat(double x) { return exp_f64(x); }
 
-template <class Real>
+template <class Real, bool LR>
 __global__ __launch_bounds__(GROUP) void basket_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const BasketGreeks<Real> o, const Work w)
 {
+    constexpr int A = BASKET_GREEKS_CHUNK;
     stage_tables<Real>();
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     Real *g = reinterpret_cast<Real *>(lds_raw) + threadIdx.x;  // this lane's column, stride GROUP
     constexpr int NPB = GenPhilox::npb<Real>();
-    const int n = o.n, nblk = (n + NPB - 1) / NPB, mine = blockIdx.y;
+    const int n = o.n, nblk = (n + NPB - 1) / NPB, chunk = blockIdx.y, a0 = chunk * A;
     GenPhilox gen(w);
     typedef const __attribute__((address_space(4))) Real *cptr;
     const cptr L = (cptr)o.consts, d = L + n * n, mu = d + n, v = mu + n, wt = v + n, s0 = wt + n, inv_s = s0 + n, vt = inv_s + n;
+    const cptr M = vt + n, inv_svt = M + n * n, inv_v = inv_svt + n, mcoef = inv_v + n;   // LR only
     const uint32_t stride = gridDim.x * GROUP;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double acc[2 + 4 * A];
+#pragma unroll
+    for (int q = 0; q < 2 + 4 * A; ++q)
+        acc[q] = 0;
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
         for (int b = 0; b < nblk; ++b) {
             Real z[NPB];
@@ -1618,35 +1637,65 @@ __global__ __launch_bounds__(GROUP) void basket_greeks_kernel(const Tail /* firs
             for (int j = 0; j < NPB; ++j)
                 g[(b * NPB + j) * GROUP] = z[j];
         }
-        Real basket = 0, term_a = 0, bt_a = 0;
-        for (int a = 0; a < n; ++a) {
-            Real bt = 0;
-            for (int b = 0; b <= a; ++b)
-                bt = fma_r(L[a * n + b], g[b * GROUP], bt);
-            bt += d[a];
-            const Real term = s0[a] * exp_nat(fma_r(v[a] * bt, o.sqrt_t, mu[a])) * wt[a];
-            basket += term;
-            if (a == mine) {   // workgroup-uniform
-                term_a = term;
-                bt_a = bt;
+        Real basket = 0, term[A], bts[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k)
+            term[k] = bts[k] = 0;
+        for (int c = 0; c * A < n; ++c) {
+#pragma unroll
+            for (int k = 0; k < A; ++k) {
+                const int a = c * A + k;
+                if (a < n) {   // workgroup-uniform
+                    Real bt = 0;
+                    for (int b = 0; b <= a; ++b)
+                        bt = fma_r(L[a * n + b], g[b * GROUP], bt);
+                    const Real bt0 = bt;   // (L g)_a, before the drift
+                    bt += d[a];
+                    const Real t_a = s0[a] * exp_nat(fma_r(v[a] * bt, o.sqrt_t, mu[a])) * wt[a];
+                    basket += t_a;
+                    if (c == chunk) {   // workgroup-uniform: the assets whose derivatives this workgroup accumulates
+                        term[k] = t_a;
+                        bts[k] = LR ? bt0 : bt;
+                    }
+                }
             }
         }
         const bool itm = basket > o.strike;
-        const double pay = itm ? (double)(basket - o.strike) : 0.0;
-        const double dl = itm ? (double)(term_a * inv_s[mine]) : 0.0;
-        const double vg = itm ? (double)(term_a * (bt_a * o.sqrt_t - vt[mine])) : 0.0;
+        const Real payoff = itm ? basket - o.strike : (Real)0;
+        const double pay = (double)payoff;
         acc[0] += pay, acc[1] = __builtin_fma(pay, pay, acc[1]);
-        acc[2] += dl, acc[3] = __builtin_fma(dl, dl, acc[3]);
-        acc[4] += vg, acc[5] = __builtin_fma(vg, vg, acc[5]);
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            const int a = a0 + k;
+            if (a < n) {   // workgroup-uniform
+                double dl, vg;
+                if constexpr (LR) {
+                    Real y = 0;
+                    for (int b = a; b < n; ++b)
+                        y = fma_r(M[a * n + b], g[b * GROUP], y);
+                    dl = (double)(payoff * (y * inv_svt[a]));
+                    vg = (double)(payoff * fma_r(fma_r(y, bts[k], (Real)-1), inv_v[a], mcoef[a] * y));
+                } else {
+                    dl = itm ? (double)(term[k] * inv_s[a]) : 0.0;
+                    vg = itm ? (double)(term[k] * (bts[k] * o.sqrt_t - vt[a])) : 0.0;
+                }
+                acc[2 + 4 * k] += dl, acc[3 + 4 * k] = __builtin_fma(dl, dl, acc[3 + 4 * k]);
+                acc[4 + 4 * k] += vg, acc[5 + 4 * k] = __builtin_fma(vg, vg, acc[5 + 4 * k]);
+            }
+        }
     }
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
+    for (int q = 0; q < 1 + 2 * A; ++q)
         group_sum2(acc[2 * q], acc[2 * q + 1]);
     const tail_ptr t = late_tail(acc[0]);
-    if (mine == 0)
+    if (chunk == 0)
         publish_pair(t, 0, acc[0], acc[1]);
-    publish_pair(t, 1 + mine, acc[2], acc[3]);
-    publish_pair(t, 1 + n + mine, acc[4], acc[5]);
+#pragma unroll
+    for (int k = 0; k < A; ++k)
+        if (a0 + k < n) {
+            publish_pair(t, 1 + a0 + k, acc[2 + 4 * k], acc[3 + 4 * k]);
+            publish_pair(t, 1 + n + a0 + k, acc[4 + 4 * k], acc[5 + 4 * k]);
+        }
     arrive_and_finish(t);
 }
 
@@ -1685,9 +1734,14 @@ __device__ __forceinline__ void bs_exposure_delta(double ln_spot, double W, cons
     s_phi = A;
 }
 
-template <class Real>
+// LR = true: the likelihood-ratio forms on the same stream.  Only the first transition's density depends on S_0, every
+// transition's on sigma, and the closed-form exposure depends on sigma explicitly (its own vega stays pathwise):
+//     d CVA / d S_0   = E[ CVA_path z_1 ] / (S_0 sigma sqrt(dt))
+//     d CVA / d sigma = E[ LGD sum_j dp_j S_j phi(d1_j) sqrt(tau_j)  +  CVA_path sum_j ((z_j^2 - 1) / sigma - z_j sqrt(dt)) ]
+// (the sums over the dates that draw a normal).  lr_delta = 1 / (S_0 sigma sqrt(dt)), inv_sigma = 1 / sigma.
+template <class Real, bool LR>
 __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real inv_spot,
-                                                           Real sqrt_dt)
+                                                           Real sqrt_dt, Real lr_delta, Real inv_sigma)
 {
     stage_tables<Real>();
     constexpr int NPB = GenPhilox::npb<Real>();
@@ -1698,7 +1752,7 @@ __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first a
     const cptr sqrt_tau = (cptr)o.extra, sig_t = sqrt_tau + n_dates;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t i = blockIdx.x * GROUP + threadIdx.x; i < w.n_units; i += stride) {
-        Real W = 0, cva = 0, delta = 0, vega = 0, z[NPB];
+        Real W = 0, cva = 0, delta = 0, vega = 0, score = 0, z_first = 0, z[NPB];
         for (int j = 0; j < n_dates; ++j) {   // wave-uniform: table rows through scalar loads
             if (j % NPB == 0)
                 gen.normals(w, w.unit_lo + i, (uint32_t)(j / NPB), 3u /*MC_DOMAIN_CVA*/, z);
@@ -1708,6 +1762,10 @@ __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first a
             for (int q = 1; q < NPB; ++q)
                 zz = (j % NPB == q) ? z[q] : zz;
             W += zz;
+            if (LR) {
+                z_first = j == 0 ? zz : z_first;
+                score += fma_r(fma_r(zz, zz, (Real)-1), inv_sigma, -zz * sqrt_dt);
+            }
             const Real ln_spot = fma_r(W, o.bx, st.xk);
             Real ee, sd, sphi;
             if (j < o.n_bs) {
@@ -1720,10 +1778,17 @@ __global__ __launch_bounds__(GROUP) void cva_greeks_kernel(const Tail /* first a
                 sphi = 0;
             }
             cva = fma_r(st.dp, ee, cva);
-            delta = fma_r(st.dp, sd, delta);
-            vega = fma_r(st.dp, fma_r(sphi, sqrt_tau[j], sd * fma_r(W, sqrt_dt, -sig_t[j])), vega);
+            if (LR) {
+                vega = fma_r(st.dp, sphi * sqrt_tau[j], vega);
+            } else {
+                delta = fma_r(st.dp, sd, delta);
+                vega = fma_r(st.dp, fma_r(sphi, sqrt_tau[j], sd * fma_r(W, sqrt_dt, -sig_t[j])), vega);
+            }
         }
-        const double c = (double)(cva * o.lgd), dl = (double)(delta * o.lgd * inv_spot), vg = (double)(vega * o.lgd);
+        const Real cva_path = cva * o.lgd;
+        const double c = (double)cva_path;
+        const double dl = LR ? (double)(cva_path * (z_first * lr_delta)) : (double)(delta * o.lgd * inv_spot);
+        const double vg = LR ? (double)fma_r(cva_path, score, vega * o.lgd) : (double)(vega * o.lgd);
         acc[0] += c, acc[1] = __builtin_fma(c, c, acc[1]);
         acc[2] += dl, acc[3] = __builtin_fma(dl, dl, acc[3]);
         acc[4] += vg, acc[5] = __builtin_fma(vg, vg, acc[5]);

@@ -23,7 +23,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mc_multi.h"
@@ -82,8 +84,14 @@ struct mc_multi {
     double last_reduce_error = 0.0;
     // one launcher thread per device (G > 1; MC_MULTI_THREADS=0 keeps the serial fan-out of rounds 2-3 for A/B)
     std::unique_ptr<mc_host::LaunchCrew> crew;
+    // the job of the call in progress lives HERE, not on run_sharded's stack: a launcher thread that comes back from a launch after
+    // its call has timed out (LaunchCrew::run_all) still reads it
+    alignas(16) unsigned char job_storage[512];
+    const volatile double *slot_storage[MAX_DEVICES + 1] = {};   // (the same goes for the call's pinned-slot addresses)
     std::vector<std::string> worker_error;     // text of a worker's failed launch (mc_last_error is per thread)
     double last_fanout_us = 0.0;               // call entry -> the last device's launch enqueued, of the last call
+    double last_collective_us = -1.0;          // last device triple seen on the host -> all-reduced triple seen, of the last call (-1: not measured)
+    double last_device_us[MAX_DEVICES] = {};   // call entry -> device g's triple seen on the host, of the last call
     double last_seen_us[MAX_DEVICES] = {};     // ... per device: when its launcher thread saw the call (-1: the caller ran it because the
     double last_at_us[MAX_DEVICES] = {};       //     thread was late, -2: because it was parked; serial fan-out: -3), when its launch was enqueued
     long linger_us = 0;                        // resolved configuration, for mc_multi_describe
@@ -108,6 +116,12 @@ extern "C" void mc_multi_destroy(mc_multi *m)
     if (!m)
         return;
     CallerDevice keep;
+    if (m->crew && m->crew->broken()) {
+        // a launcher thread never returned from a launch it had claimed (run_sharded reported MC_ERR_HIP): it may still be inside the
+        // HIP runtime with pointers into this handle -- nothing it could touch is freed; the threads are detached and the handle leaked
+        mc_host::LaunchCrew::retire(m->crew);
+        return;
+    }
     m->crew.reset();   // joins the launcher threads: none of them is inside a launch after this
     for (size_t g = 0; g < m->ctx.size(); ++g) {
         (void)hipSetDevice(m->devices[g]);
@@ -227,6 +241,16 @@ extern "C" mc_context *mc_multi_context(mc_multi *m, int i)
 }
 extern "C" double mc_multi_last_reduce_error(const mc_multi *m) { return m ? m->last_reduce_error : 0.0; }
 extern "C" double mc_multi_last_fanout_us(const mc_multi *m) { return m ? m->last_fanout_us : 0.0; }
+extern "C" double mc_multi_last_collective_us(const mc_multi *m) { return m ? m->last_collective_us : -1.0; }
+extern "C" int mc_multi_last_device_us(const mc_multi *m, int cap, double *delivered_us)
+{
+    if (!m || !delivered_us || cap < 0)
+        return fail(MC_ERR_INVALID, "mc_multi_last_device_us: bad argument");
+    const int G = (int)m->devices.size();
+    for (int g = 0; g < G && g < cap; ++g)
+        delivered_us[g] = m->last_device_us[g];
+    return G;
+}
 extern "C" int mc_multi_last_fanout_trace(const mc_multi *m, int cap, double *seen_us, double *enqueued_us)
 {
     if (!m)
@@ -393,6 +417,9 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     if (!out) return fail(MC_ERR_INVALID, "NULL output pointer");
     if (n == 0) return fail(MC_ERR_INVALID, "n_paths == 0");
     const int G = (int)m->devices.size();
+    if (m->crew && m->crew->broken())
+        return fail(MC_ERR_HIP, "this handle is unusable: a launcher thread never returned from a launch of an earlier call "
+                                "(see that call's error); destroy it -- the device it hung on is probably lost");
     CallerDevice keep;   // declared before InFlight: the drain of a failed call runs first, then the device goes back
     if (m->reduce == MC_REDUCE_RCCL)
         if (int rc = ensure_comms(m)) return rc;
@@ -401,7 +428,9 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     bool direct = !m->timing && !m->readback_copy;
     // per-device scratch of the call on the stack (mc_multi_create admits at most 64 devices): no allocation between the
     // call's entry and the first launch
-    const volatile double *slot[MAX_DEVICES + 1] = {};   // [G] = the all-reduced triple's slot
+    const volatile double **slot = m->slot_storage;   // [G] = the all-reduced triple's slot
+    for (int g = 0; g <= G; ++g)
+        slot[g] = nullptr;
     // device g's part of the call; runs on the calling thread or on launcher thread g.  Returns an MC_* status; the text
     // of a failure goes to `err` (mc_last_error is thread-local: a worker's text would be lost otherwise).
     struct Job {
@@ -409,9 +438,11 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
         uint64_t first, n;
         bool want_direct;
         const volatile double **slot;
-        Launch *launch;
+        Launch launch;            // by value (the lambdas capture the option pointer and the seed by value)
         char armed[MAX_DEVICES];
-    } job{m, first, n, direct, slot, &launch, {}};
+    };
+    static_assert(sizeof(Job) <= sizeof m->job_storage && alignof(Job) <= 16 && std::is_trivially_destructible<Job>::value, "job_storage holds the call's job");
+    Job &job = *new (m->job_storage) Job{m, first, n, direct, slot, launch, {}};
     const auto device_part = [](void *jp, int g) -> int {
         Job &j = *static_cast<Job *>(jp);
         mc_multi *m = j.m;
@@ -431,7 +462,7 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
         if (cnt) {
             if (j.want_direct && mc_context_arm_direct(m->ctx[(size_t)g], &j.slot[g]) == MC_OK)
                 j.armed[(size_t)g] = 1;   // not armed (e.g. MC_FINISH=kernel): the whole call falls back to copies
-            const int rc = (*j.launch)(g, m->ctx[(size_t)g], j.first + lo, cnt, m->d_send[(size_t)g], (void *)m->stream[(size_t)g]);
+            const int rc = j.launch(g, m->ctx[(size_t)g], j.first + lo, cnt, m->d_send[(size_t)g], (void *)m->stream[(size_t)g]);
             if (rc != MC_OK) {
                 if (err) *err = mc_last_error(); else g_multi_error = mc_last_error();
                 return rc;
@@ -447,7 +478,16 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     int rcs[MAX_DEVICES] = {};
     int64_t at_ns[MAX_DEVICES] = {}, seen_ns[MAX_DEVICES] = {};
     if (m->crew) {
-        m->crew->run_all(device_part, &job, rcs, wall0, at_ns, seen_ns);
+        if (m->crew->run_all(device_part, &job, rcs, wall0, at_ns, seen_ns) > 0) {
+            // Bounded wait (mc_multi.h): a launcher thread claimed its device's launch and has not come back.  Nothing can be
+            // drained (the same runtime call would be waited for), the slots on this stack frame must not be written through any
+            // more -- direct delivery of THIS call is abandoned by leaving the device side alone -- and the handle stays broken.
+            fl.touched = 0;
+            for (int g = 0; g < G; ++g)
+                if (rcs[(size_t)g] == mc_host::LaunchCrew::TIMED_OUT)
+                    return fail(MC_ERR_HIP, "device %d: its launcher thread has not returned from the launch it claimed (stuck inside the HIP "
+                                            "runtime); the handle is unusable from now on and leaks on mc_multi_destroy", m->devices[(size_t)g]);
+        }
     } else {
         for (int g = 0; g < G; ++g) {
             rcs[(size_t)g] = device_part(&job, g);
@@ -494,13 +534,22 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
         }
     }
     const volatile double *rslot = slot[(size_t)G];
+    m->last_collective_us = -1.0;
     float kernel_ms = 0;
     double host[3] = {0, 0, 0}, reduced[3] = {0, 0, 0};
     if (direct) {
         // one polling loop over every flag word; after 50 ms (BASELINE's C4 and C5 shards take 1-40 ms) hand the core
         // back and wait in the runtime, which is also the way out if a device faulted and will never write
-        if (!mc_host::poll_slots(slot, G + 1, wall0, std::chrono::milliseconds(50), [&] { fl.settle(); }))
+        int64_t ready_ns[MAX_DEVICES + 1];
+        if (!mc_host::poll_slots(slot, G + 1, wall0, std::chrono::milliseconds(50), [&] { fl.settle(); }, ready_ns))
             return fail(MC_ERR_HIP, "a device never delivered its result");
+        int64_t last_device_ns = -1;
+        for (int g = 0; g < G; ++g) {
+            m->last_device_us[g] = ready_ns[g] < 0 ? -1.0 : ready_ns[g] * 1e-3;
+            last_device_ns = ready_ns[g] > last_device_ns ? ready_ns[g] : last_device_ns;
+        }
+        // the collective as the host sees it: all-reduce + publish kernel, from the last device's own triple to the reduced one
+        m->last_collective_us = (slot[(size_t)G] && ready_ns[G] >= 0 && last_device_ns >= 0) ? (ready_ns[G] - last_device_ns) * 1e-3 : -1.0;
         for (int g = 0; g < G; ++g)
             for (int k = 0; k < 3; ++k)
                 host[k] += slot[g] ? slot[g][k] : 0.0;
@@ -562,7 +611,7 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     {                                                                                                                   \
         if (!o) return fail(MC_ERR_INVALID, "NULL option");                                                             \
         return run_sharded(m, first, n, std::exp(-(double)o->r * (double)o->t), 0.0, out,                               \
-                           [&](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
+                           [=](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
                                return mc_vanilla_launch_##X(c, o, seed, f, cnt, d, st);                                 \
                            });                                                                                          \
     }                                                                                                                   \
@@ -574,7 +623,7 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
         if (m && m->control && mc_basket_control_mean_##X(o, &mean) != MC_OK)                                           \
             return fail(MC_ERR_INVALID, "%s", mc_last_error());                                                         \
         return run_sharded(m, first, n, std::exp(-(double)o->r * (double)o->t), mean, out,                              \
-                           [&](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
+                           [=](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
                                return mc_basket_launch_##X(c, o, seed, f, cnt, d, st);                                  \
                            });                                                                                          \
     }                                                                                                                   \
@@ -583,7 +632,7 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     {                                                                                                                   \
         if (!o) return fail(MC_ERR_INVALID, "NULL cva");                                                                \
         return run_sharded(m, first, n, 1.0, 0.0, out,                                                                  \
-                           [&](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
+                           [=](int, mc_context *c, uint64_t f, uint64_t cnt, double *d, void *st) {                     \
                                return mc_cva_launch_##X(c, o, seed, f, cnt, d, st);                                     \
                            });                                                                                          \
     }

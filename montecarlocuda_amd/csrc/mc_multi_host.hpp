@@ -50,10 +50,37 @@ static inline bool all_ready(const volatile double *const *slots, int n)
 // Polls until every non-NULL slot is ready.  After `spin_for` the core is handed back: settle() -- which waits in the
 // runtime for everything the call enqueued -- runs ONCE, then the slots are checked a last time.
 // Returns true when all slots delivered, false when some never did (the caller reports MC_ERR_HIP).
+// `ready_ns` (optional, n entries): when each slot was first SEEN ready, in ns since t0 (-1: never, or no slot) -- the host's view
+// of when every device delivered and when the all-reduced triple did (run_sharded: mc_multi_last_collective_us).
 template <class Settle>
 static bool poll_slots(const volatile double *const *slots, int n, std::chrono::steady_clock::time_point t0,
-                       std::chrono::nanoseconds spin_for, Settle settle)
+                       std::chrono::nanoseconds spin_for, Settle settle, int64_t *ready_ns = nullptr)
 {
+    if (ready_ns) {
+        int pending = 0;
+        for (int i = 0; i < n; ++i) {
+            ready_ns[i] = -1;
+            pending += slots[i] ? 1 : 0;
+        }
+        const auto stamp = [&] {
+            for (int i = 0; i < n; ++i)
+                if (slots[i] && ready_ns[i] < 0 && slot_ready(slots[i])) {
+                    ready_ns[i] = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                    --pending;
+                }
+        };
+        for (uint32_t spin = 0;; ++spin) {
+            stamp();
+            if (pending == 0)
+                return true;
+            if ((spin & 255u) == 255u && std::chrono::steady_clock::now() - t0 > spin_for) {
+                settle();
+                stamp();
+                return pending == 0;
+            }
+            MC_CPU_RELAX();
+        }
+    }
     for (uint32_t spin = 0;; ++spin) {
         if (all_ready(slots, n))
             return true;
@@ -143,12 +170,15 @@ public:
         uint64_t slow_claimed = 0;     // jobs that took > 1 ms from claim to return on their worker: descheduled INSIDE the job (or a
                                        // runtime call that blocked) -- the one case no take-over can bound
         uint64_t wakeups = 0;          // parked workers woken up after a call because calls had started to come in quick succession
+        uint64_t timed_out = 0;        // jobs whose worker claimed them and had not returned `claimed_deadline` later (the crew is then broken)
     };
+    static constexpr int TIMED_OUT = -9999;   // rc[g] of a job that was claimed by its worker and never came back (run_all)
 
     // `cpus` = CPUs the process can keep busy (cpus_allowed(): affinity mask capped by the cgroup quota); a test passes its own.
     LaunchCrew(int n, std::chrono::nanoseconds linger, void (*thread_init)(void *, int) = nullptr, void *init_ctx = nullptr,
-               std::chrono::nanoseconds steal_after = std::chrono::microseconds(15), int cpus = cpus_allowed())
-        : linger_(linger), steal_after_(steal_after), yield_(cpus < n + 1), workers_((size_t)n)
+               std::chrono::nanoseconds steal_after = std::chrono::microseconds(15), int cpus = cpus_allowed(),
+               std::chrono::nanoseconds claimed_deadline = std::chrono::seconds(20))
+        : linger_(linger), steal_after_(steal_after), claimed_deadline_(claimed_deadline), yield_(cpus < n + 1), workers_((size_t)n)
     {
         last_end_ = last_start_ = std::chrono::steady_clock::now() - std::chrono::hours(1);
         for (int g = 0; g < n; ++g) {
@@ -169,7 +199,29 @@ public:
                 std::lock_guard<std::mutex> lk(w->mu);
                 w->cv.notify_all();
             }
-            w->th.join();
+            w->th.join();   // (a BROKEN crew must not get here: its stuck thread never joins -- retire() below)
+        }
+    }
+    // The end of a crew, broken or not.  A healthy crew is destroyed (its threads joined).  A broken one -- a worker is still
+    // inside a job it claimed -- cannot be joined and must not be freed either: that worker will touch its words, the call
+    // number and the quit flag whenever it comes back.  It is told to quit, its threads are detached and the object is LEAKED
+    // on purpose (a few hundred bytes per worker; the healthy workers leave at once, the stuck one when -- if -- it returns).
+    static void retire(std::unique_ptr<LaunchCrew> &crew)
+    {
+        if (!crew)
+            return;
+        if (!crew->broken()) {
+            crew.reset();
+            return;
+        }
+        LaunchCrew *c = crew.release();
+        c->quit_.store(true, std::memory_order_seq_cst);
+        for (auto &w : c->workers_) {
+            {
+                std::lock_guard<std::mutex> lk(w->mu);
+                w->cv.notify_all();
+            }
+            w->th.detach();
         }
     }
     LaunchCrew(const LaunchCrew &) = delete;
@@ -179,16 +231,28 @@ public:
     bool yields() const { return yield_; }
     uint64_t stolen() const { return stats_.stolen + stats_.served_parked; }   // jobs the calling thread ran itself
     const Stats &stats() const { return stats_; }
+    // true once a job has timed out: a worker is (or was) stuck inside a job it claimed.  The crew accepts no further calls
+    // (run_all returns TIMED_OUT for every job at once); whatever the stuck job's `ctx` points to must outlive it.
+    bool broken() const { return broken_; }
 
     // Runs fn(ctx, g) for every g -- on worker g, or on the calling thread when worker g is parked or late -- and waits for
-    // all of them; rc[g] = fn's return value.
+    // all of them; rc[g] = fn's return value.  The wait is bounded: a job that its worker CLAIMED and that has not returned
+    // `claimed_deadline` (default 20 s; the slowest jobs seen in 2.4 million were 7.7 ms, inside the HIP runtime) after the
+    // hand-off gets rc[g] = TIMED_OUT, the crew is broken() from then on and the number of such jobs is returned (0 = all
+    // came back).  The jobs of the other workers are still waited for (each within the same deadline).
     // enqueued_ns[g] (optional) = steady_clock time at which job g returned, in ns since `t0`.
     // seen_ns[g] (optional) = the time at which worker g SAW the call (hand-off latency apart from the job's own duration);
     //                         -1 = the caller ran it because the worker was late, -2 = because the worker was parked.
-    void run_all(JobFn fn, void *ctx, int *rc, std::chrono::steady_clock::time_point t0 = {}, int64_t *enqueued_ns = nullptr,
-                 int64_t *seen_ns = nullptr)
+    int run_all(JobFn fn, void *ctx, int *rc, std::chrono::steady_clock::time_point t0 = {}, int64_t *enqueued_ns = nullptr,
+                int64_t *seen_ns = nullptr)
     {
         using clock = std::chrono::steady_clock;
+        if (broken_) {   // a worker may still be inside an earlier call's job: fn_ / ctx_ / t0_ are its to read
+            for (size_t g = 0; g < workers_.size(); ++g)
+                rc[g] = TIMED_OUT;
+            return (int)workers_.size();
+        }
+        int timed_out = 0;
         fn_ = fn, ctx_ = ctx, t0_ = t0;
         const uint32_t seq = ++seq_;
         ++stats_.calls;
@@ -223,16 +287,31 @@ public:
         // 2. the spinning ones: wait; one that has not claimed its job `steal_after` after the hand-off lost its core -- take over
         for (size_t g = 0; g < workers_.size(); ++g) {
             Worker &w = *workers_[g];
-            while (w.done.load(std::memory_order_acquire) != seq) {
-                if (w.claim.load(std::memory_order_relaxed) != seq && clock::now() - handed > steal_after_) {
-                    uint32_t expect = seq - 1;
-                    if (w.claim.compare_exchange_strong(expect, seq, std::memory_order_acq_rel)) {
-                        on_caller(w, g, -1);
-                        ++stats_.stolen;
-                        break;
+            bool lost = false;
+            for (uint32_t spin = 0; w.done.load(std::memory_order_acquire) != seq; ++spin) {
+                if (w.claim.load(std::memory_order_relaxed) != seq) {
+                    if (clock::now() - handed > steal_after_) {
+                        uint32_t expect = seq - 1;
+                        if (w.claim.compare_exchange_strong(expect, seq, std::memory_order_acq_rel)) {
+                            on_caller(w, g, -1);
+                            ++stats_.stolen;
+                            break;
+                        }
                     }
+                } else if ((spin & 1023u) == 1023u && clock::now() - handed > claimed_deadline_) {
+                    lost = true;   // claimed by its worker, never returned: nobody can take a claimed job over
+                    break;
                 }
                 relax();
+            }
+            if (lost) {
+                rc[g] = TIMED_OUT;
+                if (enqueued_ns) enqueued_ns[g] = -1;
+                if (seen_ns) seen_ns[g] = -4;
+                broken_ = true;
+                ++timed_out;
+                ++stats_.timed_out;
+                continue;
             }
             rc[g] = w.rc;
             if (enqueued_ns)
@@ -253,6 +332,7 @@ public:
                     w->cv.notify_one();
                     ++stats_.wakeups;
                 }
+        return timed_out;
     }
     // The caller's side of "a call has ended" (run_sharded: the estimate is closed): the next call's distance from here decides
     // whether parked workers are worth waking.
@@ -324,7 +404,8 @@ private:
     // call as early as the first -- with one word per worker the caller's G stores put worker 7 about 1.2 us behind worker 0
     alignas(128) std::atomic<uint32_t> go_{0};
     alignas(128) std::chrono::nanoseconds linger_;
-    std::chrono::nanoseconds steal_after_;
+    std::chrono::nanoseconds steal_after_, claimed_deadline_;
+    bool broken_ = false;
     bool yield_;
     Stats stats_;
     std::chrono::steady_clock::time_point last_end_, last_start_;

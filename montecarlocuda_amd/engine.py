@@ -268,20 +268,21 @@ class Engine:
                                                                        first_path, n_paths, C.byref(g)))
         return _estimate(g.price), _estimate(g.delta), _estimate(g.vega)
 
-    def basket_greeks(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
-        """(price, [delta per asset], [vega per asset]) Estimates (pathwise derivatives)."""
+    def basket_greeks(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64", lr=False):
+        """(price, [delta per asset], [vega per asset]) Estimates: pathwise derivatives, or (lr=True) likelihood-ratio forms."""
         h = _BasketHolder(precision, b)
         price = _lib.Result()
         delta, vega = (_lib.Result * h.n)(), (_lib.Result * h.n)()
-        check(getattr(lib(), f"mc_basket_greeks_run_{precision}")(self._ctx, C.byref(h.struct), seed, first_path, n_paths,
-                                                                   C.byref(price), delta, vega))
+        check(getattr(lib(), f"mc_basket_greeks{'_lr' if lr else ''}_run_{precision}")(self._ctx, C.byref(h.struct), seed, first_path, n_paths,
+                                                                                        C.byref(price), delta, vega))
         return _estimate(price), [_estimate(x) for x in delta], [_estimate(x) for x in vega]
 
-    def cva_greeks(self, c, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64"):
-        """(cva, delta, vega) Estimates: the CVA and its pathwise derivatives with respect to spot and volatility."""
+    def cva_greeks(self, c, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64", lr=False):
+        """(cva, delta, vega) Estimates: the CVA and its derivatives with respect to spot and volatility, pathwise or (lr=True)
+        by the likelihood ratio."""
         g = _lib.CvaGreeks()
-        check(getattr(lib(), f"mc_cva_greeks_run_{precision}")(self._ctx, C.byref(_as_cva(precision, c)), seed, first_path,
-                                                                n_paths, C.byref(g)))
+        check(getattr(lib(), f"mc_cva_greeks{'_lr' if lr else ''}_run_{precision}")(self._ctx, C.byref(_as_cva(precision, c)), seed, first_path,
+                                                                                     n_paths, C.byref(g)))
         return _estimate(g.cva), _estimate(g.delta), _estimate(g.vega)
 
     def basket(self, b, n_paths, seed=MC_DEFAULT_SEED, first_path=0, precision="f64") -> Estimate:

@@ -132,6 +132,13 @@ void orc_closing(double sum, double sum2, long long n, double discount,
     void orc_dev_cva_greeks_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint, REAL lgd,   \
                                 int n_grid, uint64_t seed, uint64_t first_path,                  \
                                 uint64_t n_paths, orc_result *out3);                             \
+    int orc_dev_basket_greeks_lr_##X(int n, const REAL *s, const REAL *v, const REAL *p,         \
+                                     const REAL *d, const REAL *w, REAL k, REAL t, REAL r,       \
+                                     uint64_t seed, uint64_t first_path, uint64_t n_paths,       \
+                                     orc_result *out);                                           \
+    void orc_dev_cva_greeks_lr_##X(REAL s, REAL k, REAL r, REAL v, REAL t, REAL defint,          \
+                                   REAL lgd, int n_grid, uint64_t seed, uint64_t first_path,     \
+                                   uint64_t n_paths, orc_result *out3);                          \
     void orc_dev_basket_##X(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d,   \
                             const REAL *w, REAL k, REAL t, REAL r, uint64_t seed,                \
                             uint64_t first_path, uint64_t n_paths, int mode,                     \

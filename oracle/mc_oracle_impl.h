@@ -547,6 +547,76 @@ void FN(orc_dev_basket_greeks)(int n, const REAL *s, const REAL *v, const REAL *
     free(g), free(term), free(bts), free(acc);
 }
 
+/* Likelihood-ratio Greeks of the basket call: twin of basket_greeks_kernel<Real, true> (csrc/mc_kernels.hpp).  The payoff
+ * times the score of the terminal prices' joint lognormal density; y = L^-T g with M = L^-T formed in fp64 by back-substitution and
+ * rounded once, as the product's host side does (csrc/mc_api.hip: basket_greeks_run):
+ *   delta_a = payoff y_a / (S_a v_a sqrt T),   vega_a = payoff [ (y_a (L g)_a - 1) / v_a + (sqrt T d_a - v_a T) y_a / (v_a sqrt T) ]
+ * out as in orc_dev_basket_greeks.  Returns 0, or -1 when the factor is singular (some p[a][a] <= 0). */
+int FN(orc_dev_basket_greeks_lr)(int n, const REAL *s, const REAL *v, const REAL *p, const REAL *d, const REAL *w, REAL k,
+                                 REAL t, REAL r, uint64_t seed, uint64_t first_path, uint64_t n_paths, orc_result *out)
+{
+    int nblk = (n + ORC_NPB - 1) / ORC_NPB;
+    const double sqrt_td = sqrt((double)t);
+    double *inv = (double *)calloc((size_t)n * (size_t)n, sizeof(double));
+    for (int a = 0; a < n; a++) {
+        double laa = (double)p[a * n + a];
+        if (!(laa > 0)) {
+            free(inv);
+            return -1;
+        }
+        for (int b = 0; b <= a; b++) {
+            double acc = a == b ? 1.0 : 0.0;
+            for (int q = b; q < a; q++)
+                acc -= (double)p[a * n + q] * inv[q * n + b];
+            inv[a * n + b] = acc / laa;
+        }
+    }
+    REAL *M = (REAL *)calloc((size_t)n * (size_t)n, sizeof(REAL));
+    REAL *inv_svt = (REAL *)malloc(sizeof(REAL) * (size_t)n), *inv_v = (REAL *)malloc(sizeof(REAL) * (size_t)n), *mcoef = (REAL *)malloc(sizeof(REAL) * (size_t)n);
+    for (int a = 0; a < n; a++) {
+        for (int b = a; b < n; b++)
+            M[a * n + b] = (REAL)inv[b * n + a];
+        inv_svt[a] = (REAL)(1.0 / ((double)s[a] * (double)v[a] * sqrt_td));
+        inv_v[a] = (REAL)(1.0 / (double)v[a]);
+        mcoef[a] = (REAL)((sqrt_td * (double)d[a] - (double)v[a] * (double)t) / ((double)v[a] * sqrt_td));
+    }
+    REAL *g = (REAL *)malloc(sizeof(REAL) * (size_t)(nblk * ORC_NPB));
+    REAL *bt0 = (REAL *)malloc(sizeof(REAL) * (size_t)n);
+    double *acc = (double *)calloc((size_t)(2 * (1 + 2 * n)), sizeof(double));
+    const REAL sqrt_t = (REAL)sqrt_td;
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t path = first_path + i;
+        for (int b = 0; b < nblk; b++)
+            FN(dev_normals_native)(seed, ORC_DOMAIN_BASKET, path, (uint32_t)b, g + b * ORC_NPB);
+        REAL basket = 0;
+        for (int a = 0; a < n; a++) {
+            REAL bt = 0;
+            for (int b = 0; b <= a; b++)
+                bt += p[a * n + b] * g[b];
+            bt0[a] = bt;
+            bt += d[a];
+            REAL mu = (REAL)(((double)r - 0.5 * (double)v[a] * (double)v[a]) * (double)t);
+            basket += s[a] * EXP_R(mu + v[a] * bt * sqrt_t) * w[a];
+        }
+        REAL payoff = basket > k ? basket - k : 0;
+        double pay = (double)payoff;
+        acc[0] += pay, acc[1] += pay * pay;
+        for (int a = 0; a < n; a++) {
+            REAL y = 0;
+            for (int b = a; b < n; b++)
+                y += M[a * n + b] * g[b];
+            double dl = (double)(payoff * (y * inv_svt[a]));
+            double vg = (double)(payoff * ((y * bt0[a] - 1) * inv_v[a] + mcoef[a] * y));
+            acc[2 * (1 + a)] += dl, acc[2 * (1 + a) + 1] += dl * dl;
+            acc[2 * (1 + n + a)] += vg, acc[2 * (1 + n + a) + 1] += vg * vg;
+        }
+    }
+    for (int q = 0; q < 1 + 2 * n; q++)
+        FN(dev_finish)(acc[2 * q], acc[2 * q + 1], n_paths, exp(-(double)r * (double)t), out + q);
+    free(inv), free(M), free(inv_svt), free(inv_v), free(mcoef), free(g), free(bt0), free(acc);
+    return 0;
+}
+
 /* Closed-form mean of the geometric-basket control (not in the reference):
  *   G = W prod_a S_a(T)^(w_a / W),  W = sum_a w_a > 0,  is lognormal: ln G ~ N(m, sd^2) with
  *   m = ln W + sum_a wh_a (ln S_a + (r - v_a^2/2) T + v_a sqrt(T) d_a),  wh = w / W,
@@ -782,6 +852,59 @@ void FN(orc_dev_cva_greeks)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defin
             vega += dpd * (sphi * SQRT_R(ttm) + sd * (wsum * sqrt_dt - (REAL)((double)v * t_now)));
         }
         double c = (double)(cva * lgd), dl = (double)(delta * lgd * (REAL)(1.0 / (double)s0)), vg = (double)(vega * lgd);
+        acc[0] += c, acc[1] += c * c, acc[2] += dl, acc[3] += dl * dl, acc[4] += vg, acc[5] += vg * vg;
+    }
+    FN(dev_finish)(acc[0], acc[1], n_paths, 1.0, out);
+    FN(dev_finish)(acc[2], acc[3], n_paths, 1.0, out + 1);
+    FN(dev_finish)(acc[4], acc[5], n_paths, 1.0, out + 2);
+}
+
+/* Likelihood-ratio Greeks of the CVA: twin of cva_greeks_kernel<Real, true>.  Only the first transition's density depends on S_0,
+ * every transition's on sigma; the closed-form exposure's own dependence on sigma stays pathwise (S_j phi(d1_j) sqrt(tau_j)):
+ *   delta = CVA_path z_1 / (S_0 sigma sqrt dt),   vega = LGD sum_j dp_j S_j phi(d1_j) sqrt(tau_j) + CVA_path sum_j ((z_j^2 - 1) / sigma - z_j sqrt dt)
+ * over the dates that draw a normal.  out[0] = CVA, out[1] = delta, out[2] = vega. */
+void FN(orc_dev_cva_greeks_lr)(REAL s0, REAL k, REAL r, REAL v, REAL t0, REAL defint, REAL lgd, int n_grid, uint64_t seed,
+                               uint64_t first_path, uint64_t n_paths, orc_result *out)
+{
+    const REAL dt = t0 / n_grid;
+    const REAL step_drift = (REAL)(((double)r - 0.5 * (double)v * (double)v) * (double)dt);
+    const REAL step_vol = (REAL)((double)v * sqrt((double)dt));
+    const REAL sqrt_dt = (REAL)sqrt((double)dt);
+    const REAL lr_delta = (REAL)(1.0 / ((double)s0 * (double)v * sqrt((double)dt))), inv_sigma = (REAL)(1.0 / (double)v);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    REAL z[ORC_NPB];
+    for (uint64_t i = 0; i < n_paths; i++) {
+        uint64_t path = first_path + i;
+        REAL spot = s0, ttm = t0, cva = 0, vega = 0, score = 0, z_first = 0;
+        for (int j = 1; j <= n_grid; j++) {
+            double t_prev = (double)dt * (double)(j - 1), t_now = (double)dt * (double)j;
+            REAL dpd = (REAL)(-exp(-(double)defint * t_prev) * expm1(-(double)defint * (t_now - t_prev)));
+            ttm -= dt;
+            if (!(ttm >= 0))
+                continue;
+            int idx = j - 1;
+            if (idx % ORC_NPB == 0)
+                FN(dev_normals_native)(seed, ORC_DOMAIN_CVA, path, (uint32_t)(idx / ORC_NPB), z);
+            REAL zz = z[idx % ORC_NPB];
+            spot = spot * EXP_R(step_drift + step_vol * zz);
+            if (idx == 0)
+                z_first = zz;
+            score += (zz * zz - 1) * inv_sigma - zz * sqrt_dt;
+            REAL ee, sphi = 0;
+            if (ttm == 0) {
+                ee = spot > k ? spot - k : 0;
+            } else {
+                REAL sqrt_t = SQRT_R(ttm);
+                double num = (double)LOG_R(spot / k) + ((double)r + 0.5 * (double)v * (double)v) * (double)ttm;
+                REAL d1 = (REAL)(num / (double)(v * sqrt_t));
+                ee = FN(orc_bs_call)(spot, k, r, v, ttm);
+                sphi = spot * (REAL)0.39894228040143267793994605993438 * EXP_R((REAL)(-0.5 * (double)d1 * (double)d1));
+            }
+            cva += dpd * ee;
+            vega += dpd * (sphi * SQRT_R(ttm));
+        }
+        REAL cva_path = cva * lgd;
+        double c = (double)cva_path, dl = (double)(cva_path * (z_first * lr_delta)), vg = (double)(cva_path * score + vega * lgd);
         acc[0] += c, acc[1] += c * c, acc[2] += dl, acc[3] += dl * dl, acc[4] += vg, acc[5] += vg * vg;
     }
     FN(dev_finish)(acc[0], acc[1], n_paths, 1.0, out);

@@ -409,24 +409,26 @@ def dev_vanilla_greeks_lr(X, opt, seed, first, n):
     return [x.as_dict() for x in r]
 
 
-def dev_basket_greeks(X, b, seed, first, n):
-    """(price, [delta_a], [vega_a]) result dicts of the pathwise basket-Greeks twin."""
+def dev_basket_greeks(X, b, seed, first, n, lr=False):
+    """(price, [delta_a], [vega_a]) result dicts of the basket-Greeks twin: pathwise, or (lr=True) likelihood ratio."""
     nn = len(b["s"])
     keep = [_arr(b[k], X) for k in ("s", "v", "p", "d", "w")]
     r = (OrcResult * (1 + 2 * nn))()
-    f = getattr(lib(), f"orc_dev_basket_greeks_{X}")
+    f = getattr(lib(), f"orc_dev_basket_greeks{'_lr' if lr else ''}_{X}")
     RP = C.POINTER(CT[X])
     f.argtypes = [C.c_int, RP, RP, RP, RP, RP, CT[X], CT[X], CT[X], C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p]
-    f.restype = None
-    f(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], seed, first, n, C.cast(r, C.c_void_p))
+    f.restype = C.c_int if lr else None
+    rc = f(nn, *[p for _, p in keep], b["k"], b["t"], b["r"], seed, first, n, C.cast(r, C.c_void_p))
+    if lr and rc != 0:
+        raise ValueError("singular factor")
     out = [x.as_dict() for x in r]
     return out[0], out[1:1 + nn], out[1 + nn:]
 
 
-def dev_cva_greeks(X, c, seed, first, n):
-    """(cva, delta, vega) result dicts of the CVA-Greeks twin."""
+def dev_cva_greeks(X, c, seed, first, n, lr=False):
+    """(cva, delta, vega) result dicts of the CVA-Greeks twin: pathwise, or (lr=True) likelihood ratio."""
     r = (OrcResult * 3)()
-    f = getattr(lib(), f"orc_dev_cva_greeks_{X}")
+    f = getattr(lib(), f"orc_dev_cva_greeks{'_lr' if lr else ''}_{X}")
     f.argtypes = [CT[X]] * 7 + [C.c_int, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(OrcResult * 3)]
     f.restype = None
     f(c["s"], c["k"], c["r"], c["v"], c["t"], c["defint"], c["lgd"], c["n_grid"], seed, first, n, C.byref(r))

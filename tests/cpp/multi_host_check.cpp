@@ -255,6 +255,51 @@ int main()
             printf("   %d of 80000 jobs ran on the caller\n", ctx.on_caller.load());
         }
     }
+    // ---- the bounded wait for a CLAIMED job (ADVICE r04 / VERDICT r05 #5) --------------------------------------------------
+    {
+        // worker 2 claims its job and blocks inside it (a launch call stuck in the runtime): run_all gives up on THAT device after
+        // the deadline, still collects the others, and the crew is broken from then on; retiring it frees nothing the stuck thread
+        // can touch, so the job may finish whenever it likes
+        struct Ctx {
+            std::atomic<int> gate{0}, ran{0};
+        } ctx;
+        const auto job = [](void *c, int g) -> int {
+            Ctx &x = *static_cast<Ctx *>(c);
+            if (g == 2)
+                while (!x.gate.load(std::memory_order_acquire))
+                    std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            x.ran.fetch_add(1);
+            return 10 + g;
+        };
+        std::unique_ptr<LaunchCrew> crew(new LaunchCrew(4, std::chrono::milliseconds(100), nullptr, nullptr, std::chrono::seconds(10), 64,
+                                                        std::chrono::milliseconds(150)));
+        int rc[4] = {0, 0, 0, 0};
+        int64_t at[4], seen[4];
+        const auto t0 = clk::now();
+        const int lost = crew->run_all(job, &ctx, rc, t0, at, seen);
+        const auto took = clk::now() - t0;
+        EXPECT(lost == 1 && rc[2] == LaunchCrew::TIMED_OUT && rc[0] == 10 && rc[1] == 11 && rc[3] == 13,
+               "a job blocked inside its worker: run_all returns 1, TIMED_OUT in that slot, the other statuses in theirs");
+        EXPECT(took >= std::chrono::milliseconds(150) && took < std::chrono::seconds(5), "... after the deadline, not for ever");
+        EXPECT(seen[2] == -4 && at[2] == -1, "... and the trace marks the device (seen = -4)");
+        EXPECT(crew->broken() && crew->stats().timed_out == 1, "the crew is broken and counts the job");
+        int rc2[4] = {0, 0, 0, 0};
+        const auto t1 = clk::now();
+        const int refused = crew->run_all(job, &ctx, rc2);
+        EXPECT(refused == 4 && rc2[0] == LaunchCrew::TIMED_OUT && rc2[3] == LaunchCrew::TIMED_OUT && clk::now() - t1 < std::chrono::milliseconds(100) &&
+                   ctx.ran.load() == 3,
+               "a broken crew refuses the next call at once and runs nothing");
+        LaunchCrew::retire(crew);
+        EXPECT(!crew, "retire() takes the broken crew away without joining (it is leaked on purpose)");
+        ctx.gate.store(1, std::memory_order_release);
+        for (int i = 0; i < 2000 && ctx.ran.load() != 4; ++i)
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        EXPECT(ctx.ran.load() == 4, "the stuck job finishes on its own thread afterwards: nothing it touches was freed");
+        std::this_thread::sleep_for(std::chrono::milliseconds(20));   // let that thread see the quit flag and leave before ctx goes
+        std::unique_ptr<LaunchCrew> healthy(new LaunchCrew(2, std::chrono::milliseconds(1)));
+        LaunchCrew::retire(healthy);
+        EXPECT(!healthy, "retire() of a healthy crew is its destructor (threads joined)");
+    }
     if (failures) {
         printf("%d check(s) FAILED\n", failures);
         return 1;

@@ -137,7 +137,7 @@ def test_multi_library_exports_every_declared_symbol(mc):
     L = C.CDLL(MULTI_LIB)
     header = open(os.path.join(INC, "mc_multi.h")).read()
     declared = set(re.findall(r"\b(mc_multi_[a-z0-9_]+)\s*\(", header))
-    assert len(declared) == 23, sorted(declared)      # round 5: + mc_multi_last_fanout_trace, mc_multi_fanout_stats, mc_multi_describe
+    assert len(declared) == 25, sorted(declared)      # round 6: + mc_multi_last_collective_us, mc_multi_last_device_us
     for name in sorted(declared):
         assert hasattr(L, name), name
     needed = subprocess.check_output(["readelf", "-d", MULTI_LIB], text=True)

@@ -44,7 +44,7 @@ def test_bench_contract_single_gpu(tmp_path):
     assert len(out.stderr) < 2000 and "{" not in out.stderr, out.stderr[-2000:]     # no record on stderr either
     line = _json_line(out.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "fp64", "region_ms_per_step", "strong_summary", "detail"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "fp64", "configs", "strong_summary", "detail"):
         assert k in line, k
     assert "dropped_for_size" not in line
     assert line["n_gpus"] == 1 and line["steps"] == 40 and line["warmup"] == 4 and line["unit"] == "paths/s" and line["dtype"] == "f32"
@@ -55,12 +55,22 @@ def test_bench_contract_single_gpu(tmp_path):
     assert lr["bound"] == "valu" and lr["unit"] == "TFLOP/s" and lr["peak"] == 157.3 and 0 < lr["frac"] < 1 and "traffic" in lr
     assert lc["cores"] == 1 and lc["kind"] in ("reference", "port") and lc["value"] > 1e6 and lc["sample"]
     ss = line["strong_summary"]
-    assert set(ss) == {"C4", "C4x10", "C5", "C5x10", "C4_n32", "C5_n32"}
-    for c in ("C4", "C5", "C4_n32", "C5_n32"):       # [bench.py's torch path, the C library]
-        assert len(ss[c]["t1_ms"]) == 2 and all(v and v > 0 for v in ss[c]["t1_ms"] + ss[c]["t8_ms"]), ss[c]
-        assert all(0.5 < v < 1.1 for v in ss[c]["eff8"] + ss[c]["eff8_cold"]), ss[c]
-    assert ss["C5"]["eff8"][0] > 0.9 and ss["C4"]["eff8"][1] > 0.9          # hot / hot: 0.96-1.00 measured
-    assert ss["C4"]["t1_ms"][1] == pytest.approx(ss["C4"]["t1_ms"][0], rel=0.05)      # the two harnesses agree
+    assert set(ss) == {"cols", "src", "C4", "C4x10", "C5", "C5x10", "C4_n32", "C5_n32"}
+    assert ss["cols"] == ["t1_ms", "t_shard8_ms", "shard8_device_side_eff_1gpu", "shard8_device_side_eff_1gpu_cold"]
+    for c in ("C4", "C5", "C4_n32", "C5_n32"):       # per column [bench.py's torch path, the C library]
+        t1, t8, eff, cold = ss[c]
+        assert len(t1) == 2 and all(v and v > 0 for v in t1 + t8), ss[c]
+        assert all(0.5 < v < 1.1 for v in eff + cold), ss[c]
+    assert ss["C5"][2][0] > 0.9 and ss["C4"][2][1] > 0.9          # hot / hot: 0.96-1.02 measured
+    assert ss["C4"][0][1] == pytest.approx(ss["C4"][0][0], rel=0.05)      # the two harnesses agree
+    # BASELINE configs[1..4], each with its fractions, price error and the reference's CPU path (0.5 s samples here)
+    cf = line["configs"]
+    assert list(cf) == ["C2", "C3", "C4", "C5"]
+    for name, e in cf.items():
+        assert e["paths_per_s"] > 1e8 and e["kernel_us"] > 0 and 0.05 < e["frac"] < 0.6 and e["cpu_baseline"]["cores"] == 1, (name, e)
+        assert e["paths_per_s"] > 1e3 * e["cpu_baseline"]["value"] and 1000 < e["sclk_mhz"] <= 2450
+    assert cf["C2"]["err"] < 2e-3 and cf["C3"]["err"] < 5e-3 and cf["C4"]["err"] < 5e-3 and cf["C5"]["err"] < 5e-4
+    assert 40 < cf["C2"]["single_call"][0] < 200
 
     # ---- the full record ---------------------------------------------------------------------------------
     d = _detail(line, tmp)
@@ -88,6 +98,10 @@ def test_bench_contract_single_gpu(tmp_path):
     else:
         assert "issue_model_withheld" in r
     assert r["grid_workgroups"] == 2048 and len(r["launch_stamp"]) == 16
+    # the clock the card held while the headline kernel ran back to back (amdgpu hwmon), and the ceiling priced at it
+    assert 1500 < r["sclk_mhz"] <= 2450 and lr["sclk_mhz"] == pytest.approx(r["sclk_mhz"], rel=1e-4)
+    if "issue_frac" in r:
+        assert r["issue_frac_at_measured_clock"] == pytest.approx(r["issue_frac"] * 2400.0 / r["sclk_mhz"], rel=1e-6) and r["issue_frac_at_measured_clock"] < 1.0
     # counters collected from THIS build at THIS grid must not be called stale (round 4: the grid used to be read after the
     # fp64 side run and the strong rows, i.e. from another kernel's launch, and fresh counters were flagged)
     sys.path.insert(0, ROOT)
@@ -101,7 +115,7 @@ def test_bench_contract_single_gpu(tmp_path):
     assert abs(d["fp64"]["price"] - BS) < 0.05
     # strong-scaling rows and the C library's own multi-GPU path are in the full record (brief: no 10x sizes on fp32 normals)
     rows = {x["config"]: x for x in d["strong"]["rows"]}
-    assert set(rows) == set(ss) and rows["C4"]["paths_priced"] == 10 ** 9 and rows["C5x10"]["paths_priced"] == 10 ** 8
+    assert set(rows) == set(ss) - {"cols", "src"} and rows["C4"]["paths_priced"] == 10 ** 9 and rows["C5x10"]["paths_priced"] == 10 ** 8
     assert 9.70 < rows["C4"]["value"] < 9.74 and 0.1895 < rows["C5"]["value"] < 0.1905
     assert 9.70 < rows["C4_n32"]["value"] < 9.74 and 0.1895 < rows["C5_n32"]["value"] < 0.1905      # the reference's dp arithmetic: same prices
     assert rows["C4_n32"]["wall_ms_median"] < 0.8 * rows["C4"]["wall_ms_median"] and rows["C4_n32"]["normals"] == "f32"
@@ -115,7 +129,12 @@ def test_bench_contract_single_gpu(tmp_path):
     assert set(sh) == {(c, 8) for c in rows} and sh[("C4", 8)]["paths"] == 125000000
     assert all(0.5 < x["device_side_efficiency"] < 1.1 for x in sh.values()) and sh[("C4x10", 8)]["device_side_efficiency"] > 0.9
     assert sh[("C5", 8)]["device_side_efficiency"] > 0.9 and "cold" in sh[("C5", 8)]      # hot / hot: 0.96-0.99 measured
-    assert ss["C5"]["t8_ms"][0] == pytest.approx(sh[("C5", 8)]["wall_ms_median"], rel=1e-5)
+    assert ss["C5"][1][0] == pytest.approx(sh[("C5", 8)]["wall_ms_median"], rel=1e-4)
+    # the configs block of the full record: where every number of the line's `configs` comes from
+    dc = d["configs"]
+    assert dc["C4"]["paths_per_s"] == pytest.approx(10 ** 9 / (rows["C4"]["wall_ms_median"] * 1e-3), rel=1e-9) and dc["C4"]["price"] == rows["C4"]["value"]
+    assert dc["C5"]["vs"].startswith("closed form") and dc["C3"]["steps"] == [40, 3] and dc["C3"]["vs_confidence_95"] < 2e-3
+    assert dc["C3"]["cpu"]["object"].endswith("libref_f32_n4.so") and dc["C4"]["cpu"]["object"].endswith("libref_f32_n16.so") and dc["C4"]["cpu"]["cpu_dp"] > 1e5
     cm = d["c_multi"]
     assert cm["rc"] == 0 and "--brief" in cm["command"]
     crows = [x for x in cm["rows"] if "config" in x]
@@ -141,7 +160,7 @@ def test_bench_detail_full_adds_the_rows_brief_leaves_out(tmp_path):
     d = _detail(line, tmp)
     assert line["config"]["detail"] == "full" and "fp64" not in line
     base = {"C4", "C4x10", "C5", "C5x10"}
-    assert {x["config"] for x in d["strong"]["rows"]} == base | {c + "_n32" for c in base} == set(line["strong_summary"])
+    assert {x["config"] for x in d["strong"]["rows"]} == base | {c + "_n32" for c in base} == set(line["strong_summary"]) - {"cols", "src"}
     assert {(x["shard_of"]) for x in d["strong"]["shard_rows"]} == {2, 4, 8}
     assert "value_at_O0" in d["cpu_baseline"] and line["cpu_baseline"]["value_at_O0"] > 1e6
 
@@ -169,6 +188,18 @@ def test_bench_two_ranks_share_the_gpu(scaling, tmp_path):
     rows = {x["config"]: x for x in d["strong"]["rows"]}               # one call sharded over the two ranks
     assert d["strong"]["n_gpus"] == 2 and rows["C4"]["paths_per_gpu"] == 5 * 10 ** 8 and rows["C4"]["paths_priced"] == 10 ** 9
     assert 9.70 < rows["C4"]["value"] < 9.74 and 0.1895 < rows["C5"]["value"] < 0.1905
+    # the N > 1 line explains itself: every rank's own shard time, what the collective adds, T(1) on rank 0,
+    # the efficiency split, and the 24-byte all-reduce alone -- here two gloo ranks sharing one GPU, so only the plumbing counts
+    ssn = line["strong_summary"]
+    assert ssn["allreduce_us"]["calls"] == 200 and ssn["allreduce_us"]["median"] > 0
+    for c in ("C4", "C5", "C4_n32", "C5_n32"):
+        e, full = ssn[c], rows[c]
+        assert len(full["t_shard_ms_by_rank"]) == 2 and e["t_shard_ms"] == [pytest.approx(min(full["t_shard_ms_by_rank"]), rel=1e-4),
+                                                                              pytest.approx(max(full["t_shard_ms_by_rank"]), rel=1e-4)]
+        assert e["collective_ms"] == pytest.approx(e["wall_ms_median"] - e["t_shard_ms"][1], rel=1e-2, abs=1e-3)
+        assert e["t1_ms_rank0"] > 0 and e["eff"] == pytest.approx(e["t1_ms_rank0"] / (2 * e["wall_ms_median"]), rel=1e-3)
+        assert e["eff_device_side"] == pytest.approx(e["t1_ms_rank0"] / (2 * e["t_shard_ms"][1]), rel=1e-3)
+    assert "t_shard_ms" not in ssn["C4x10"]            # base sizes only
 
 
 def test_bench_rccl_plumbing_world_of_one(tmp_path):

@@ -1,5 +1,5 @@
 """Greeks beyond the vanilla pathwise ones (the reference prices only): likelihood-ratio delta / vega of
-the vanilla call, pathwise delta and vega per asset of the basket call, pathwise delta of the CVA.  Each estimator has
+the vanilla call, pathwise AND likelihood-ratio delta and vega per asset of the basket call and of the CVA.  Each estimator has
 an oracle twin on the same Philox counters (sums compared at the stated tolerances), a closed-form or
 finite-difference target (common random numbers), and runs through both forms of the final reduction."""
 import math
@@ -161,3 +161,84 @@ def test_greeks_run_the_same_through_both_finish_forms(mc):
         with pytest.raises(mc.McError, match="plain estimator"):
             fused.set_antithetic(True)
             fused.basket_greeks(b, 1000, SEED, 0, "f64")
+
+
+# ---- likelihood-ratio Greeks of the basket and of the CVA (DESIGN claimed them for all three products) ----
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("n_assets", [1, 3, 4, 9, 16, 20])
+def test_basket_likelihood_ratio_greeks_match_oracle(mc, eng, po, X, n_assets):
+    """The payoff times the score of the joint lognormal density, y = L^-T g formed from the host-inverted factor: against the
+    oracle twin on the same normals.  9 and 20 assets: a last chunk of one and of four assets (8 per pass)."""
+    b = basket_inputs(mc, n_assets, X, rho=0.4)
+    b["d"] = [0.01 * ((i % 3) - 1) for i in range(n_assets)]
+    b["w"] = [(1.0 + 0.25 * (i % 2)) / n_assets for i in range(n_assets)]
+    n, first = 20001, ((1 << 32) - 7000 if n_assets == 4 else 5)
+    price, delta, vega = eng.basket_greeks(b, n, SEED, first, X, lr=True)
+    op, od, ov = po.dev_basket_greeks(X, b, SEED, first, n, lr=True)
+    rel = 8 * TOL[X]["rel"]
+    same(price, op, rel)
+    pw = eng.basket_greeks(b, n, SEED, first, X)
+    assert (price.sum, price.sum2) == (pw[0].sum, pw[0].sum2)          # the same payoffs, bit for bit, as the pathwise kernel's
+    for g, o in zip(delta, od):
+        # score terms change sign from path to path; y is a sum of up to n products with entries of L^-T (|M| up to ~3)
+        assert g.n == o["n"] and g.sum == pytest.approx(o["sum"], rel=40 * rel, abs=n * 20 * TOL[X]["pay"])
+        assert g.sum2 == pytest.approx(o["sum2"], rel=40 * rel)
+    for g, o in zip(vega, ov):
+        assert g.sum == pytest.approx(o["sum"], rel=40 * rel, abs=n * 4000 * TOL[X]["pay"]) and g.sum2 == pytest.approx(o["sum2"], rel=40 * rel)
+
+
+def test_basket_likelihood_ratio_greeks_agree_with_pathwise_and_closed_form(mc, eng):
+    one = dict(s=[100.0], v=[0.2], p=[[1.0]], d=[0.0], w=[1.0], k=100.0, t=1.0, r=0.048790)
+    n = 4 * 10 ** 7
+    price, delta, vega = eng.basket_greeks(one, n, SEED, 0, "f64", lr=True)
+    van = eng.vanilla_greeks_lr(VAN, n, SEED, 0, "f64")
+    want_d, want_v = bs_greeks(VAN)
+    assert abs(price.expected - BS_EXACT) < 3.5 / 1.96 * price.confidence
+    assert abs(delta[0].expected - want_d) < 3.5 / 1.96 * delta[0].confidence
+    assert abs(vega[0].expected - want_v) < 3.5 / 1.96 * vega[0].confidence
+    assert delta[0].confidence == pytest.approx(van[1].confidence, rel=0.02) and vega[0].confidence == pytest.approx(van[2].confidence, rel=0.02)
+    # four and sixteen correlated assets: both estimators are unbiased for the same derivative
+    for n_assets, paths in ((4, 2 * 10 ** 7), (16, 4 * 10 ** 6)):
+        b = basket_inputs(mc, n_assets, "f64", rho=0.4)
+        b["d"] = [0.02 * ((i % 3) - 1) for i in range(n_assets)]
+        _, dl, vl = eng.basket_greeks(b, paths, SEED, 0, "f64", lr=True)
+        _, dp, vp = eng.basket_greeks(b, paths, SEED, 0, "f64")
+        for a in range(n_assets):
+            assert abs(dl[a].expected - dp[a].expected) < 4 / 1.96 * math.hypot(dl[a].confidence, dp[a].confidence), (n_assets, a)
+            assert abs(vl[a].expected - vp[a].expected) < 4 / 1.96 * math.hypot(vl[a].confidence, vp[a].confidence), (n_assets, a)
+            assert dl[a].confidence > dp[a].confidence        # the known price of the likelihood ratio on a smooth payoff
+    with pytest.raises(mc.McError, match="non-singular"):     # the reference driver's own 3 x 3 correlation: L[2][2] = 0 (SURVEY 2.3 #10)
+        L, bad = mc.chol(np.full((3, 3), -0.5) + 1.5 * np.eye(3), "f64")
+        eng.basket_greeks(dict(s=[100.0] * 3, v=[0.3, 0.2, 0.3], p=L.tolist(), d=[0.0] * 3, w=[1 / 3] * 3, k=100.0, t=1.0, r=0.05), 1000, SEED, 0,
+                          "f64", lr=True)
+
+
+@pytest.mark.parametrize("X", ["f32", "f64"])
+@pytest.mark.parametrize("n_grid", [1, 25, 64, 250, 256])
+def test_cva_likelihood_ratio_greeks_match_oracle(mc, eng, po, X, n_grid):
+    c = dict(CVA0, n_grid=n_grid)
+    n = 5001
+    cva, delta, vega = eng.cva_greeks(c, n, SEED, 11, X, lr=True)
+    oc, od, ov = po.dev_cva_greeks(X, c, SEED, 11, n, lr=True)
+    rel = 4 * TOL[X]["rel"]
+    same(cva, oc, rel)
+    pw = eng.cva_greeks(c, n, SEED, 11, X)
+    assert (cva.sum, cva.sum2) == (pw[0].sum, pw[0].sum2)                      # the same CVA plane as the pathwise kernel
+    # the scores change sign from path to path and grow with the number of dates: sums of comparable magnitudes cancel
+    assert delta.sum == pytest.approx(od["sum"], rel=40 * rel, abs=n * 20 * TOL[X]["cva"]) and delta.sum2 == pytest.approx(od["sum2"], rel=40 * rel)
+    assert vega.sum == pytest.approx(ov["sum"], rel=40 * rel, abs=n * 400 * TOL[X]["cva"]) and vega.sum2 == pytest.approx(ov["sum2"], rel=40 * rel)
+
+
+def test_cva_likelihood_ratio_greeks_vs_analytic(mc, eng):
+    c = dict(CVA0, n_grid=16)
+    n = 2 * 10 ** 7
+    cva, delta, vega = eng.cva_greeks(c, n, SEED, 0, "f64", lr=True)
+    dt = c["t"] / c["n_grid"]
+    weight = sum((math.exp(-c["defint"] * dt * (j - 1)) - math.exp(-c["defint"] * dt * j)) * math.exp(c["r"] * dt * j)
+                 for j in range(1, c["n_grid"] + 1))
+    want_d, want_v = (c["lgd"] * g * weight for g in bs_greeks(c))
+    assert abs(cva.expected - cva_analytic(c)) < 3.5 / 1.96 * cva.confidence + 2e-6
+    assert abs(delta.expected - want_d) < 3.5 / 1.96 * delta.confidence, (delta.expected, want_d)
+    assert abs(vega.expected - want_v) < 3.5 / 1.96 * vega.confidence, (vega.expected, want_v)
+    pw = eng.cva_greeks(c, n, SEED, 0, "f64")
+    assert delta.confidence > 3 * pw[1].confidence and vega.confidence > 3 * pw[2].confidence     # what the scores cost
