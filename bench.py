@@ -233,15 +233,23 @@ class SclkSampler:
             self.mhz = v[len(v) // 2] if v else None
 
 
-def sustained_clock(torch, engines, streams, launch, pci, ms=150.0):
-    """Shader clock while `launch(i, engine, stream)` runs back to back on the given context/stream pairs for `ms` milliseconds."""
-    with SclkSampler(pci) as sm:
-        t0, i = time.perf_counter(), 0
-        while (time.perf_counter() - t0) * 1e3 < ms:
+def sustained_clock(torch, engines, streams, launch, pci, ms=150.0, preheat_ms=300.0):
+    """Shader clock while `launch(i, engine, stream)` runs back to back on the given context/stream pairs: `preheat_ms` of it
+    unsampled first (the hwmon figure is a moving average: read straight after a change of load it still shows the previous
+    state -- 2017 MHz for a kernel that holds 2393), then `ms` milliseconds sampled."""
+    i = 0
+
+    def burn(for_ms):
+        nonlocal i
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < for_ms:
             for _ in range(16):
                 launch(i, engines[i % len(engines)], streams[i % len(streams)])
                 i += 1
             torch.cuda.synchronize()
+    burn(preheat_ms)
+    with SclkSampler(pci) as sm:
+        burn(ms)
     return sm.mhz
 
 

@@ -13,7 +13,7 @@ mkdir -p "$OUT"
 PATHS_ARG=""
 run() { # name, counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --workload "$W" $PATHS_ARG --steps 20 --warmup 2 --regions 1 --cpu-seconds 0 --profile-every 0 --preheat-ms 0 --strong-reps 0 --c-multi-seconds 0 --fp64-steps 0 --exclusive-launches 0 > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
+  rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py --workload "$W" $PATHS_ARG --steps 20 --warmup 2 --regions 1 --cpu-seconds 0 --profile-every 0 --preheat-ms 0 --strong-reps 0 --c-multi-seconds 0 --fp64-steps 0 --exclusive-launches 0 --configs 0 > "$OUT/$name.log" 2>&1 || { echo "pass $name failed"; tail -5 "$OUT/$name.log"; return 1; }
   echo "pass $name ok"
 }
 run fetch FETCH_SIZE &&
