@@ -1683,11 +1683,11 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
     // generators, one segment each (the external array is indexed from the call's first path), and a table small enough not
     // to cost the one-lane-per-path workgroups their residency (24 KB: 4 workgroups per CU beside the fp64 math tables)
     const int n_dates = args.n_bs + args.last_intrinsic;
-    const size_t table_lds = (size_t)n_dates * sizeof(CvaStep<Real>);
+    const size_t table_lds = (size_t)(n_dates + (n_dates & 1)) * sizeof(CvaStep<Real>);   // whole date pairs (the fp32 layout pairs them)
     // (calls on an external array -- the from-normals hooks, the staged launch-geometry form -- are compared bit for bit with
     // one-lane-per-path kernels: they go date-parallel only when the setting forces it)
     const int lanes_setting = (c->ext && c->cva_date_lanes == 0) ? 1 : c->cva_date_lanes;
-    CvaPlan plan = cva_plan(lanes_setting, n, n_dates, c->compute_units, !xorwow && table_lds <= 48 * 1024);
+    CvaPlan plan = cva_plan(lanes_setting, n, n_dates, c->compute_units, !xorwow && table_lds <= 48 * 1024, sizeof(Real));
     std::vector<Segment> segs, tail_segs;
     if (plan.main_paths && plan.tail_paths) {
         bool split = !c->antithetic && !c->ext && table_lds <= 24 * 1024;

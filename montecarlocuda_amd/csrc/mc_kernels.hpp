@@ -1426,13 +1426,13 @@ __device__ __forceinline__ double lane_fetch(double v, uint32_t src_lane)
 
 // exposures of two consecutive dates of one path, table rows in vector registers; same operations per date as the pair
 // forms of cva_path (fp32: the two dates in the halves of every packed instruction; fp64: one shared reciprocal)
-__device__ __forceinline__ void exposure_pair_rows(float bx, float W_a, float W_b, const CvaStep<float> &sa, const CvaStep<float> &sb,
-                                                   float &ee_a, float &ee_b)
+// fp32: `row` = the pair's 12 floats {g, g', e1, e1', e2, e2', xk, xk', disc, disc', dp, dp'} (date, next date) read per lane from the
+// LDS copy -- adjacent registers are ready-made packed operands (two separate 6-float rows made the compiler transpose them
+// through scratch memory: 28 bytes per lane and twice the time of the one-lane-per-path kernel)
+__device__ __forceinline__ f2 exposure_pair_rows(float bx, f2 Wp, const float (&row)[12])
 {
-    const f2 Wp = {W_a, W_b};
-    const f2 ee = bs_exposure_dates(pk_fma(Wp, (f2){bx, bx}, (f2){sa.xk, sb.xk}), Wp, (f2){sa.g, sb.g}, (f2){sa.e1, sb.e1}, (f2){sa.e2, sb.e2},
-                                    (f2){sa.disc, sb.disc});
-    ee_a = ee.x, ee_b = ee.y;
+    return bs_exposure_dates(pk_fma(Wp, (f2){bx, bx}, (f2){row[6], row[7]}), Wp, (f2){row[0], row[1]}, (f2){row[2], row[3]}, (f2){row[4], row[5]},
+                             (f2){row[8], row[9]});
 }
 __device__ __forceinline__ void exposure_pair_rows(double bx, double W_a, double W_b, const CvaStep<double> &sa, const CvaStep<double> &sb,
                                                    double &ee_a, double &ee_b)
@@ -1455,11 +1455,18 @@ __device__ __forceinline__ void cva_dates_role(const CvaArgs<Real> &o, const Wor
     static_assert(CH % NPB == 0 && CH % 2 == 0, "a lane's chunk is whole generator blocks and whole date pairs");
     CvaStep<Real> *rows = reinterpret_cast<CvaStep<Real> *>(lds_raw);
     const int n_dates = o.n_bs + o.last_intrinsic;
-    {   // the per-date table, once per workgroup (n_dates * 6 reals; the host checked that it fits)
+    {   // the per-date table, once per workgroup (n_dates * 6 reals, rounded up to whole date pairs; the host checked that it fits).
+        // fp64: the rows as they are.  fp32: two dates per row, field by field -- {g, g', e1, e1', ...} -- the packed operands of a pair
         const Real *src = reinterpret_cast<const Real *>(o.steps);
         Real *dst = reinterpret_cast<Real *>(lds_raw);
-        for (int k = threadIdx.x; k < 6 * n_dates; k += GROUP)
-            dst[k] = src[k];
+        for (int k = threadIdx.x; k < 6 * (n_dates + (n_dates & 1)); k += GROUP) {
+            const int date = k / 6, field = k - 6 * date;
+            const Real x = date < n_dates ? src[k] : (Real)0;
+            if constexpr (sizeof(Real) == 4)
+                dst[12 * (date >> 1) + 2 * field + (date & 1)] = x;
+            else
+                dst[k] = x;
+        }
     }
     __syncthreads();
     const uint32_t L = 1u << log2_lanes, lane = threadIdx.x & 63u, sub = lane & (L - 1u);
@@ -1471,8 +1478,9 @@ __device__ __forceinline__ void cva_dates_role(const CvaArgs<Real> &o, const Wor
         const bool live = i < w.n_units;
         const uint32_t unit = w.unit_lo + (live ? i : i0);
         Real W_done = 0, acc = 0;   // W_done: the path's W at the end of the previous round
+        f2 acc2 = {0.0f, 0.0f};     // fp32: even / odd dates of the packed pairs
         for (int r0 = 0; r0 < n_dates; r0 += CH << log2_lanes) {
-            const int j0 = r0 + (int)sub * CH;   // this lane's first date (0-based) of the round
+            const int j0 = r0 + (int)sub * CH;   // this lane's first date (0-based) of the round: a multiple of CH, so every pair starts on an even date
             Real z[CH];
 #pragma unroll
             for (int t = 0; t < CH; ++t)
@@ -1502,31 +1510,60 @@ __device__ __forceinline__ void cva_dates_role(const CvaArgs<Real> &o, const Wor
 #pragma unroll
             for (int t = 0; t < CH; t += 2) {
                 const int ja = j0 + t, jb = ja + 1;
-                const CvaStep<Real> sa = rows[ja < n_dates ? ja : n_dates - 1], sb = rows[jb < n_dates ? jb : n_dates - 1];
                 const Real W_a = Wl + z[t], W_b = W_a + z[t + 1];
                 Wl = W_b;
-                Real ee_a, ee_b;
-                exposure_pair_rows(o.bx, W_a, W_b, sa, sb, ee_a, ee_b);
-                if (ANTI) {
-                    Real em_a, em_b;
-                    exposure_pair_rows(o.bx, -W_a, -W_b, sa, sb, em_a, em_b);
-                    ee_a += em_a, ee_b += em_b;
-                }
-                ee_a = ja < o.n_bs ? ee_a : (Real)0;   // beyond the closed-form dates: the intrinsic-value date below, or nothing
-                ee_b = jb < o.n_bs ? ee_b : (Real)0;
-                if (o.last_intrinsic && (ja == o.n_bs || jb == o.n_bs)) {   // one lane of one wave of the path
-                    const bool first = ja == o.n_bs;
-                    const Real Wi = first ? W_a : W_b, xk = first ? sa.xk : sb.xk;
-                    Real iv = intrinsic_exposure(o.bx, Wi, xk, o.strike);
+                const bool intrinsic_here = o.last_intrinsic && (ja == o.n_bs || jb == o.n_bs);   // one lane of one wave of the path
+                if constexpr (sizeof(Real) == 4) {
+                    const int pair = (ja < n_dates ? ja : n_dates - 1) >> 1;
+                    float row[12];
+                    const float *pr = reinterpret_cast<const float *>(lds_raw) + 12 * pair;
+#pragma unroll
+                    for (int f = 0; f < 12; ++f)
+                        row[f] = pr[f];
+                    const f2 Wp = {W_a, W_b};
+                    f2 ee = exposure_pair_rows(o.bx, Wp, row);
                     if (ANTI)
-                        iv += intrinsic_exposure(o.bx, -Wi, xk, o.strike);
-                    ee_a = first ? iv : ee_a;   // (selects: a reference picked at run time would put both in scratch)
-                    ee_b = first ? ee_b : iv;
+                        ee += exposure_pair_rows(o.bx, -Wp, row);
+                    ee.x = ja < o.n_bs ? ee.x : 0.0f;   // beyond the closed-form dates: the intrinsic-value date below, or nothing
+                    ee.y = jb < o.n_bs ? ee.y : 0.0f;
+                    if (intrinsic_here) {
+                        const bool first = ja == o.n_bs;
+                        const float Wi = first ? W_a : W_b, xk = first ? row[6] : row[7];
+                        float iv = intrinsic_exposure(o.bx, Wi, xk, o.strike);
+                        if (ANTI)
+                            iv += intrinsic_exposure(o.bx, -Wi, xk, o.strike);
+                        ee.x = first ? iv : ee.x;
+                        ee.y = first ? ee.y : iv;
+                    }
+                    const f2 dp = {ja < n_dates ? row[10] : 0.0f, jb < n_dates ? row[11] : 0.0f};
+                    acc2 = pk_fma(dp, ee, acc2);
+                } else {
+                    const CvaStep<Real> sa = rows[ja < n_dates ? ja : n_dates - 1], sb = rows[jb < n_dates ? jb : n_dates - 1];
+                    Real ee_a, ee_b;
+                    exposure_pair_rows(o.bx, W_a, W_b, sa, sb, ee_a, ee_b);
+                    if (ANTI) {
+                        Real em_a, em_b;
+                        exposure_pair_rows(o.bx, -W_a, -W_b, sa, sb, em_a, em_b);
+                        ee_a += em_a, ee_b += em_b;
+                    }
+                    ee_a = ja < o.n_bs ? ee_a : (Real)0;   // beyond the closed-form dates: the intrinsic-value date below, or nothing
+                    ee_b = jb < o.n_bs ? ee_b : (Real)0;
+                    if (intrinsic_here) {
+                        const bool first = ja == o.n_bs;
+                        const Real Wi = first ? W_a : W_b, xk = first ? sa.xk : sb.xk;
+                        Real iv = intrinsic_exposure(o.bx, Wi, xk, o.strike);
+                        if (ANTI)
+                            iv += intrinsic_exposure(o.bx, -Wi, xk, o.strike);
+                        ee_a = first ? iv : ee_a;   // (selects: a reference picked at run time would put both in scratch)
+                        ee_b = first ? ee_b : iv;
+                    }
+                    acc = fma_r(sa.dp, ee_a, acc);
+                    acc = fma_r(sb.dp, ee_b, acc);
                 }
-                acc = fma_r(sa.dp, ee_a, acc);
-                acc = fma_r(sb.dp, ee_b, acc);
             }
         }
+        if constexpr (sizeof(Real) == 4)
+            acc += acc2.x + acc2.y;
         for (uint32_t d = 1; d < L; d <<= 1)   // the path's sum over its lanes (every lane ends up with a total; lane sub = 0's is used)
             acc += lane_fetch(acc, lane ^ d);
         const Real p = acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);

@@ -108,16 +108,23 @@ static int basket_tiled_min()
 //   tail_paths   trailing paths, date-parallel (both > 0: one launch of cva_split_kernel; main_paths == 0: cva_dates_kernel)
 // The one-lane-per-path kernel's time is a staircase in steps of one WAVE-TRIP = 64 lanes x 4 SIMDs x CUs paths (65 536 on
 // MI355X): a launch pays for whole trips -- 1 250 000 paths (C5's shard of 8: 19.07 trips) cost what 1 310 720 do, 990.9 us against
-// 944.8 for 19 trips -- and a wave alone on its SIMD needs 104 us for its path whatever the call's size.  Measured with
-// tools/c/shard_clock (profiles/r06_shard_clock_AD_fused_split.log), 256 dates fp64:
-//   * a call of 2.5 ... 64 trips that ends in a partial trip of at most 60 % hands that remainder to the date-parallel
-//     workgroups of the same launch, with enough lanes per path to put about two of their waves on every SIMD
-//     (1 250 000 paths: 953.0 us; the gain shrinks to nothing as the remainder approaches a full trip: 0.31 of a trip -21.6 us,
-//     0.45 -15.2, 0.53 -8.0; beyond 64 trips a trip is under 1.6 % of the call);
-//   * a call below 2.5 trips runs date-parallel as a whole, with lanes for ~4 waves per SIMD: 4096 paths 104.1 -> 15.0 us
-//     (64 lanes), 32 768: 105.3 -> 41.9 (8), 65 536: 104.7 -> 67.6 (4), 131 072 -- the reference driver's own call,
-//     dp/cvaOpt.cu:12-15 -- 127.6 -> 119.2 (4); from 196 608 paths on one lane per path is as fast or faster (the date-parallel
-//     form pays per-lane table rows and Philox counters: +6 % at 2 lanes, +11 % at 8, +26...33 % from 16 on at 1e6 paths);
+// 944.8 for 19 trips -- and a wave alone on its SIMD needs 105 us (fp64; 49 us fp32) for a 256-date path whatever the call's size.
+// Measured with tools/c/shard_clock and tools/cva_call_latency.py (profiles/r06_shard_clock_AD_fused_split.log,
+// profiles/r06_cva_call_latency.log):
+//   * a call of more than the small-call limit and at most 64 trips, on a grid of at least 64 dates, that ends in a partial trip
+//     of at most 60 % hands that remainder to date-parallel workgroups of the same launch, with enough lanes per path to put
+//     about two of their waves on every SIMD (1 250 000 paths x 256 dates: fp64 990.9 -> 953.0 us, fp32 409.4 -> 393.3; the gain
+//     shrinks to nothing as the remainder approaches a full trip: 0.31 of a trip -21.6 us, 0.45 -15.2, 0.53 -8.0; beyond 64 trips
+//     a trip is under 1.6 % of the call);
+//   * a SMALL call runs date-parallel as a whole, with lanes for ~4 waves per SIMD.  What "small" is depends on how long a
+//     lane's serial walk is and on how many waves the one-lane-per-path kernel keeps per SIMD (fp64: 6, fp32: 8):
+//         fp64, >= 64 dates: up to 2 trips   (256 dates: 4096 paths 104.9 -> 15.7 us, 65 536: 107.4 -> 66.8, 131 072 -- the reference
+//                                             driver's own call, dp/cvaOpt.cu:12-15 -- 130.4 -> 120.6; 196 608: a tie)
+//         fp64, <  64 dates: up to 1 trip    (25 dates: 16 384 paths 17.8 -> 11.3 us, 65 536: 18.6 -> 17.0; 131 072: 20.7 -> 26.2, worse)
+//         fp32, >= 64 dates: up to 1 trip    (256 dates: 4096 paths 48.9 -> 11.0 us, 65 536: 50.1 -> 35.5; 131 072: a tie)
+//         fp32, <  64 dates: up to 1/4 trip  (25 dates: 16 384 paths 11.4 -> 9.1 us; 65 536: 11.6 -> 12.6, worse)
+//     (the date-parallel form pays per-lane table rows and per-lane Philox counters: +6 % at 2 lanes, +11 % at 8, +26...33 % from
+//     16 on at 1e6 fp64 paths);
 //   * everything else keeps one lane per path.
 // `forced_lanes`: 0 = this rule, 1 = one lane per path always, 2 ... 64 = the whole call date-parallel with that many lanes
 // (mc_context_set_cva_date_lanes / MC_CVA_DATE_LANES; the tests sweep it).  A path cannot use more lanes than it has
@@ -131,9 +138,10 @@ static int cva_max_log2_lanes(int n_dates)
         ++l;
     return l;
 }
-static CvaPlan cva_plan(int forced_lanes, uint64_t n, int n_dates, int compute_units, bool dates_kernel_possible)
+static CvaPlan cva_plan(int forced_lanes, uint64_t n, int n_dates, int compute_units, bool dates_kernel_possible, size_t real_bytes)
 {
-    constexpr int tail_max_pct = 60, small_trips_x4 = 10 /* 2.5 trips */, small_fill = 4, split_max_trips = 64;
+    constexpr int tail_max_pct = 60, small_fill = 4, split_max_trips = 64, long_grid = 64;
+    const int small_trips_x4 = real_bytes == 8 ? (n_dates >= long_grid ? 8 : 4) : (n_dates >= long_grid ? 4 : 1);   // quarter trips, inclusive
     const int max_l = cva_max_log2_lanes(n_dates);
     CvaPlan p = {n, 0, 0};
     if (!dates_kernel_possible || max_l == 0 || forced_lanes == 1 || n == 0)
@@ -146,7 +154,7 @@ static CvaPlan cva_plan(int forced_lanes, uint64_t n, int n_dates, int compute_u
         return p;
     }
     const uint64_t trip = 64ull * 4ull * (uint64_t)(compute_units > 0 ? compute_units : 256);
-    if (4 * n < (uint64_t)small_trips_x4 * trip) {   // small call: all of it date-parallel, ~small_fill waves per SIMD
+    if (4 * n <= (uint64_t)small_trips_x4 * trip) {   // small call: all of it date-parallel, ~small_fill waves per SIMD
         int l = log2_ceil(((uint64_t)small_fill * trip + n - 1) / n);
         l = l > max_l ? max_l : l;
         if (l > 0)
@@ -154,7 +162,7 @@ static CvaPlan cva_plan(int forced_lanes, uint64_t n, int n_dates, int compute_u
         return p;
     }
     const uint64_t r = n % trip;
-    if (r == 0 || 100 * r > (uint64_t)tail_max_pct * trip || n > (uint64_t)split_max_trips * trip)
+    if (r == 0 || 100 * r > (uint64_t)tail_max_pct * trip || n > (uint64_t)split_max_trips * trip || n_dates < long_grid)
         return p;
     int l = log2_ceil((2 * trip + r - 1) / r);
     l = l < 1 ? 1 : (l > max_l ? max_l : l);

@@ -159,16 +159,21 @@ def test_split_call_main_beside_tail(mc, po, X):
 
 
 def test_small_call_runs_date_parallel_by_default(mc, po):
-    """The reference driver's own call (dp/cvaOpt.cu:12-15: 131 072 paths, 1024 blocks): below three wave-trips the automatic
-    rule prices the whole call date-parallel; same estimate as one lane per path."""
-    c = dict(CVA0, n_grid=250)
+    """The reference driver's own call (dp/cvaOpt.cu:12-15: 131 072 paths, 1024 blocks; grids 25 ... 500, :70-75): in fp64 on a grid of
+    64 dates or more the automatic rule prices it date-parallel as a whole (up to 2 wave-trips); on the 25-date grid, and in fp32,
+    131 072 paths keep one lane per path (measured slower otherwise: profiles/r06_cva_call_latency.log).  Same estimate either way."""
     with mc.Engine(0) as e:
-        auto = e.cva(c, 131072, SEED, 0, "f64")
-        wgs_auto = e.last_launch()[0]
-        e.set_cva_date_lanes(1)
-        one = e.cva(c, 131072, SEED, 0, "f64")
-        assert e.last_launch()[0] == 131072 // 256 and wgs_auto > 131072 // 256
-        assert auto.sum == pytest.approx(one.sum, rel=1e-12) and auto.sum2 == pytest.approx(one.sum2, rel=2e-12)
+        for X, n_grid, paths, parallel in (("f64", 250, 131072, True), ("f64", 25, 131072, False), ("f64", 25, 65536, True),
+                                           ("f32", 250, 131072, False), ("f32", 250, 65536, True), ("f32", 25, 65536, False), ("f32", 25, 16384, True)):
+            c = dict(CVA0, n_grid=n_grid)
+            e.set_cva_date_lanes(0)
+            auto = e.cva(c, paths, SEED, 0, X)
+            wgs_auto = e.last_launch()[0]
+            e.set_cva_date_lanes(1)
+            one = e.cva(c, paths, SEED, 0, X)
+            assert e.last_launch()[0] == paths // 256
+            assert (wgs_auto > paths // 256) == parallel, (X, n_grid, paths, wgs_auto)
+            assert auto.sum == pytest.approx(one.sum, rel=TOL[X]["rel"]) and auto.sum2 == pytest.approx(one.sum2, rel=2 * TOL[X]["rel"])
 
 
 def test_reference_stream_meets_the_goldens(eng, po):

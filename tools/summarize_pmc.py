@@ -18,7 +18,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)   # bench.py (launch_stamp) lives at the repo root; `python tools/summarize_pmc.py` does not put it on the path
 w = sys.argv[1] if len(sys.argv) > 1 else "vanilla_f32"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r06"
 base = os.path.join(ROOT, "gpurun_out", f"pmc_{w}")
 acc = defaultdict(lambda: defaultdict(list))   # kernel -> counter -> values per dispatch
 grids = defaultdict(set)                       # kernel -> {(workgroups, lanes per workgroup)} seen in the passes
@@ -85,7 +85,7 @@ if main and "FETCH_SIZE" in summary[main[0]]:
     med = lambda v: sorted(v)[len(v) // 2]
     b = {c: med(v) for c, v in x2.get(main[0], {}).items()}
     a1 = {c: med(v) for c, v in acc[main[0]].items()}
-    if b and abs(b.get("SQ_WAVES", 0) - a.get("SQ_WAVES", -1)) < 0.5:
+    if b and abs(b.get("SQ_WAVES", 0) - a1.get("SQ_WAVES", -1)) < 0.5:   # the same grid in both passes (medians: an average would mix in the odd dispatch)
         for c, key in (("SQ_INSTS_VALU", "valu"), ("SQ_INSTS_VALU_TRANS_F32", "trans_f32"), ("SQ_INSTS_VALU_TRANS_F64", "trans_f64"),
                        ("SQ_INSTS_SALU", "salu"), ("SQ_INSTS_SMEM", "smem"), ("SQ_INSTS_LDS", "lds")):
             if c in a1 and c in b:
