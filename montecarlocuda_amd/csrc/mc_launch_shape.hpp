@@ -108,21 +108,21 @@ static int basket_tiled_min()
 //   tail_paths   trailing paths, date-parallel (both > 0: one launch of cva_split_kernel; main_paths == 0: cva_dates_kernel)
 // The one-lane-per-path kernel's time is a staircase in steps of one WAVE-TRIP = 64 lanes x 4 SIMDs x CUs paths (65 536 on
 // MI355X): a launch pays for whole trips -- 1 250 000 paths (C5's shard of 8: 19.07 trips) cost what 1 310 720 do, 990.9 us against
-// 944.8 for 19 trips -- and a wave alone on its SIMD needs 105 us (fp64; 49 us fp32) for a 256-date path whatever the call's size.
+// 944.8 for 19 trips -- and a wave alone on its SIMD needs ~105 us (fp64; ~49 us fp32) for a 256-date path whatever the call's size.
 // Measured with tools/c/shard_clock and tools/cva_call_latency.py (profiles/r06_shard_clock_AD_fused_split.log,
 // profiles/r06_cva_call_latency.log):
 //   * a call of more than the small-call limit and at most 64 trips, on a grid of at least 64 dates, that ends in a partial trip
 //     of at most 60 % hands that remainder to date-parallel workgroups of the same launch, with enough lanes per path to put
-//     about two of their waves on every SIMD (1 250 000 paths x 256 dates: fp64 990.9 -> 953.0 us, fp32 409.4 -> 393.3; the gain
+//     about two of their waves on every SIMD (1 250 000 paths x 256 dates: fp64 990.9 -> 953.0 us, fp32 -4 %; the gain
 //     shrinks to nothing as the remainder approaches a full trip: 0.31 of a trip -21.6 us, 0.45 -15.2, 0.53 -8.0; beyond 64 trips
 //     a trip is under 1.6 % of the call);
 //   * a SMALL call runs date-parallel as a whole, with lanes for ~4 waves per SIMD.  What "small" is depends on how long a
 //     lane's serial walk is and on how many waves the one-lane-per-path kernel keeps per SIMD (fp64: 6, fp32: 8):
-//         fp64, >= 64 dates: up to 2 trips   (256 dates: 4096 paths 104.9 -> 15.7 us, 65 536: 107.4 -> 66.8, 131 072 -- the reference
-//                                             driver's own call, dp/cvaOpt.cu:12-15 -- 130.4 -> 120.6; 196 608: a tie)
-//         fp64, <  64 dates: up to 1 trip    (25 dates: 16 384 paths 17.8 -> 11.3 us, 65 536: 18.6 -> 17.0; 131 072: 20.7 -> 26.2, worse)
-//         fp32, >= 64 dates: up to 1 trip    (256 dates: 4096 paths 48.9 -> 11.0 us, 65 536: 50.1 -> 35.5; 131 072: a tie)
-//         fp32, <  64 dates: up to 1/4 trip  (25 dates: 16 384 paths 11.4 -> 9.1 us; 65 536: 11.6 -> 12.6, worse)
+//         fp64, >= 64 dates: up to 2 trips   (256 dates, kernel time rounded to the us: 4096 paths 105 -> 16, 65 536: 107 -> 67, 131 072 --
+//                                             the reference driver's own call, dp/cvaOpt.cu:12-15 -- 130 -> 120; 196 608: a tie)
+//         fp64, <  64 dates: up to 1 trip    (25 dates: 16 384 paths 18 -> 11, 65 536: 19 -> 17; 131 072: 21 -> 26, worse)
+//         fp32, >= 64 dates: up to 1 trip    (256 dates: 4096 paths 49 -> 11, 65 536: 50 -> 36; 131 072: a tie)
+//         fp32, <  64 dates: up to 1/4 trip  (25 dates: 16 384 paths 11.5 -> 9.1; 65 536: 11.7 -> 12.1, worse)
 //     (the date-parallel form pays per-lane table rows and per-lane Philox counters: +6 % at 2 lanes, +11 % at 8, +26...33 % from
 //     16 on at 1e6 fp64 paths);
 //   * everything else keeps one lane per path.

@@ -249,6 +249,12 @@ def test_bench_two_ranks_rccl_one_rank_per_device(tmp_path):
     assert rows["C4"]["paths_per_gpu"] == 5 * 10 ** 8 and rows["C4"]["paths_priced"] == 10 ** 9 and 9.70 < rows["C4"]["value"] < 9.74
     assert rows["C5"]["paths_priced"] == 10 ** 7 and 0.1895 < rows["C5"]["value"] < 0.1905
     assert line["value"] > 2e11          # two devices, weak scaling: no less than one device's worth
+    # the first measured collective: the line must explain whatever efficiency it shows
+    ssn = line["strong_summary"]
+    print("allreduce_us", ssn["allreduce_us"], {c: ssn[c] for c in ("C4", "C5")})
+    assert 1 < ssn["allreduce_us"]["median"] < 5000
+    for c in ("C4", "C5", "C4_n32", "C5_n32"):
+        assert 0.3 < ssn[c]["eff"] <= ssn[c]["eff_device_side"] * 1.02 and ssn[c]["collective_ms"] > -0.05
 
 
 def test_bench_four_ranks_share_the_gpu(tmp_path):
@@ -268,3 +274,9 @@ def test_bench_four_ranks_share_the_gpu(tmp_path):
     rows = {x["config"]: x for x in d["strong"]["rows"]}
     assert rows["C4"]["paths_per_gpu"] == 25 * 10 ** 7 and rows["C4"]["paths_priced"] == 10 ** 9 and 9.70 < rows["C4"]["value"] < 9.74
     assert rows["C5"]["paths_per_gpu"] == 25 * 10 ** 5 and rows["C5"]["paths_priced"] == 10 ** 7 and 0.1895 < rows["C5"]["value"] < 0.1905
+    # the decomposition of every base row over the four ranks, and the 24-byte collective alone (gloo here)
+    ssn = line["strong_summary"]
+    assert ssn["allreduce_us"]["calls"] == 200
+    for c in ("C4", "C5", "C4_n32", "C5_n32"):
+        assert len(rows[c]["t_shard_ms_by_rank"]) == 4 and ssn[c]["t_shard_ms"][0] <= ssn[c]["t_shard_ms"][1] and ssn[c]["t1_ms_rank0"] > 0
+        assert ssn[c]["eff_device_side"] == pytest.approx(ssn[c]["t1_ms_rank0"] / (4 * ssn[c]["t_shard_ms"][1]), rel=1e-3)

@@ -113,6 +113,8 @@ def test_strong_scaling_driver_emits_json():
     assert all(r["wall_ms_median"] > 0 and 0.05 < r["device_side_efficiency"] < 1.2 for r in shards)
     runs = [r for r in rows if "workload" in r and "shard_of" not in r]
     assert len(runs) >= 4 and all(r["wall_ms_median"] > 0 and r["rccl_vs_host_rel"] <= 1e-12 for r in runs)
+    # the collective as the calling thread saw it (last device's own triple -> all-reduced triple): RCCL over one rank + the publish kernel here
+    assert all(0 < r["collective_us"] < 500 and r["device_delivery_us"][0] > 0 for r in runs), [r.get("collective_us") for r in runs]
     assert any(r["workload"].startswith("C4 basket n=16") and 9.5 < r["value"] < 9.9 for r in runs)
     assert any(r["workload"].startswith("C5 CVA") and 0.18 < r["value"] < 0.20 for r in runs)
 
