@@ -37,7 +37,7 @@ for it in range(cases):
       seed = int(rng.integers(0, 2 ** 63))
       first = int(rng.integers(0, 2 ** 40)) if rng.random() < 0.7 else (1 << 32) * int(rng.integers(1, 100)) - int(rng.integers(1, 300))
       n_paths = int(rng.integers(1, 700))
-      prod = rng.choice(["vanilla", "basket", "basket", "cva"])
+      prod = rng.choice(["vanilla", "basket", "basket", "cva", "cva"])
       spot = float(np.exp(rng.uniform(np.log(5), np.log(500))))
       r, t = float(rng.uniform(0.0, 0.08)), float(rng.choice([0.25, 0.5, 1.0, 2.0, 3.0]))
       vol_lo, vol_hi, k_lo, k_hi = 0.05, 0.6, 0.6, 1.5
@@ -70,10 +70,12 @@ for it in range(cases):
       else:
           c = dict(s=spot, k=spot * float(rng.uniform(max(k_lo, 0.2), min(k_hi, 5.0))), r=r, v=float(rng.uniform(max(vol_lo, 0.02), min(vol_hi, 1.0))), t=t,
                    defint=float(rng.uniform(0.005, 0.1)), lgd=float(rng.uniform(0.2, 0.9)), n_grid=int(rng.integers(1, 1500 if EXTREME else 300)))
+          lanes = int(rng.choice([0, 0, 1, 2, 4, 8, 16, 32, 64]))    # 0 = the call-size rule (small calls: date-parallel), else forced
+          eng[(anti, False)].set_cva_date_lanes(lanes)
           got = eng[(anti, False)].cva_paths(c, min(n_paths, 200), seed, first, X).astype(np.float64)
           want, _ = po.dev_cva(X, c, seed, first, min(n_paths, 200), antithetic=anti)
           level = spot * float(np.exp(max(0.0, r) * t + 4 * c["v"] * np.sqrt(t)))
-          note((prod, X), float(np.abs(got - want.astype(np.float64)).max()), TOL[X]["cva"] * level / 100 * 3 * (1 + c["n_grid"] / 256), (c, anti, first))
+          note((prod, X), float(np.abs(got - want.astype(np.float64)).max()), TOL[X]["cva"] * level / 100 * 3 * (1 + c["n_grid"] / 256), (c, anti, first, lanes))
   except mc.McError as ex:
       # inputs whose exponent leaves the range of the precision are REFUSED by the engine (tests/test_gpu_parity.py
       # test_invalid_arguments_are_errors_not_crashes); anything else is a failure of the sweep
