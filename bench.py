@@ -86,12 +86,26 @@ def workloads(mc):
         "vanilla_f64_n32": ("vanilla", "f64", VAN, 10 ** 8, 15.5, "European vanilla call, 1e8 paths, fp64 on fp32 normals (reference dp arithmetic)"),
         "basket16_f64_n32": ("basket", "f64", lambda: basket_inputs(mc, 16, "f64"), 125 * 10 ** 6, f_basket(16), "Basket call, 16 assets, 1e9/8 paths per GPU, fp64 on fp32 normals (reference dp arithmetic)"),
         "cva256_f64_n32": ("cva", "f64", CVA, 1250000, 60.0 * 256 + 5, "CVA, 256 dates x 1e7/8 paths per GPU, fp64 on fp32 normals (reference dp arithmetic)"),
+        # the secondary estimators on the same kernels (the reference has the plain estimator only).  A "path" of the antithetic
+        # estimator is a mirrored PAIR on one normal (6.5 + 2 x 9 flop vanilla; n^2 + n + 6.5 n + 2 (5 n + 6) basket); the control variate
+        # adds the geometric basket's weighted log-sum and payoff (2 n + 4 flop)
+        "vanilla_f32_anti": ("vanilla", "f32", VAN, 10 ** 8, 24.5, "European vanilla call, 1e8 antithetic pairs, fp32"),
+        "basket16_f64_anti": ("basket", "f64", lambda: basket_inputs(mc, 16, "f64"), 125 * 10 ** 6, 16 * 16 + 17.5 * 16 + 12,
+                              "Basket call, 16 assets, 1.25e8 antithetic pairs, fp64"),
+        "basket16_f64_cv": ("basket", "f64", lambda: basket_inputs(mc, 16, "f64"), 125 * 10 ** 6, f_basket(16) + 2 * 16 + 4,
+                            "Basket call, 16 assets, 1.25e8 paths, fp64, geometric-basket control variate"),
     }
 
 
 def workload_settings(name):
     """Engine settings a workload runs under (besides the defaults)."""
-    return {"normals": "f32"} if name.endswith("_n32") else {}
+    if name.endswith("_n32"):
+        return {"normals": "f32"}
+    if name.endswith("_anti"):
+        return {"antithetic": True}
+    if name.endswith("_cv"):
+        return {"control_variate": True}
+    return {}
 
 
 def elf_section(path, name):
@@ -948,6 +962,10 @@ def main():
         e_.set_finish(args.finish == "fused")
         if "normals" in settings:
             e_.set_normals(settings["normals"])
+        if settings.get("antithetic"):
+            e_.set_antithetic(True)
+        if settings.get("control_variate"):
+            e_.set_control_variate(True)
     eng = engines[0]
     eng_info = eng.info()
     prod, X, inputs, paths, flop_per_path, desc = workloads(mc)[args.workload]
@@ -1190,6 +1208,8 @@ def main():
             r, t_ = float(np.float32(r)), float(np.float32(t_))
         disc = 1.0 if prod == "cva" else math.exp(-r * t_)
         price, ci = mc.closing(tot[0], tot[1], int(tot[2]), disc)
+        if settings.get("control_variate"):     # the simulated quantity is payoff - control: its closed-form mean comes back on the host
+            price += disc * mc.basket_control_mean(inputs, X)
         assert int(tot[2]) == R * K * step_total, (tot[2], R * K * step_total)
         units_per_step = step_total
         value = units_per_step * K / elapsed
@@ -1245,7 +1265,8 @@ def main():
                                                / kernel_s / 8e12) if committed.get("hbm_bytes_per_launch") and kernel_s else None,
                          "traffic_source": (committed.get("source", "") + " (committed PMC profile, not measured in this run)")
                          if committed else None,
-                         "kernel": kernel_name(prod, X, inputs), "flop_per_path": flop_per_path,
+                         "kernel": kernel_name(prod, X, inputs) + (" [antithetic]" if settings.get("antithetic") else " [control variate]" if settings.get("control_variate") else ""),
+                         "flop_per_path": flop_per_path,
                          "avg_kernel_us": kernel_s * 1e6 if kernel_s else None, "kernel_samples": ex_n if ex_s else samples,
                          "kernel_paths_per_s": shard_count / kernel_s if kernel_s else None,
                          "duration_basis": "exclusive: %d launches of the same kernel on the same inputs, one at a time on one "

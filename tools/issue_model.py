@@ -200,6 +200,11 @@ WORKLOADS = {
     "cva256_f64": spec("cva_kernelIdLb0ENS_9GenPhiloxEEE", dates_per_trip=2),
     "cva256_f64_n32": spec("cva_kernelIdLb0ENS_13GenPhiloxF32NEEE", dates_per_trip=2),
     "cva256_f32": spec("cva_kernelIfLb0ENS_9GenPhiloxEEE", dates_per_trip=4),
+    # secondary estimators (no performance record): antithetic = the ANTI instantiation of the same kernel (a unit is a
+    # mirrored pair), control variate = the plain instantiation with its wave-uniform `cv` branches taken
+    "vanilla_f32_anti": spec("vanilla_f32_kernelILb1ENS_9GenPhiloxEEE", units=4, rules=[flush(8)]),
+    "basket16_f64_anti": spec("basket_tiled_kernelIdLi16ELb1ENS_9GenPhiloxEEE", units=1, rules=[DUMP], note="anti"),
+    "basket16_f64_cv": spec("basket_tiled_kernelIdLi16ELb0ENS_9GenPhiloxEEE", units=1, rules=[DUMP], note="cv"),
 }
 
 
@@ -259,15 +264,19 @@ def main():
             # nor the main block (most VALU)
             if ops is big["ops"]:
                 return False
+            if sp.get("note") == "anti" and n(ops, r"^v_") >= 100:
+                return False   # the mirrored half of the pair (its exponentials and payoff): a block of its own in the ANTI instantiation, always run
             gen = n(ops, PHILOX) or n(ops, r"^v_(sqrt|rsq)_f64|^v_log_f32|^v_sin_f32")
             # (the fp32 CVA loop has TWO paired-exposure blocks per trip of four dates, each nearly the size of the biggest)
             return not gen and n(ops, r"^v_") < 0.7 * n(big["ops"], r"^v_") and n(ops, r"^v_(exp_f32|rcp_f32|rcp_f64|ldexp_f64)") > 0
 
+        cv_on = sp.get("note") == "cv"   # the control variate's blocks run: only the dump stays cold
+
         def cold(ops):
-            return is_dump(ops) or is_single(ops)
+            return is_dump(ops) or (is_single(ops) and not cv_on)
 
         def periodic(ops):   # the every-8th-trip flush of the packed fp32 sums: its own small block in the two kernels that have one
-            return 1.0 / 8 if (wl in ("vanilla_f32", "basket4_f32") and n(ops, r"^v_cvt_f64_f32") > 0 and n(ops, PHILOX) == 0) else None
+            return 1.0 / 8 if (wl in ("vanilla_f32", "vanilla_f32_anti", "basket4_f32") and n(ops, r"^v_cvt_f64_f32") > 0 and n(ops, PHILOX) == 0) else None
         # executions per trip of the hot loop.  No dynamic trace is to be had here (rocprofv3's thread trace needs a decoder the
         # image lacks), so the weights are rules, each a statement about a wave-uniform branch whose outcome is known for a
         # pricing call of the bench, and the hardware counters check the sum (below):
@@ -290,7 +299,7 @@ def main():
             nm, ops = bk["name"], bk["ops"]
             if is_dump(ops):
                 weight[nm], why[nm] = 0.0, "per-path dump: `out` is NULL in pricing calls"
-            elif is_single(ops):
+            elif is_single(ops) and not cv_on:
                 weight[nm], why[nm] = 0.0, ("single-date path (cva_single_date): a grid of 256 closed-form dates never enters it" if is_cva
                                             else "control variate: off in the bench's plain estimator")
             elif periodic(ops):
