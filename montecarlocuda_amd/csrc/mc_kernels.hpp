@@ -1398,10 +1398,11 @@ __global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument
 // [r0 + sub CH, r0 + (sub + 1) CH):
 //   1. it draws ITS dates' normals -- the generator is counter-based (block = date / NPB): nothing is handed over --
 //      and keeps them in registers (CH of them);
-//   2. one scan over the L lanes (ds_bpermute: the LDS crossbar, no memory) turns the chunk sums into every lane's W offset;
+//   2. one DPP scan over the L lanes (row_shr inside rows of 16, row_bcast across rows: pure VALU) turns the chunk sums into every
+//      lane's W offset;
 //   3. it prices its CH dates with the same per-date operations as cva_kernel, the table row read per LANE from an LDS copy
 //      of the table (the date is no longer wave-uniform, so the scalar loads of cva_kernel are not available);
-// and after the last round one butterfly over the L lanes forms the path's sum_j dp_j ee_j BEFORE it is squared.  The
+// and after the last round one DPP reduction over the L lanes forms the path's sum_j dp_j ee_j BEFORE it is squared.  The
 // values differ from cva_kernel's only by the association of two sums (W, and the sum over dates): 1e-16-level in fp64.
 // What it is for (mc_api.hip: cva_enqueue picks L): a unit of work is 1/L of a path, so
 //   * the LAST PARTIAL WAVE-TRIP of a large call (cva_kernel's time is a staircase in steps of 64 lanes x 1024 SIMDs = 65 536
@@ -1422,6 +1423,41 @@ __device__ __forceinline__ double lane_fetch(double v, uint32_t src_lane)
     const int lo = __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __double2loint(v));
     const int hi = __builtin_amdgcn_ds_bpermute((int)(src_lane << 2), __double2hiint(v));
     return __hiloint2double(hi, lo);
+}
+// DPP moves inside the wave (pure VALU: no LDS round trip on the scan's dependent chain).  Lanes without a source lane, or in a
+// row masked off, receive 0.  Controls (gfx9 encoding): row_shr:n = 0x110 + n (shift right by n inside a row of 16),
+// wave_shr:1 = 0x138 (the whole wave by one lane); the others are mc_reduce.hpp's.
+constexpr int DPP_ROW_SHR = 0x110, DPP_WAVE_SHR1 = 0x138;
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_fetch(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// Inclusive scan of `v` over aligned groups of L = 2^k <= 64 adjacent lanes (`sub` = lane & (L - 1), L wave-uniform): first inside
+// the rows of 16 (row_shr 1, 2, 4, 8), then row totals across rows (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+template <class Real>
+__device__ __forceinline__ Real group_scan_incl(Real v, uint32_t L, uint32_t sub)
+{
+    const uint32_t r = sub & 15u;   // position inside the row of 16
+    if (L > 1) { const Real t = dpp_fetch<DPP_ROW_SHR + 1>(v); v += r >= 1u ? t : (Real)0; }
+    if (L > 2) { const Real t = dpp_fetch<DPP_ROW_SHR + 2>(v); v += r >= 2u ? t : (Real)0; }
+    if (L > 4) { const Real t = dpp_fetch<DPP_ROW_SHR + 4>(v); v += r >= 4u ? t : (Real)0; }
+    if (L > 8) { const Real t = dpp_fetch<DPP_ROW_SHR + 8>(v); v += r >= 8u ? t : (Real)0; }
+    if (L > 16) { const Real t = dpp_fetch<DPP_ROW_BCAST15, 0xA>(v); v += (sub & 16u) ? t : (Real)0; }
+    if (L > 32) { const Real t = dpp_fetch<DPP_ROW_BCAST31, 0xC>(v); v += (sub & 32u) ? t : (Real)0; }
+    return v;
+}
+// Sum of `v` over the same groups, valid in the group's LAST lane (sub == L - 1; for L <= 16 in every lane of the group).
+template <class Real>
+__device__ __forceinline__ Real group_total_in_last_lane(Real v, uint32_t L)
+{
+    if (L > 1) v += dpp_fetch<DPP_QUAD_XOR1>(v);
+    if (L > 2) v += dpp_fetch<DPP_QUAD_XOR2>(v);
+    if (L > 4) v += dpp_fetch<DPP_ROW_HALF_MIRROR>(v);
+    if (L > 8) v += dpp_fetch<DPP_ROW_MIRROR>(v);
+    if (L > 16) v += dpp_fetch<DPP_ROW_BCAST15, 0xA>(v);
+    if (L > 32) v += dpp_fetch<DPP_ROW_BCAST31, 0xC>(v);
+    return v;
 }
 
 // exposures of two consecutive dates of one path, table rows in vector registers; same operations per date as the pair
@@ -1499,14 +1535,10 @@ __device__ __forceinline__ void cva_dates_role(const CvaArgs<Real> &o, const Wor
 #pragma unroll
             for (int t = 1; t < CH; ++t)
                 incl += z[t];
-            for (uint32_t d = 1; d < L; d <<= 1) {   // inclusive scan of the chunk sums over the path's L lanes
-                const Real below = lane_fetch(incl, lane - d);
-                if (sub >= d)
-                    incl += below;
-            }
-            const Real before = lane_fetch(incl, lane - 1u);
+            incl = group_scan_incl(incl, L, sub);                    // inclusive scan of the chunk sums over the path's L lanes (DPP)
+            const Real before = dpp_fetch<DPP_WAVE_SHR1>(incl);      // the lane below's inclusive sum
             Real Wl = sub ? W_done + before : W_done;                 // W at the end of the date before this lane's chunk
-            W_done += lane_fetch(incl, lane | (L - 1u));
+            W_done += lane_fetch(incl, lane | (L - 1u));              // the round's total, for the NEXT round: off the dependent chain
 #pragma unroll
             for (int t = 0; t < CH; t += 2) {
                 const int ja = j0 + t, jb = ja + 1;
@@ -1564,10 +1596,9 @@ __device__ __forceinline__ void cva_dates_role(const CvaArgs<Real> &o, const Wor
         }
         if constexpr (sizeof(Real) == 4)
             acc += acc2.x + acc2.y;
-        for (uint32_t d = 1; d < L; d <<= 1)   // the path's sum over its lanes (every lane ends up with a total; lane sub = 0's is used)
-            acc += lane_fetch(acc, lane ^ d);
+        acc = group_total_in_last_lane(acc, L);   // the path's sum over its lanes, in the group's last lane
         const Real p = acc * (ANTI ? o.lgd * (Real)0.5 : o.lgd);
-        if (live && sub == 0) {
+        if (live && sub == L - 1u) {
             acc_s += (double)p;
             acc_q = __builtin_fma((double)p, (double)p, acc_q);
             if (out)

@@ -123,7 +123,7 @@ static int basket_tiled_min()
 //         fp64, <  64 dates: up to 1 trip    (25 dates: 16 384 paths 18 -> 11, 65 536: 19 -> 17; 131 072: 21 -> 26, worse)
 //         fp32, >= 64 dates: up to 1 trip    (256 dates: 4096 paths 49 -> 11, 65 536: 50 -> 36; 131 072: a tie)
 //         fp32, <  64 dates: up to 1/4 trip  (25 dates: 16 384 paths 11.5 -> 9.1; 65 536: 11.7 -> 12.1, worse)
-//     (the date-parallel form pays per-lane table rows and per-lane Philox counters: +6 % at 2 lanes, +11 % at 8, +26...33 % from
+//     (the date-parallel form pays per-lane table rows and per-lane Philox counters: +6 % at 2 lanes, +11 % at 8, +19...22 % from
 //     16 on at 1e6 fp64 paths);
 //   * everything else keeps one lane per path.
 // `forced_lanes`: 0 = this rule, 1 = one lane per path always, 2 ... 64 = the whole call date-parallel with that many lanes

@@ -21,7 +21,7 @@ constexpr int DPP_ROW_MIRROR = 0x140;      // lane i <- lane 15-i within each ro
 constexpr int DPP_ROW_BCAST15 = 0x142;     // lane 15 of a row -> every lane of the next row
 constexpr int DPP_ROW_BCAST31 = 0x143;     // lane 31 -> every lane of rows 2,3
 
-template <int CTRL, int ROW_MASK>
+template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ double dpp_fetch(double v)
 {
     // a 64-bit value moves as two 32-bit DPP movs; lanes whose row is masked off (or whose
