@@ -81,7 +81,7 @@ def test_bench_contract_single_gpu(tmp_path):
     assert abs(d["price"] - BS) < 3.5 / 1.96 * d["confidence_95"]
     r = d["roofline"]
     assert r["achieved"] == pytest.approx(15.5 * 1e8 / (r["avg_kernel_us"] * 1e-6) / 1e12, rel=1e-9)
-    assert lr["achieved"] == pytest.approx(r["achieved"], rel=1e-5) and lr["avg_kernel_us"] == pytest.approx(r["avg_kernel_us"], rel=1e-5)
+    assert lr["achieved"] == pytest.approx(r["achieved"], rel=1e-4) and lr["avg_kernel_us"] == pytest.approx(r["avg_kernel_us"], rel=1e-4)
     # the per-launch duration is the kernel alone on the device (50 launches one at a time), never above the step
     # period by more than the launch gap; the in-region samples (every launch of a short run) are kept for the record
     assert r["kernel_samples"] == 50 and r["duration_basis"].startswith("exclusive")
@@ -94,7 +94,7 @@ def test_bench_contract_single_gpu(tmp_path):
     elif "issue_frac" in r:    # a CEILING now: the cheapest measured cost of every opcode of the hot loop -- never above 1, on the step period either
         assert 0.5 < r["issue_frac"] <= 1.0 and r["issue_model"]["frac_effective"] <= 1.0
         assert r["issue_model"]["ceiling_us"] <= r["issue_model"]["typical_us"]
-        assert lr["issue_frac"] == pytest.approx(r["issue_frac"], rel=1e-5)
+        assert lr["issue_frac"] == pytest.approx(r["issue_frac"], rel=1e-4)
     else:
         assert "issue_model_withheld" in r
     assert r["grid_workgroups"] == 2048 and len(r["launch_stamp"]) == 16
