@@ -426,8 +426,8 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     const auto wall0 = std::chrono::steady_clock::now();
     InFlight fl(m);
     bool direct = !m->timing && !m->readback_copy;
-    // per-device scratch of the call on the stack (mc_multi_create admits at most 64 devices): no allocation between the
-    // call's entry and the first launch
+    // per-device scratch of the call in the handle (mc_multi_create admits at most 64 devices): no allocation between the
+    // call's entry and the first launch, and nothing a late launcher thread could touch lives on this stack frame
     const volatile double **slot = m->slot_storage;   // [G] = the all-reduced triple's slot
     for (int g = 0; g <= G; ++g)
         slot[g] = nullptr;
@@ -480,8 +480,8 @@ static int run_sharded(mc_multi *m, uint64_t first, uint64_t n, double discount,
     if (m->crew) {
         if (m->crew->run_all(device_part, &job, rcs, wall0, at_ns, seen_ns) > 0) {
             // Bounded wait (mc_multi.h): a launcher thread claimed its device's launch and has not come back.  Nothing can be
-            // drained (the same runtime call would be waited for), the slots on this stack frame must not be written through any
-            // more -- direct delivery of THIS call is abandoned by leaving the device side alone -- and the handle stays broken.
+            // drained (the same runtime call would be waited for); whatever the other devices still deliver lands in pinned slots
+            // the handle keeps alive (it is leaked on destroy), and the handle stays broken.
             fl.touched = 0;
             for (int g = 0; g < G; ++g)
                 if (rcs[(size_t)g] == mc_host::LaunchCrew::TIMED_OUT)
