@@ -190,3 +190,34 @@ def test_compact_line_of_an_n_rank_strong_run_explains_itself():
         assert set(e) >= {"wall_ms_median", "paths_per_gpu", "t_shard_ms", "collective_ms", "t1_ms_rank0", "eff", "eff_device_side"}
         assert e["eff"] < e["eff_device_side"] <= 1.0 and e["t_shard_ms"][0] <= e["t_shard_ms"][1]
         assert e["wall_ms_median"] == pytest.approx(e["t_shard_ms"][1] + e["collective_ms"], rel=1e-3)
+
+
+def test_scale_report_reads_the_lines_of_one_and_eight_ranks():
+    """tools/scale_report.py on a 1-rank and an 8-rank line: weak efficiency from the values, strong efficiency of every config from the
+    N = 1 line's T(1), and the N-rank line's own decomposition next to it."""
+    import io
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import scale_report
+    d = _fixture6()
+    one = bench.compact_line(d, "bench_detail.json")
+    d8 = copy.deepcopy(d)
+    d8["n_gpus"], d8["value"] = 8, 7.6 * d["value"]
+    for k in ("cpu_baseline", "cpu_all_cores", "c_multi", "configs"):
+        d8.pop(k, None)
+    d8["strong"]["shard_rows"] = []
+    for r in d8["strong"]["rows"]:
+        t1 = r["wall_ms_median"]
+        r["paths_per_gpu"] = r["paths_total"] // 8
+        r.update(t_shard_ms=[t1 / 8 * 0.99, t1 / 8 * 1.01], collective_ms=0.041, t1_ms_rank0=t1, eff=t1 / (8 * (t1 / 8 * 1.01 + 0.041)),
+                 eff_device_side=1 / 1.01, wall_ms_median=t1 / 8 * 1.01 + 0.041)
+    d8["strong"]["allreduce_us"] = {"median": 38.1, "p10": 35.0, "p90": 45.0, "calls": 200}
+    d8.update(world_size=8, backend="nccl", ranks=[{"rank": i, "device": i, "pci": "0000:%02x:00.0" % (5 + 16 * i), "host": "node"} for i in range(8)])
+    out = io.StringIO()
+    scale_report.report([one, bench.compact_line(d8, "bench_detail.json")], out)
+    text = out.getvalue()
+    assert " 8 " in text and "0.9500" in text and "nccl / 8" in text                 # weak efficiency 7.6 / 8
+    c5 = next(line for line in text.splitlines() if line.startswith("C5 "))
+    t1 = next(r["wall_ms_median"] for r in d["strong"]["rows"] if r["config"] == "C5")
+    assert f"{t1 / (8 * (t1 / 8 * 1.01 + 0.041)):.4f}" in c5 and "0.9901" in c5 and "38.1000" in c5
+    assert "C5x10" in text and "cold" in text
