@@ -129,7 +129,7 @@ struct GenGridStream {
                 out[j] = block * (uint32_t)N + (uint32_t)j < w.ext_per_unit ? (Real)z.next() : (Real)0;
         }
     }
-    struct Carry {};
+    struct Carry { const F64K *K = nullptr; };
     __device__ __forceinline__ void pair(const Work &w, uint32_t, uint32_t, uint32_t P, Carry &, double &z0, double &z1)
     {
         z0 = 2u * P < w.ext_per_unit ? (double)z.next() : 0.0;

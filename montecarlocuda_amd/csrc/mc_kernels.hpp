@@ -1334,7 +1334,13 @@ __device__ __forceinline__ double cva_path(Gen &gen, const CvaArgs<double> &o, c
     double W = 0, acc = 0;
     const int n_dates = o.n_bs + o.last_intrinsic;
     const double bx_v = to_vgpr(o.bx);   // in a vector register for the whole path: ln s = fma(W, bx, xk_j) then reads ONE scalar (xk_j)
+    // the polynomial coefficients of the pair's Box-Muller as opaque vector registers: one three-operand v_fma_f64 per Horner step
+    // instead of hipcc's v_mov + v_fmac (mc_math_f64.hpp: F64K; 9 of the 225 instructions per two dates -- the exponentials and
+    // Hastings tails of the exposure gain nothing from the same treatment and stay on literals)
+    F64K K;
+    K.load();
     typename Gen::Carry carry;
+    carry.K = &K;
 #pragma unroll 1
     for (int j = 0; j < n_dates; j += 2) {
         double z0, z1;

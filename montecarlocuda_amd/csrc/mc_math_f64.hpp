@@ -162,4 +162,71 @@ __device__ __forceinline__ void sincos_turns_tab(uint32_t lo, uint32_t hi, doubl
     cos_out = __builtin_fma(-e.x, sb, __builtin_fma(e.y, cm, e.y));
 }
 
+
+// ---- the same functions on REGISTER-RESIDENT constants ------------------------------------------------------------
+// For a kernel whose scalar register file is full (the CVA date loop: two table rows, the Philox key schedule, ...) hipcc keeps the
+// polynomial coefficients in vector registers, shares the equal halves of different coefficients (1/192, 1/12, 1/6, 1/24 all end in
+// 0x55555555) and re-assembles a register pair before every use that needs the coefficient as the ADDEND of a two-address v_fmac_f64:
+// v_mov_b32 + v_mov_b64 + v_fmac_f64 for one Horner step.  28 of the 225 VALU instructions per two fp64 CVA dates were such moves.
+// F64K holds the coefficients that appear as addends (and the first-step multipliers next to them) as OPAQUE 64-bit vector registers
+// (an empty asm the compiler cannot see through, executed once per kernel) and fma3() is ONE three-operand v_fma_f64 on them.  Same
+// operations in the same order as the functions above: bit-identical results (tests/test_gpu_parity.py compares both with the oracle,
+// tests/test_gpu_cva_dates.py the two kernels with each other).  Only the Box-Muller pieces: the exponentials and Hastings tails of the
+// CVA exposure showed no gain from the same treatment (their remaining moves are table rows coming from scalar registers).
+__device__ __forceinline__ double k_vgpr(double x)
+{
+    asm("" : "+v"(x));
+    return x;
+}
+__device__ __forceinline__ double fma3(double a, double b, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+struct F64K {
+    double l448, l192, l80, l32, l12, lk;          // -2 ln u
+    double s2pi53, s120, sm6, sm720, s24;          // sincos
+    __device__ __forceinline__ void load()
+    {
+        l448 = k_vgpr(1.0 / 448), l192 = k_vgpr(1.0 / 192), l80 = k_vgpr(1.0 / 80), l32 = k_vgpr(1.0 / 32), l12 = k_vgpr(1.0 / 12);
+        lk = k_vgpr(-1.3862943611198906188);
+        s2pi53 = k_vgpr(6.283185307179586477 * 0x1p-53), s120 = k_vgpr(1.0 / 120), sm6 = k_vgpr(-1.0 / 6), sm720 = k_vgpr(-1.0 / 720), s24 = k_vgpr(1.0 / 24);
+    }
+};
+
+__device__ __forceinline__ double neg2log_unit_tab(double u, const F64K &K)
+{
+    const int h = __double2hiint(u) - 0x3fe6a09e;
+    const int k = h >> 20;
+    const double m = __hiloint2double(__double2hiint(u) - (k << 20), __double2loint(u));
+    const F64Pair e = f64_tables[(h >> 13) & 0x7f];
+    const double r = __builtin_fma(m, e.x, 2.0);
+    double p = fma3(r, K.l448, K.l192);
+    p = fma3(r, p, K.l80);
+    p = fma3(r, p, K.l32);
+    p = fma3(r, p, K.l12);
+    p = __builtin_fma(r, p, 0.25);
+    const double small = __builtin_fma(r * r, p, r);
+    const double big = fma3((double)k, K.lk, e.y);
+    return big + small;
+}
+
+__device__ __forceinline__ void sincos_turns_tab(uint32_t lo, uint32_t hi, const F64K &K, double &sin_out, double &cos_out)
+{
+    const F64Pair e = f64_tables[128 + (hi >> 24)];
+    const uint32_t mant_lo = __builtin_amdgcn_alignbit(hi, lo, 12);
+    const uint32_t mant_hi = ((hi >> 12) & 0xfffu) | 0x3ff00000u;
+    const double y = __hiloint2double((int)mant_hi, (int)mant_lo) - (1.0 + 0x1p-9);
+    const double b = fma3(y, 6.283185307179586477, K.s2pi53);
+    const double z = b * b;
+    const double ps = fma3(z, K.s120, K.sm6);
+    const double sb = __builtin_fma(z * b, ps, b);
+    double pc = fma3(z, K.sm720, K.s24);
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cm = z * pc;
+    sin_out = __builtin_fma(e.y, sb, __builtin_fma(e.x, cm, e.x));
+    cos_out = __builtin_fma(-e.x, sb, __builtin_fma(e.y, cm, e.y));
+}
+
 }  // namespace mc

@@ -150,6 +150,15 @@ __device__ __forceinline__ void pair_normals_f64(uint32_t a, uint32_t m, uint32_
 {
     box_muller_f64((u32x4){m, a, m << 20, c}, z_cos, z_sin);   // (lo, hi) of the radius, (lo, hi) of the angle
 }
+// the same pair on register-resident coefficients (mc_math_f64.hpp: F64K): same operations, same bits
+__device__ __forceinline__ void pair_normals_f64(uint32_t a, uint32_t m, uint32_t c, const F64K &K, double &z_cos, double &z_sin)
+{
+    const double radius = sqrt_pos(neg2log_unit_tab(u01_f64(m, a), K));
+    double s, co;
+    sincos_turns_tab(m << 20, c, K, s, co);
+    z_cos = radius * co;
+    z_sin = radius * s;
+}
 __device__ __forceinline__ void words_to_normals(const u32x4 r0, const u32x4 r1, const u32x4 r2, double (&out)[8])
 {
     pair_normals_f64(r0.x, r0.y, r0.z, out[0], out[1]);
@@ -233,7 +242,11 @@ struct GenPhilox {
     // order (the CVA date loop: pair P = dates 2P + 1, 2P + 2) and cannot afford eight normals and twelve words live at once.
     // P (wave-uniform) = 0, 1, 2, ... ; the words a Philox block yields beyond the current pair wait in `carry`:
     // pairs 4b .. 4b + 3 cost Philox blocks 3b, 3b + 1, 3b + 2 and nothing.
-    struct Carry { uint32_t c0, c1, c2; };
+    // `K`: the caller's register-resident coefficients (the CVA date loop binds them once per kernel), or nullptr for the literal forms
+    struct Carry {
+        uint32_t c0, c1, c2;
+        const F64K *K = nullptr;
+    };
     __device__ __forceinline__ void pair(const Work &w, uint32_t unit_lo, uint32_t domain, uint32_t P, Carry &k, double &z0, double &z1)
     {
         const uint32_t b3 = 3u * (P >> 2);
@@ -244,7 +257,10 @@ struct GenPhilox {
         case 2: { const u32x4 r = words(w, unit_lo, b3 + 2u, domain); a = k.c0, m = k.c1, c = r.x, k.c0 = r.y, k.c1 = r.z, k.c2 = r.w; break; }
         default: a = k.c0, m = k.c1, c = k.c2; break;
         }
-        pair_normals_f64(a, m, c, z0, z1);
+        if (k.K)   // compile-time after inlining: the caller either bound the coefficients or did not
+            pair_normals_f64(a, m, c, *k.K, z0, z1);
+        else
+            pair_normals_f64(a, m, c, z0, z1);
     }
     // after the last pair of a unit (`pairs` of them were drawn): nothing to do for a counter-based stream
     __device__ __forceinline__ void pairs_done(uint32_t) {}
@@ -286,7 +302,7 @@ struct GenXorwow {
         const u32x4 r0 = words(w, unit_lo, block, domain), r1 = words(w, unit_lo, block, domain), r2 = words(w, unit_lo, block, domain);
         words_to_normals(r0, r1, r2, z);
     }
-    struct Carry {};
+    struct Carry { const F64K *K = nullptr; };
     __device__ __forceinline__ void pair(const Work &, uint32_t, uint32_t, uint32_t, Carry &, double &z0, double &z1)
     {
         const uint32_t a = next(), m = next(), c = next();   // the next three words: twelve per four pairs, as normals() draws them
@@ -318,7 +334,7 @@ struct GenPhiloxF32N : GenPhilox {
     {
         words_to_normals(words(w, unit_lo, block, domain), z);
     }
-    struct Carry { float z2, z3; };
+    struct Carry { float z2, z3; const F64K *K = nullptr; };
     __device__ __forceinline__ void pair(const Work &w, uint32_t unit_lo, uint32_t domain, uint32_t P, Carry &k, double &z0, double &z1)
     {
         if ((P & 1u) == 0) {
@@ -346,7 +362,7 @@ struct GenExternal {
             z[j] = idx < w.ext_per_unit ? p[idx] : (Real)0;
         }
     }
-    struct Carry {};
+    struct Carry { const F64K *K = nullptr; };
     __device__ __forceinline__ void pair(const Work &w, uint32_t unit_lo, uint32_t, uint32_t P, Carry &, double &z0, double &z1)
     {
         const double *p = static_cast<const double *>(w.ext) + (size_t)(unit_lo - w.unit_lo) * w.ext_per_unit;
