@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void grid_normals_kernel(const uint32_t *__res
 template <bool WHOLE>
 struct GenGridStream {
     static constexpr bool external = true;   // values, not words: the kernels take their fma(z, b, a) paths
+    static constexpr int cursor_phases = 1;
     template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }
     XorwowNormalStream z;
     __device__ __forceinline__ explicit GenGridStream(const uint32_t *row) : z(row, GenXorwow::Row{}) {}

@@ -1325,9 +1325,12 @@ __device__ __forceinline__ float cva_path(Gen &gen, const CvaArgs<float> &o, con
     return acc * (ANTI ? o.lgd * 0.5f : o.lgd);
 }
 
-// fp64: one Box-Muller pair = two dates per trip, drawn through the generator's pair cursor (mc_rng.hpp): the fp64 stream
-// hands out eight normals per block, and a date loop unrolled over all eight keeps four pairs of table rows in SGPRs (they
-// spill into VGPR lanes) and eight normals in VGPRs -- 129 VGPRs, 3 waves per SIMD; one pair per trip stays at round 2's 77.
+// fp64: dates in Box-Muller pairs drawn through the generator's pair cursor (mc_rng.hpp): the fp64 stream hands out eight
+// normals per block, and a date loop that draws all eight at once keeps four pairs of table rows in SGPRs (they spill into
+// VGPR lanes) and eight normals in VGPRs.  The cursor draws one pair at a time; the loop runs FOUR pairs per trip with the
+// cursor's phase a compile-time constant in each copy (round 6: 793 vector instructions per eight dates instead of 4 x 216,
+// -3.4 % at C5's shard and -4.2 % at C5 in one process, profiles/r06_ab_cva_four_pairs.log; 129 VGPRs = 3 waves per SIMD,
+// and forcing 4 with amdgpu_waves_per_eu changes nothing), and one pair per trip for what is left of the grid.
 template <bool ANTI, class Gen>
 __device__ __forceinline__ double cva_path(Gen &gen, const CvaArgs<double> &o, const Work &w, uint32_t c0)
 {
@@ -1341,24 +1344,45 @@ __device__ __forceinline__ double cva_path(Gen &gen, const CvaArgs<double> &o, c
     K.load();
     typename Gen::Carry carry;
     carry.K = &K;
+    // dates j, j + 1 (both with a closed-form exposure) from one pair of normals
+    auto closed_pair = [&](int j, double z0, double z1) {
+        const CvaStep<double> sa = o.steps[j], sb = o.steps[j + 1];
+        const double W_a = W + z0, W_b = W_a + z1;
+        W = W_b;
+        double ee_a, ee_b;
+        bs_exposure2(fma_scalar_addend(W_a, bx_v, sa.xk), W_a, sa, fma_scalar_addend(W_b, bx_v, sb.xk), W_b, sb, ee_a, ee_b);
+        if (ANTI) {
+            double em_a, em_b;
+            bs_exposure2(fma_scalar_addend(-W_a, bx_v, sa.xk), -W_a, sa, fma_scalar_addend(-W_b, bx_v, sb.xk), -W_b, sb, em_a, em_b);
+            ee_a += em_a;
+            ee_b += em_b;
+        }
+        acc = fma_r(sa.dp, ee_a, acc);
+        acc = fma_r(sb.dp, ee_b, acc);
+    };
+    // FOUR pairs per trip while eight closed-form dates remain: P = 4g + {0, 1, 2, 3} makes the cursor's phase a compile-time
+    // constant in each of the four copies -- no four-way switch, and the carried words are plain values instead of loop-carried
+    // copies (the one-pair loop below spends 8 v_mov_b32 + 3 v_mov_b64 of its 216 instructions per trip on them).
+    // (the Philox cursors only: a sequential or external stream has no phase switch, and four copies cost it 13 to 90 VGPRs)
+    int j = 0;
+    if constexpr (Gen::cursor_phases > 1) {
 #pragma unroll 1
-    for (int j = 0; j < n_dates; j += 2) {
+        for (; j + 8 <= o.n_bs; j += 8) {
+            const uint32_t g4 = (uint32_t)(j >> 3) << 2;
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+                double z0, z1;
+                gen.pair(w, c0, 3u /*MC_DOMAIN_CVA*/, g4 | k, carry, z0, z1);
+                closed_pair(j + 2 * (int)k, z0, z1);
+            }
+        }
+    }
+#pragma unroll 1
+    for (; j < n_dates; j += 2) {
         double z0, z1;
         gen.pair(w, c0, 3u /*MC_DOMAIN_CVA*/, (uint32_t)(j >> 1), carry, z0, z1);
         if (j + 1 < o.n_bs) {  // wave-uniform: both dates of this pair have a closed-form exposure
-            const CvaStep<double> sa = o.steps[j], sb = o.steps[j + 1];
-            const double W_a = W + z0, W_b = W_a + z1;
-            W = W_b;
-            double ee_a, ee_b;
-            bs_exposure2(fma_scalar_addend(W_a, bx_v, sa.xk), W_a, sa, fma_scalar_addend(W_b, bx_v, sb.xk), W_b, sb, ee_a, ee_b);
-            if (ANTI) {
-                double em_a, em_b;
-                bs_exposure2(fma_scalar_addend(-W_a, bx_v, sa.xk), -W_a, sa, fma_scalar_addend(-W_b, bx_v, sb.xk), -W_b, sb, em_a, em_b);
-                ee_a += em_a;
-                ee_b += em_b;
-            }
-            acc = fma_r(sa.dp, ee_a, acc);
-            acc = fma_r(sb.dp, ee_b, acc);
+            closed_pair(j, z0, z1);
         } else {
             cva_single_date<double, ANTI>(o, j, n_dates, z0, W, acc);
             cva_single_date<double, ANTI>(o, j + 1, n_dates, z1, W, acc);

@@ -221,6 +221,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));  // one VGPR pair: v_pk_{f
 // Indices beyond a unit's count read as 0.
 struct GenPhilox {
     static constexpr bool external = false;
+    // the fp64 pair cursor below has a four-phase state: a date loop that draws FOUR pairs per trip makes the phase a compile-time
+    // constant (mc_kernels.hpp: cva_path<double>); a cursor without phases (cursor_phases = 1) only pays registers for it
+    static constexpr int cursor_phases = 4;
     template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }
     __device__ __forceinline__ explicit GenPhilox(const Work &) {}
     __device__ __forceinline__ u32x4 words(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain)
@@ -268,6 +271,7 @@ struct GenPhilox {
 
 struct GenXorwow {
     static constexpr bool external = false;
+    static constexpr int cursor_phases = 1;
     template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }
     uint32_t x0, x1, x2, x3, x4, d;
     __device__ __forceinline__ explicit GenXorwow(const uint32_t *states)
@@ -320,6 +324,7 @@ struct GenXorwow {
 };
 
 struct GenPhiloxF32N : GenPhilox {
+    static constexpr int cursor_phases = 2;   // one Philox block per two pairs
     template <class Real> static constexpr int npb() { return 4; }
     __device__ __forceinline__ explicit GenPhiloxF32N(const Work &w) : GenPhilox(w) {}
     __device__ __forceinline__ void normals(const Work &w, uint32_t unit_lo, uint32_t block, uint32_t domain, double (&z)[4])
@@ -350,6 +355,7 @@ struct GenPhiloxF32N : GenPhilox {
 
 struct GenExternal {
     static constexpr bool external = true;
+    static constexpr int cursor_phases = 1;
     template <class Real> static constexpr int npb() { return sizeof(Real) == 4 ? 4 : 8; }   // the native block sizes
     __device__ __forceinline__ explicit GenExternal(const Work &) {}
     template <class Real, int N>

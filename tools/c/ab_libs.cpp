@@ -1,7 +1,7 @@
 // ab_libs.cpp -- two builds of libmc_mi355x.so in ONE process on ONE box, alternating: box-to-box differences of +-3 % (clock state,
 // silicon) are larger than most kernel changes, so a variant is only believed when it wins here.
 //   hipcc -O2 -Iinclude tools/c/ab_libs.cpp -ldl -o tools/c/ab_libs
-//   tools/c/ab_libs <libA.so> <libB.so> [cva64|cva32|van64|bsk64] [paths] [rounds]
+//   tools/c/ab_libs <libA.so> <libB.so> [cva64|cva32|van64|bsk64] [paths] [rounds]      (AB_ANTITHETIC=1: the antithetic estimator)
 // Each round: 24 back-to-back launches of the workload through A, then through B (stream-event brackets per launch, median of the
 // round); prints the per-round medians and the ratio B / A of the medians over all rounds.
 #include <dlfcn.h>
@@ -35,7 +35,12 @@ static bool load(const char *path, Lib &l)
 #define SYM(f, n) l.f = (decltype(l.f))dlsym(l.h, n); if (!l.f) { fprintf(stderr, "%s: no %s\n", path, n); return false; }
     SYM(create, "mc_context_create") SYM(destroy, "mc_context_destroy") SYM(stream, "mc_context_stream") SYM(cva64, "mc_cva_launch_f64")
     SYM(cva32, "mc_cva_launch_f32") SYM(van64, "mc_vanilla_launch_f64") SYM(bsk64, "mc_basket_launch_f64") SYM(chol, "mc_chol_f64") SYM(err, "mc_last_error")
-    return l.create(0, 0, &l.ctx) == MC_OK;
+    if (l.create(0, 0, &l.ctx) != MC_OK) return false;
+    if (getenv("AB_ANTITHETIC")) {
+        auto set = (decltype(&mc_context_set_antithetic))dlsym(l.h, "mc_context_set_antithetic");
+        if (!set || set(l.ctx, 1) != MC_OK) return false;
+    }
+    return true;
 }
 
 int main(int argc, char **argv)
