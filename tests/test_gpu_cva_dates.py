@@ -17,8 +17,10 @@ pytestmark = pytest.mark.gpu
 SEED = 0x4D435F4D49333535
 CVA0 = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6)  # reference cvaOpt.cu:22-34
 TOL = {"f32": dict(cva=2e-5, rel=3e-6), "f64": dict(cva=1e-13, rel=1e-12)}
-LANES = [2, 4, 8, 16, 32, 64]
-GRIDS = [1, 2, 3, 25, 50, 75, 250, 256, 500]   # the reference driver's grids (cvaOpt.cu:70-75), 256 (BASELINE C5), tiny ones
+LANES = [1, 2, 4, 8, 16, 32, 64]   # 1 = cva_kernel itself (the default rule would run a call this small date-parallel)
+# the reference driver's grids (cvaOpt.cu:70-75), 256 (BASELINE C5), tiny ones, and grids either side of the eight-date trips of the
+# fp64 one-lane loop (cva_path<double>: four Box-Muller pairs per trip while eight closed-form dates remain) and of the 8-date chunks
+GRIDS = [1, 2, 3, 7, 8, 9, 10, 16, 17, 18, 24, 25, 50, 75, 250, 256, 500]
 
 
 def f64(a):
