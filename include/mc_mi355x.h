@@ -185,8 +185,9 @@ int mc_context_set_finish(mc_context *ctx, int fused);
 /* CVA: how many adjacent lanes share one path's dates (reference: one thread walks all N_GRID dates of its path,
  * dp/MonteCarloKernel.cu:241-262).  lanes == 0 (default): chosen per call from its size -- a large call keeps one lane per path
  * and hands only its last partial wave-trip (n mod 64 x 4 x CUs paths, when that is at most 60 % of a trip) to date-parallel
- * workgroups of the same launch; a small call (fp64: up to 2 wave-trips on a grid of 64 dates or more -- the reference driver's
- * own 131 072 paths, dp/cvaOpt.cu:12-15 -- up to 1 on a shorter grid; fp32: 1 and 1/4) runs date-parallel as a whole.  lanes == 1: never (the one-lane-per-path kernel only).  lanes == 2, 4, ... 64:
+ * workgroups of the same launch; a small call (up to 7/4 wave-trips on a grid of 64 dates or more, 3/4 of one on a shorter
+ * grid) runs date-parallel as a whole -- the reference driver's own 131 072 paths (dp/cvaOpt.cu:12-15) are two
+ * trips and keep one lane per path.  lanes == 1: never (the one-lane-per-path kernel only).  lanes == 2, 4, ... 64:
  * the whole call date-parallel with that many lanes per path (capped by the number of 8-date chunks of the grid).  The
  * estimate differs between settings only by the association of two sums per path (1e-16-level in fp64, 1e-7 in fp32);
  * XORWOW calls (one sequence per lane) and grids whose table exceeds 48 KB of LDS always use one lane per path.

@@ -108,7 +108,7 @@ static int basket_tiled_min()
 //   tail_paths   trailing paths, date-parallel (both > 0: one launch of cva_split_kernel; main_paths == 0: cva_dates_kernel)
 // The one-lane-per-path kernel's time is a staircase in steps of one WAVE-TRIP = 64 lanes x 4 SIMDs x CUs paths (65 536 on
 // MI355X): a launch pays for whole trips -- 1 250 000 paths (C5's shard of 8: 19.07 trips) cost what 1 310 720 do, 990.9 us against
-// 944.8 for 19 trips -- and a wave alone on its SIMD needs ~105 us (fp64; ~49 us fp32) for a 256-date path whatever the call's size.
+// 944.8 for 19 trips -- and a wave alone on its SIMD needs ~85 us (fp64; ~49 us fp32) for a 256-date path whatever the call's size.
 // Measured with tools/c/shard_clock and tools/cva_call_latency.py (profiles/r06_shard_clock_AD_fused_split.log,
 // profiles/r06_cva_call_latency.log):
 //   * a call of more than the small-call limit and at most 64 trips, on a grid of at least 64 dates, that ends in a partial trip
@@ -117,12 +117,13 @@ static int basket_tiled_min()
 //     shrinks to nothing as the remainder approaches a full trip: 0.31 of a trip -21.6 us, 0.45 -15.2, 0.53 -8.0; beyond 64 trips
 //     a trip is under 1.6 % of the call);
 //   * a SMALL call runs date-parallel as a whole, with lanes for ~4 waves per SIMD.  What "small" is depends on how long a
-//     lane's serial walk is and on how many waves the one-lane-per-path kernel keeps per SIMD (fp64: 6, fp32: 8):
-//         fp64, >= 64 dates: up to 2 trips   (256 dates, kernel time rounded to the us: 4096 paths 105 -> 16, 65 536: 107 -> 67, 131 072 --
-//                                             the reference driver's own call, dp/cvaOpt.cu:12-15 -- 130 -> 120; 196 608: a tie)
-//         fp64, <  64 dates: up to 1 trip    (25 dates: 16 384 paths 18 -> 11, 65 536: 19 -> 17; 131 072: 21 -> 26, worse)
-//         fp32, >= 64 dates: up to 1 trip    (256 dates: 4096 paths 49 -> 11, 65 536: 50 -> 36; 131 072: a tie)
-//         fp32, <  64 dates: up to 1/4 trip  (25 dates: 16 384 paths 11.5 -> 9.1; 65 536: 11.7 -> 12.1, worse)
+//     lane's serial walk is (the one-lane kernel's second wave on a SIMD costs it a third of the first: 256 dates fp64 85 us for
+//     one trip, 113 for two; fp32 49 and 59), in both precisions alike:
+//         >= 64 dates: up to 7/4 trips (256 dates, kernel time in us, fp64: 4096 paths 83 -> 15, 65 536: 84 -> 68, 98 304: 113 -> 95,
+//                                       114 688: 113 -> 108; 131 072 -- the reference driver's own call, dp/cvaOpt.cu:12-15 -- 113 -> 121,
+//                                       worse; fp32: 4096 paths 49 -> 11, 65 536: 49 -> 35, 98 304: 58 -> 48, 114 688: 59 -> 53, 131 072: a tie)
+//         <  64 dates: up to 3/4 trip  (25 dates, fp64: 16 384 paths 15.6 -> 11.6, 49 152: 16.2 -> 15.2; 65 536: 15.7 -> 17.2, worse;
+//                                       fp32: 16 384 paths 11.3 -> 8.9, 49 152: 11.6 -> 11.1; 65 536: 11.7 -> 12.2, worse)
 //     (the date-parallel form pays per-lane table rows and per-lane Philox counters: +6 % at 2 lanes, +11 % at 8, +19...22 % from
 //     16 on at 1e6 fp64 paths);
 //   * everything else keeps one lane per path.
@@ -141,7 +142,8 @@ static int cva_max_log2_lanes(int n_dates)
 static CvaPlan cva_plan(int forced_lanes, uint64_t n, int n_dates, int compute_units, bool dates_kernel_possible, size_t real_bytes)
 {
     constexpr int tail_max_pct = 60, small_fill = 4, split_max_trips = 64, long_grid = 64;
-    const int small_trips_x4 = real_bytes == 8 ? (n_dates >= long_grid ? 8 : 4) : (n_dates >= long_grid ? 4 : 1);   // quarter trips, inclusive
+    const int small_trips_x4 = n_dates >= long_grid ? 7 : 3;   // quarter trips, inclusive
+    (void)real_bytes;
     const int max_l = cva_max_log2_lanes(n_dates);
     CvaPlan p = {n, 0, 0};
     if (!dates_kernel_possible || max_l == 0 || forced_lanes == 1 || n == 0)

@@ -161,12 +161,13 @@ def test_split_call_main_beside_tail(mc, po, X):
 
 
 def test_small_call_runs_date_parallel_by_default(mc, po):
-    """The reference driver's own call (dp/cvaOpt.cu:12-15: 131 072 paths, 1024 blocks; grids 25 ... 500, :70-75): in fp64 on a grid of
-    64 dates or more the automatic rule prices it date-parallel as a whole (up to 2 wave-trips); on the 25-date grid, and in fp32,
-    131 072 paths keep one lane per path (measured slower otherwise: profiles/r06_cva_call_latency.log).  Same estimate either way."""
+    """The automatic rule (csrc/mc_launch_shape.hpp: cva_plan) prices a small call date-parallel as a whole: up to 7/4 wave-trips on a grid
+    of 64 dates or more and 3/4 of one on a shorter grid.  The reference driver's own call (dp/cvaOpt.cu:12-15: 131 072 paths = 2 trips;
+    grids 25 ... 500, :70-75) keeps one lane per path in both precisions (measured slower otherwise: profiles/r06_cva_call_latency.log).
+    Same estimate either way."""
     with mc.Engine(0) as e:
-        for X, n_grid, paths, parallel in (("f64", 250, 131072, True), ("f64", 25, 131072, False), ("f64", 25, 65536, True),
-                                           ("f32", 250, 131072, False), ("f32", 250, 65536, True), ("f32", 25, 65536, False), ("f32", 25, 16384, True)):
+        cases = ((250, 131072, False), (250, 114688, True), (25, 65536, False), (25, 49152, True))
+        for X, n_grid, paths, parallel in [(X, *k) for X in ("f64", "f32") for k in cases]:
             c = dict(CVA0, n_grid=n_grid)
             e.set_cva_date_lanes(0)
             auto = e.cva(c, paths, SEED, 0, X)

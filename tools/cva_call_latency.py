@@ -2,7 +2,7 @@
 """Wall time of the reference CVA driver's own call -- 131 072 paths (dp/cvaOpt.cu:12-15), grids 25 ... 500 (:70-75) and BASELINE's 256 --
 as ONE synchronous mc_cva_run_* (what dev_cvaEquityOption does), timing off (pinned-slot read-back), back to back, median of 300 after
 30 warm-ups: one lane per path (mc_context_set_cva_date_lanes(ctx, 1): round 5's only form) against the default rule, which prices a
-call below 2.5 wave-trips date-parallel (csrc/mc_launch_shape.hpp: cva_plan).  Also the same for C5's shard of 8 (1 250 000 paths).
+small call date-parallel (fp64: up to 7/4 wave-trips; csrc/mc_launch_shape.hpp: cva_plan).  Also the same for C5's shard of 8 (1 250 000 paths).
 
     python tools/cva_call_latency.py > profiles/r06_cva_call_latency.log      # on the GPU box
 """
@@ -42,7 +42,7 @@ print(f"{'paths':>9} {'dates':>6} {'X':>4} | " + " ".join(f"{'L=' + str(l):>8}" 
 eng.set_timing(True)
 for X in ("f64", "f32"):
     for n_grid in (25, 256):
-        for paths in (4096, 16384, 65536, 131072, 196608, 262144):
+        for paths in (4096, 16384, 49152, 65536, 98304, 114688, 131072, 196608, 262144):
             c = dict(bench.CVA, n_grid=n_grid)
             cells = []
             for lanes in (1, 2, 4, 8, 16, 32, 0):

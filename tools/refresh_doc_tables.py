@@ -99,11 +99,14 @@ for label, key, r05 in (("| C4 basket n=16 fp64, 1e9 paths |", "C4", ("27.9101, 
     d = "\n".join((f"{label} " + " | ".join(cells) + " |") if ln.startswith(label) else ln for ln in d.split("\n"))
 # ---- small calls (one synchronous call, 256 dates fp64; kernel times of forced lane counts)
 lat = open(os.path.join(P, f"{TAG}_cva_call_latency.log")).read()
-m = re.search(r"^\s+131072\s+256\s+f64 \|\s+(\S+)\s+(\S+)", lat, re.M)
-k64 = re.search(r"^\s+4096\s+256\s+f64 \|\s+(\S+)(?:\s+\S+){5} \| (\S+)", lat, re.M)
-k32 = re.search(r"^\s+65536\s+256\s+f32 \|\s+(\S+)\s+\S+\s+(\S+)", lat, re.M)
-d = sub(r"256 dates fp64: [0-9.]+ µs one lane per path, [0-9.]+ µs by the default rule; 4096 paths: [0-9.]+ → [0-9.]+ µs of",
-        f"256 dates fp64: {m.group(1)} µs one lane per path, {m.group(2)} µs by the default rule; 4096 paths: {k64.group(1)} → {k64.group(2)} µs of", d)
+forced = lat[lat.index("forced lane counts"):]
+k64 = re.search(r"^\s+4096\s+256\s+f64 \|\s+(\S+)(?:\s+\S+){5} \| (\S+)", forced, re.M)
+t64 = re.search(r"^\s+65536\s+256\s+f64 \|\s+(\S+)(?:\s+\S+){5} \| (\S+)", forced, re.M)
+own = re.search(r"^\s+131072\s+256\s+f64 \|\s+(\S+)\s+\S+\s+(\S+)", forced, re.M)   # L = 1 and L = 4
+k32 = re.search(r"^\s+65536\s+256\s+f32 \|\s+(\S+)\s+\S+\s+(\S+)", forced, re.M)
+d = sub(r"4096 paths: [0-9.]+ → [0-9.]+ µs, 65 536 paths: [0-9.]+ → [0-9.]+ µs\.",
+        f"4096 paths: {k64.group(1)} → {k64.group(2)} µs, 65 536 paths: {t64.group(1)} → {t64.group(2)} µs.", d)
+d = sub(r"keeps one lane per path \([0-9.]+ µs against [0-9.]+ µs on 4 lanes\)", f"keeps one lane per path ({own.group(1)} µs against {own.group(2)} µs on 4 lanes)", d)
 d = sub(r"\(65 536 paths: [0-9.]+ → [0-9.]+ µs\)", f"(65 536 paths: {k32.group(1)} → {k32.group(2)} µs)", d)
 # ---- secondary estimators
 sec = json.load(open(os.path.join(P, f"{TAG}_bench_secondary_estimators.json")))["workloads"]
