@@ -9,6 +9,13 @@ export TMPDIR=/tmp
 set -e -o pipefail
 mkdir -p $O
 step() { echo "== $1 $(date +%T)"; }
+# the issue ceilings of every bench line come from profiles/issue_model.json: stale (stamp of another code object) means lines without them
+python3 - <<'P' || { echo "profiles/issue_model.json or pmc_traffic.json is stale: collect_pmc_all.sh, then make asm + tools/issue_model.py in the container, THEN this"; exit 3; }
+import json, sys, bench
+s = bench.launch_stamp()["stamp"]
+m = json.load(open("profiles/issue_model.json")); p = json.load(open("profiles/pmc_traffic.json"))
+sys.exit(0 if m["vanilla_f32"]["launch_stamp"] == s and p["vanilla_f32"]["launch_stamp"] == s else 1)
+P
 # every bench run: the ONE stdout line (<= 4 KB) into the .log, the full record next to it (--detail-file)
 step "bench default";       python3 bench.py --detail-file $O/${TAG}_bench_detail_default.json > $O/${TAG}_bench_default.log 2>&1
 step "bench detail full";   python3 bench.py --detail full --detail-file $O/${TAG}_bench_detail_full.json > $O/${TAG}_bench_full.log 2>&1
