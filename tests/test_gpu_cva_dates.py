@@ -83,7 +83,7 @@ def test_grid_stride_and_range_position(eng, po, X):
 @pytest.mark.parametrize("X", ["f32", "f64"])
 def test_antithetic_and_other_inputs(eng, po, X):
     c = dict(s=90.0, k=100.0, r=0.01, v=0.4, t=2.0, defint=0.1, lgd=0.45, n_grid=37)
-    for lanes in (2, 8):
+    for lanes in (1, 2, 8):   # 1: cva_kernel's own antithetic instantiation (a call this small would otherwise never reach it)
         eng.set_cva_date_lanes(lanes)
         eng.set_antithetic(False)
         got = f64(eng.cva_paths(c, 4000, 5, 0, X))
