@@ -1653,6 +1653,7 @@ static int cva_table_ready(mc_context *c, const typename CvaIn<Real>::type *v, h
     memcpy(blob.data() + step_reals + pair_reals, extra.data(), extra.size() * sizeof(Real));
     if (int rc = upload_table(c, st, key, blob.data(), blob.size() * sizeof(Real))) return rc;
     args.pairs = nullptr;
+    args.pairs_in_lds = 0;   // set per launch (cva_enqueue)
     if constexpr (sizeof(Real) == 4)
         args.pairs = (const float *)c->d_table + step_reals;
     args.extra = (const Real *)c->d_table + step_reals + pair_reals;
@@ -1723,7 +1724,12 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         if (int rc = xorwow_one_segment(segs)) return rc;
         if (int rc = xorwow_ready(c, seed, st)) return rc;
     }
+    // fp32, one lane per path: the date pairs' rows through LDS instead of scalar registers (mc_kernels.hpp: cva_path<float>) while the copy
+    // leaves the kernel its eight waves per SIMD (16 KB = 341 date pairs; a split launch already carries the whole table's LDS)
+    const size_t pairs_lds = sizeof(Real) == 4 ? (size_t)48 * (size_t)(args.n_bs / 2) : 0;
+    const bool pairs_fit = pairs_lds > 0 && pairs_lds <= 16 * 1024 && !c->antithetic;   // (the antithetic instantiation does not take them)
     if (fused_split) {
+        args.pairs_in_lds = pairs_lds > 0;
         const Work w = context_work(c, seed, segs[0], 0, 0), wt = context_work(c, seed, tail_segs[0], 0, 0);
         const int g_tail = grid_for_cva_dates(c->blocks, tail_segs[0].count, plan.log2_lanes);
         Real *dst = out, *dst_tail = out ? out + segs[0].count : (Real *)nullptr;
@@ -1735,6 +1741,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
             return rc;
         return finish_call(c, t, total, st);
     }
+    args.pairs_in_lds = pairs_fit;
     for (const Segment &s : segs) {
         const Work w = context_work(c, seed, s, 0, 0);
         const int g = grid_for(c->blocks, s.count, scale);
@@ -1742,7 +1749,7 @@ static int cva_enqueue(mc_context *c, const typename CvaIn<Real>::type *v, uint6
         Real *dst = out ? out + done : (Real *)nullptr;
         constexpr unsigned ALLOW = GEN_PHILOX | GEN_XORWOW | GEN_EXTERNAL | (sizeof(Real) == 8 ? GEN_F32N : 0);
         if (int rc = with_anti_gen<ALLOW>(c->antithetic, gen_of(c, w, sizeof(Real)), [&](auto a, auto tag) {
-                launch_sim(prof, cva_kernel<Real, decltype(a)::value, typename decltype(tag)::type>, g, st, t, args, w, dst);
+                launch_sim_lds(prof, cva_kernel<Real, decltype(a)::value, typename decltype(tag)::type>, g, pairs_fit ? pairs_lds : 0, st, t, args, w, dst);
             }))
             return rc;
         slot += g;

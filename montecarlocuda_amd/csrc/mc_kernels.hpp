@@ -1096,6 +1096,7 @@ struct CvaArgs {
     Real bx;                     // v sqrt(dt) (times log2 e in f32)
     Real lgd, strike;
     const Real *extra;           // Greeks only: sqrt(tau_j) for every date, then sigma t_j for every date (2 (n_bs + last_intrinsic) reals)
+    int pairs_in_lds;            // fp32 one-lane-per-path loop: the launch carries dynamic LDS for `pairs` (host: cva_enqueue), rows come as ds_read_b128
 };
 
 // Black-Scholes exposure at one date, from the lane's state W and the date's table row.
@@ -1290,8 +1291,14 @@ __device__ __forceinline__ void cva_single_date(const CvaArgs<Real> &o, int j, i
 }
 
 // fp32: a block of four normals = two packed date pairs per trip of the date loop.
+__device__ __forceinline__ f2 exposure_pair_rows(float bx, f2 Wp, const float (&row)[12]);   // below, next to the date-parallel role that shares it
+// `lds_pairs`: the workgroup's LDS copy of o.pairs, or nullptr.  From scalar registers a pair's row costs six v_mov_b32 per pair (a
+// packed fma takes ONE scalar operand, so every addend and second factor is copied into vector registers first: 12 of the 169
+// instructions per four dates); from LDS the twelve floats arrive in vector registers as three ds_read_b128 at a wave-uniform
+// address, which issue beside the VALU (44 instead of 49 vector instructions per pair; -2.5 % at 19 trips, -2.3 % at 1e7 paths in one
+// process: profiles/r06_ab_cva_f32_rows_in_lds.log).  Same operations on the same values either way.
 template <bool ANTI, class Gen>
-__device__ __forceinline__ float cva_path(Gen &gen, const CvaArgs<float> &o, const Work &w, uint32_t c0)
+__device__ __forceinline__ float cva_path(Gen &gen, const CvaArgs<float> &o, const Work &w, uint32_t c0, const float *lds_pairs = nullptr)
 {
     constexpr int NPB = Gen::template npb<float>();
     static_assert(NPB == 4, "two packed date pairs per block");
@@ -1307,14 +1314,28 @@ __device__ __forceinline__ float cva_path(Gen &gen, const CvaArgs<float> &o, con
             if (j + 1 < o.n_bs) {  // wave-uniform: both dates of this pair have a closed-form exposure
                 // the pair's rows once more, field by field ({g, g'} ... {dp, dp'} adjacent: mc_api.hip), so the two dates
                 // ride in the halves of every packed instruction (-8 % against packing d1, d2 of one date)
-                const float *row = o.pairs + 12 * (j / 2);
                 const f2 Wp = {W + z[2 * h], (W + z[2 * h]) + z[2 * h + 1]};
                 W = Wp.y;
-                const f2 bx = {o.bx, o.bx}, xk = {row[6], row[7]}, dp = {row[10], row[11]};
-                f2 ee = bs_exposure_dates(pk_fma(Wp, bx, xk), Wp, row);
-                if (ANTI)
-                    ee += bs_exposure_dates(pk_fma(-Wp, bx, xk), -Wp, row);
-                acc2 = pk_fma(dp, ee, acc2);
+                if (lds_pairs) {   // wave-uniform
+                    float row[12];
+                    const float4 *src = reinterpret_cast<const float4 *>(lds_pairs + 12 * (j / 2));
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const float4 v = src[q];
+                        row[4 * q] = v.x, row[4 * q + 1] = v.y, row[4 * q + 2] = v.z, row[4 * q + 3] = v.w;
+                    }
+                    f2 ee = exposure_pair_rows(o.bx, Wp, row);
+                    if (ANTI)
+                        ee += exposure_pair_rows(o.bx, -Wp, row);
+                    acc2 = pk_fma((f2){row[10], row[11]}, ee, acc2);
+                } else {
+                    const float *row = o.pairs + 12 * (j / 2);
+                    const f2 bx = {o.bx, o.bx}, xk = {row[6], row[7]}, dp = {row[10], row[11]};
+                    f2 ee = bs_exposure_dates(pk_fma(Wp, bx, xk), Wp, row);
+                    if (ANTI)
+                        ee += bs_exposure_dates(pk_fma(-Wp, bx, xk), -Wp, row);
+                    acc2 = pk_fma(dp, ee, acc2);
+                }
             } else {
                 cva_single_date<float, ANTI>(o, j, n_dates, z[2 * h], W, acc);
                 cva_single_date<float, ANTI>(o, j + 1, n_dates, z[2 * h + 1], W, acc);
@@ -1394,15 +1415,30 @@ __device__ __forceinline__ double cva_path(Gen &gen, const CvaArgs<double> &o, c
 
 // one lane per path, grid-stride over the segment's paths: workgroup `block` of `n_blocks` (the whole grid for cva_kernel, the
 // main part of it for cva_split_kernel)
+// `lds_raw`: the launch's dynamic LDS.  fp32 with o.pairs_in_lds: the pair rows are staged there once per workgroup (all threads; a barrier)
 template <class Real, bool ANTI, class Gen>
 __device__ __forceinline__ void cva_paths_role(const CvaArgs<Real> &o, const Work &w, Real *__restrict__ out, uint32_t block, uint32_t n_blocks,
-                                               double &acc_s, double &acc_q)
+                                               unsigned char *lds_raw, double &acc_s, double &acc_q)
 {
     const uint32_t stride = n_blocks * GROUP;
     const uint32_t gtid = block * GROUP + threadIdx.x;
+    [[maybe_unused]] const float *lds_pairs = nullptr;
+    if constexpr (sizeof(Real) == 4 && !ANTI) {   // (the antithetic form holds a row across two exposures: measured 0.5 % slower from LDS)
+        if (o.pairs_in_lds) {   // uniform over the launch
+            float *dst = reinterpret_cast<float *>(lds_raw);
+            for (int k = threadIdx.x; k < 12 * (o.n_bs / 2); k += GROUP)
+                dst[k] = o.pairs[k];
+            __syncthreads();
+            lds_pairs = dst;
+        }
+    }
     Gen gen(w);
     for (uint32_t i = gtid; i < w.n_units; i += stride) {
-        const Real p = cva_path<ANTI>(gen, o, w, w.unit_lo + i);
+        Real p;
+        if constexpr (sizeof(Real) == 4 && !ANTI)
+            p = cva_path<ANTI>(gen, o, w, w.unit_lo + i, lds_pairs);
+        else
+            p = cva_path<ANTI>(gen, o, w, w.unit_lo + i);
         acc_s += (double)p;
         acc_q = __builtin_fma((double)p, (double)p, acc_q);
         if (out)  // wave-uniform: per-path dump for the parity tests
@@ -1414,8 +1450,9 @@ template <class Real, bool ANTI, class Gen = GenPhilox>
 __global__ __launch_bounds__(GROUP) void cva_kernel(const Tail /* first argument, read late: mc_reduce.hpp */, const CvaArgs<Real> o, const Work w, Real *__restrict__ out)
 {
     stage_tables<Real>();
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     double acc_s = 0.0, acc_q = 0.0;
-    cva_paths_role<Real, ANTI, Gen>(o, w, out, blockIdx.x, gridDim.x, acc_s, acc_q);
+    cva_paths_role<Real, ANTI, Gen>(o, w, out, blockIdx.x, gridDim.x, lds_raw, acc_s, acc_q);
     group_sum2(acc_s, acc_q);
     finish_group(acc_s, acc_q);
 }
@@ -1668,7 +1705,7 @@ __global__ __launch_bounds__(GROUP) void cva_split_kernel(const Tail /* first ar
     if (blockIdx.x < tail_groups)   // workgroup-uniform
         cva_dates_role<Real, CH, false, Gen>(o, wt, log2_lanes, out_tail, blockIdx.x, tail_groups, lds_raw, acc_s, acc_q);
     else
-        cva_paths_role<Real, false, Gen>(o, w, out, blockIdx.x - tail_groups, gridDim.x - tail_groups, acc_s, acc_q);
+        cva_paths_role<Real, false, Gen>(o, w, out, blockIdx.x - tail_groups, gridDim.x - tail_groups, lds_raw, acc_s, acc_q);
     group_sum2(acc_s, acc_q);
     finish_group(acc_s, acc_q);
 }

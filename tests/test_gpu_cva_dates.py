@@ -19,8 +19,9 @@ CVA0 = dict(s=100.0, k=100.0, r=0.05, v=0.2, t=1.0, defint=0.03, lgd=0.6)  # ref
 TOL = {"f32": dict(cva=2e-5, rel=3e-6), "f64": dict(cva=1e-13, rel=1e-12)}
 LANES = [1, 2, 4, 8, 16, 32, 64]   # 1 = cva_kernel itself (the default rule would run a call this small date-parallel)
 # the reference driver's grids (cvaOpt.cu:70-75), 256 (BASELINE C5), tiny ones, and grids either side of the eight-date trips of the
-# fp64 one-lane loop (cva_path<double>: four Box-Muller pairs per trip while eight closed-form dates remain) and of the 8-date chunks
-GRIDS = [1, 2, 3, 7, 8, 9, 10, 16, 17, 18, 24, 25, 50, 75, 250, 256, 500]
+# fp64 one-lane loop (cva_path<double>: four Box-Muller pairs per trip while eight closed-form dates remain) and of the 8-date chunks;
+# 700: the fp32 one-lane loop takes its pair rows from scalar registers there (above 16 KB of them), from LDS on every smaller grid
+GRIDS = [1, 2, 3, 7, 8, 9, 10, 16, 17, 18, 24, 25, 50, 75, 250, 256, 500, 700]
 
 
 def f64(a):

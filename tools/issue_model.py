@@ -199,7 +199,7 @@ WORKLOADS = {
     "basket16_f64_n32": spec("basket_tiled_kernelIdLi16ELb0ENS_13GenPhiloxF32NEEE", units=1, rules=[DUMP]),
     "cva256_f64": spec("cva_kernelIdLb0ENS_9GenPhiloxEEE", dates_per_trip=8),
     "cva256_f64_n32": spec("cva_kernelIdLb0ENS_13GenPhiloxF32NEEE", dates_per_trip=8),
-    "cva256_f32": spec("cva_kernelIfLb0ENS_9GenPhiloxEEE", dates_per_trip=4),
+    "cva256_f32": spec("cva_kernelIfLb0ENS_9GenPhiloxEEE", dates_per_trip=4, note="lds_rows"),
     # secondary estimators (no performance record): antithetic = the ANTI instantiation of the same kernel (a unit is a
     # mirrored pair), control variate = the plain instantiation with its wave-uniform `cv` branches taken
     "vanilla_f32_anti": spec("vanilla_f32_kernelILb1ENS_9GenPhiloxEEE", units=4, rules=[flush(8)]),
@@ -313,6 +313,10 @@ def main():
             elif is_single(ops) and not cv_on:
                 weight[nm], why[nm] = 0.0, ("single-date path (cva_single_date): a grid of 256 closed-form dates never enters it" if is_cva
                                             else "control variate: off in the bench's plain estimator")
+            elif sp.get("note") == "lds_rows" and n(ops, r"^v_rcp_f32") >= 4 and n(ops, r"^ds_read") == 0:
+                # cva_path<float> holds both forms of the packed date pair behind a launch-uniform branch: rows from LDS (three ds_read_b128)
+                # or from scalar registers (grids whose pair rows exceed 16 KB); the bench grid of 256 dates takes the first
+                weight[nm], why[nm] = 0.0, "date pair on scalar-register rows: this launch carries the rows in LDS (mc_api.hip: pairs_fit)"
             elif periodic(ops):
                 weight[nm], why[nm] = 1.0 / 8, "fp32 partial sums flushed to fp64 every 8th trip"
             elif is_cva and bk["depth"] < inner_depth and n(ops, PHILOX) < 8:
