@@ -228,3 +228,47 @@ def test_committed_issue_model_and_pmc_counts_describe_one_build():
     if live not in stamps:
         print("NOTE: the committed counters describe another build than the one in the tree (bench.py will flag traffic_stale): "
               "re-run tools/collect_pmc_all.sh and tools/issue_model.py on a GPU box")
+
+
+def test_cva_plan_rule_table(tmp_path):
+    """csrc/mc_launch_shape.hpp: cva_plan, the cut between one lane per path and the date-parallel form of a CVA call, as a pure host
+    function (hipcc, host code only, nothing launched): small calls whole (up to 7/4 wave-trips on a grid of 64 dates or more, 3/4 on a
+    shorter one), the last partial trip of a call of up to 64 trips when it is at most 60 % of a trip, nothing on grids that fit one 8-date
+    chunk, and the forced settings.  The GPU twin of this table is tests/test_gpu_cva_dates.py::test_small_call_runs_date_parallel_by_default."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not found")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "cva_plan_check"
+    subprocess.check_call([hipcc, "-O1", "-std=c++17", "--offload-arch=gfx950", "-I", os.path.join(root, "montecarlocuda_amd", "csrc"),
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "cva_plan_check.hip"), "-o", str(exe)])
+    trip = 65536
+    cases = {   # (paths, dates, real bytes, forced lanes) -> (one lane per path, date-parallel, log2 lanes)
+        (2 * trip, 256, 8, 0): (2 * trip, 0, 0),                      # the reference driver's own call (dp/cvaOpt.cu:12-15): two trips
+        (7 * trip // 4, 256, 8, 0): (0, 7 * trip // 4, 2),            # 7/4 trips: whole call date-parallel, lanes for ~4 waves per SIMD
+        (7 * trip // 4 + 1, 256, 4, 0): (7 * trip // 4 + 1, 0, 0),    # one path more, a remainder above 60 % of a trip: one lane per path
+        (4096, 256, 4, 0): (0, 4096, 5),                              # capped by the grid's 8-date chunks (32 of them)
+        (4096, 25, 8, 0): (0, 4096, 2),                               # 25 dates = 4 chunks: at most 4 lanes
+        (3 * trip // 4, 25, 4, 0): (0, 3 * trip // 4, 2),
+        (trip, 25, 4, 0): (trip, 0, 0),
+        (1250000, 256, 8, 0): (19 * trip, 1250000 - 19 * trip, 5),    # C5's shard of 8: 19 whole trips + 4816 paths date-parallel, one launch
+        (1250000, 50, 8, 0): (1250000, 0, 0),                         # short grid: no split
+        (10000000, 256, 8, 0): (10000000, 0, 0),                      # beyond 64 trips a trip is under 1.6 % of the call
+        (19 * trip + 45000, 256, 8, 0): (19 * trip + 45000, 0, 0),    # remainder above 60 % of a trip
+        (1000, 3, 8, 0): (1000, 0, 0),                                # one chunk: nothing to share
+        (1000, 256, 8, 1): (1000, 0, 0),
+        (1000, 256, 8, 16): (0, 1000, 4),
+        (1000, 25, 8, 64): (0, 1000, 2),
+        (0, 256, 8, 0): (0, 0, 0),
+    }
+    argv = [str(x) for k in cases for x in k]
+    out = subprocess.run([str(exe)] + argv, capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    got = {}
+    for ln in out.stdout.splitlines():
+        a, b = ln.split("->")
+        got[tuple(int(x) for x in a.split())] = tuple(int(x) for x in b.split())
+    assert got == cases
